@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs only in the build container, where the upstream repository is mounted
+read-only at /root/reference.  It imports ``models.net`` from there, feeds it
+seeded synthetic inputs (itermvs_amd.synthetic) and records inputs / outputs at
+the reference's own seams (forward hooks on its sub-modules, no source edits).
+Only DATA is written: inputs, expected outputs, the seeded weights and the
+numbers of the published DTU checkpoint.  The reference's code never ships.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("ITERMVS_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+
+from itermvs_amd import synthetic  # noqa: E402
+from itermvs_amd.schema import check_state_dict, strip_module_prefix  # noqa: E402
+
+import models.module as ref_module  # noqa: E402  (reference, read-only)
+import models.net as ref_net  # noqa: E402
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(arrays)} arrays")
+
+
+def build_reference(weights, iteration, test):
+    m = ref_net.Pipeline(iteration=iteration, test=test)
+    m.load_state_dict(weights, strict=True)
+    return m.eval() if test else m.train()
+
+
+# ----------------------------------------------------------------------------
+# 1. weights
+# ----------------------------------------------------------------------------
+def golden_weights():
+    w0 = synthetic.random_state_dict(0)
+    check_state_dict(w0)
+    save("weights_seed0.npz", **{k: npy(v) for k, v in w0.items()})
+    ckpt = torch.load(os.path.join(REF, "checkpoints/dtu/model_000015.ckpt"), map_location="cpu",
+                      weights_only=False)
+    wd = strip_module_prefix(ckpt["model"])
+    check_state_dict(wd)
+    save("weights_dtu.npz", **{k: npy(v) for k, v in wd.items()})
+    return w0, wd
+
+
+# ----------------------------------------------------------------------------
+# 2. differentiable_warping seam (module.py:68)
+# ----------------------------------------------------------------------------
+def golden_warp():
+    gen = torch.Generator().manual_seed(7)
+    full_h, full_w = 64, 96
+    out = {}
+    cases = [
+        # name, B, C, level of source map, N, sample-grid divisor, behind-camera view?
+        ("l1", 1, 16, 1, 4, 4, False),
+        ("l2_b2", 2, 32, 2, 4, 4, False),      # batch==2 branch, module.py:78-84
+        ("l3", 1, 48, 3, 2, 4, False),
+        ("init", 1, 48, 3, 32, 8, False),
+        ("l1_behind", 1, 16, 1, 4, 4, True),   # negative-depth patch lands in-bounds at level 1
+        ("l3_behind", 1, 48, 3, 2, 4, True),
+    ]
+    for name, b, c, lvl, n, div, behind in cases:
+        sample = synthetic.make_sample(batch=b, num_views=3, height=full_h, width=full_w, seed=3)
+        pm = sample["proj_matrices"][f"level_{lvl}"].clone()
+        if behind:
+            # turn the source camera by ~100 deg about y so a band of pixels projects behind it
+            ang = np.radians(100.0)
+            ry = torch.tensor([[np.cos(ang), 0, np.sin(ang), 0], [0, 1, 0, 0],
+                               [-np.sin(ang), 0, np.cos(ang), 600.0], [0, 0, 0, 1]], dtype=torch.float32)
+            pm[:, 1] = pm[:, 1] @ ry
+        h1, w1 = full_h >> lvl, full_w >> lvl
+        h, w = full_h // div, full_w // div
+        src = torch.randn((b, c, h1, w1), generator=gen)
+        depth = 425.0 + torch.rand((b, n, h, w), generator=gen) * 510.0
+        warped, mask = ref_module.differentiable_warping(src, pm[:, 1], pm[:, 0], depth, return_mask=True)
+        out.update({f"{name}.src": npy(src), f"{name}.src_proj": npy(pm[:, 1]), f"{name}.ref_proj": npy(pm[:, 0]),
+                    f"{name}.depth": npy(depth), f"{name}.warped": npy(warped), f"{name}.mask": npy(mask)})
+        frac0 = float((warped.abs().sum(1) == 0).float().mean())
+        print(f"  warp {name}: zero-fraction {frac0:.3f}, valid-fraction {float(mask.float().mean()):.3f}")
+    save("warp_cases.npz", **out)
+
+
+# ----------------------------------------------------------------------------
+# 3. small end-to-end run with every seam recorded
+# ----------------------------------------------------------------------------
+def record_e2e(weights, tag, height=64, width=96, views=3, iteration=2, seed=11):
+    model = build_reference(weights, iteration, test=True)
+    ev, up = model.iter_mvs.evaluation, model.iter_mvs.update
+    rec = {"corrnet_in": [], "pvw_in": [], "eval_out": [], "eval_samples": [], "logits": [],
+           "update_in": [], "update_out": [], "hidden_init": [], "depth_init": []}
+    hooks = []
+    for i, net in enumerate(ev.corr_conv1):
+        hooks.append(net.register_forward_pre_hook(lambda m, a, i=i: rec["corrnet_in"].append((i, a[0].clone()))))
+    hooks.append(ev.pixel_view_weight.register_forward_pre_hook(lambda m, a: rec["pvw_in"].append(a[0].clone())))
+    hooks.append(ev.register_forward_hook(lambda m, a, o: rec["eval_out"].append(o)))
+    hooks.append(ev.register_forward_pre_hook(lambda m, a: rec["eval_samples"].append(a[4])))
+    hooks.append(up.depth_head.register_forward_hook(lambda m, a, o: rec["logits"].append(o.clone())))
+    hooks.append(up.register_forward_pre_hook(lambda m, a: rec["update_in"].append([x.clone() for x in a[:3]])))
+    hooks.append(up.register_forward_hook(lambda m, a, o: rec["update_out"].append(o)))
+    feats = {}
+    hooks.append(model.feature_net.register_forward_hook(lambda m, a, o: feats.update(o)))
+    upw = []
+    hooks.append(model.iter_mvs.upsample.register_forward_hook(lambda m, a, o: upw.append(o.clone())))
+    orig_hi, orig_di = up.hidden_init, up.depth_init
+    up.hidden_init = lambda corr: rec["hidden_init"].append(orig_hi(corr)) or rec["hidden_init"][-1]
+    up.depth_init = lambda hid: rec["depth_init"].append(orig_di(hid)) or rec["depth_init"][-1]
+
+    sample = synthetic.make_sample(batch=1, num_views=views, height=height, width=width, seed=seed)
+    with torch.no_grad():
+        out = model(sample["imgs"], sample["proj_matrices"], sample["depth_min"], sample["depth_max"])
+    for h in hooks:
+        h.remove()
+
+    arrays = {
+        "imgs": npy(sample["imgs"]["level_0"]),
+        "depth_min": npy(sample["depth_min"]), "depth_max": npy(sample["depth_max"]),
+        "iteration": np.int64(iteration),
+        "out.depths_upsampled": npy(out["depths_upsampled"]),
+        "out.confidence_upsampled": npy(out["confidence_upsampled"]),
+        "upsample_logits": npy(upw[0]),
+    }
+    for l in (1, 2, 3):
+        arrays[f"proj.level_{l}"] = npy(sample["proj_matrices"][f"level_{l}"])
+        arrays[f"feat.level{l}"] = np.stack([npy(f) for f in feats[f"level{l}"]], axis=1)  # [B,V,C,h,w]
+    # Evaluation: call 0 = init branch, calls 1.. = iteration branch
+    vw, score0, depth0 = rec["eval_out"][0]
+    arrays.update({"init.samples": npy(rec["eval_samples"][0]), "init.view_weights": npy(vw),
+                   "init.score": npy(score0), "init.depth": npy(depth0)})
+    for s, x in enumerate(rec["pvw_in"]):
+        arrays[f"init.corr_view{s}"] = npy(x)
+    # CorrNet inputs: first the init call (index 2), then (0,1,2) per iteration
+    arrays["init.agg"] = npy(rec["corrnet_in"][0][1])
+    for it in range(iteration):
+        for j in range(3):
+            idx, x = rec["corrnet_in"][1 + it * 3 + j]
+            assert idx == j
+            arrays[f"iter{it}.agg.level{j + 1}"] = npy(x)
+        for l in (1, 2, 3):
+            arrays[f"iter{it}.samples.level{l}"] = npy(rec["eval_samples"][1 + it][f"level{l}"])
+        arrays[f"iter{it}.score"] = npy(rec["eval_out"][1 + it])
+        hid_in, nd_in, corr_in = rec["update_in"][it]
+        hid, nd, prob, conf, conf0 = rec["update_out"][it]
+        arrays.update({f"iter{it}.hidden_in": npy(hid_in), f"iter{it}.nd_in": npy(nd_in),
+                       f"iter{it}.hidden": npy(hid), f"iter{it}.nd": npy(nd),
+                       f"iter{it}.best": npy(torch.argmax(prob, dim=1, keepdim=True)),
+                       f"iter{it}.logits": npy(rec["logits"][1 + it])})
+        if conf is not None:
+            arrays[f"iter{it}.conf"] = npy(conf)
+    arrays["iter_last.prob"] = npy(rec["update_out"][-1][2])
+    arrays["hidden0"] = npy(rec["hidden_init"][0])
+    nd0, prob0 = rec["depth_init"][0]
+    arrays.update({"nd0": npy(nd0), "best0": npy(torch.argmax(prob0, dim=1, keepdim=True)),
+                   "logits0": npy(rec["logits"][0])})
+    save(f"e2e_small_{tag}.npz", **arrays)
+
+
+# ----------------------------------------------------------------------------
+# 4. convex upsample seam (module.py:127)
+# ----------------------------------------------------------------------------
+def golden_upsample():
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand((2, 1, 6, 10), generator=gen)
+    logits = torch.randn((2, 144, 6, 10), generator=gen)
+    w = torch.softmax(logits.view(2, 1, 9, 4, 4, 6, 10), dim=2)
+    y = ref_module.upsample(x, w)
+    inv_min = torch.tensor([1 / 425.0, 1 / 300.0]).view(2, 1, 1, 1)
+    inv_max = torch.tensor([1 / 935.0, 1 / 1200.0]).view(2, 1, 1, 1)
+    d = ref_module.depth_unnormalization(y, inv_min, inv_max)
+    nd = ref_module.depth_normalization(d, inv_min, inv_max)
+    save("upsample.npz", x=npy(x), logits=npy(logits), up=npy(y), depth=npy(d), renorm=npy(nd),
+         inv_min=npy(inv_min), inv_max=npy(inv_max))
+
+
+# ----------------------------------------------------------------------------
+# 5. BASELINE cfg-1 shape: seeded inputs are regenerated on the GPU box, only the
+#    expected outputs (sub-sampled) are stored
+# ----------------------------------------------------------------------------
+def golden_cfg1(weights, tag, scene=False):
+    model = build_reference(weights, 4, test=True)
+    if scene:   # photo-consistent textured plane instead of noise images
+        sample = synthetic.make_scene_sample(num_views=5, height=512, width=640, seed=0)
+        tag += "_scene"
+    else:
+        sample = synthetic.make_sample(batch=1, num_views=5, height=512, width=640, seed=0)
+    with torch.no_grad():
+        out = model(sample["imgs"], sample["proj_matrices"], sample["depth_min"], sample["depth_max"])
+    d, c = out["depths_upsampled"], out["confidence_upsampled"]
+    save(f"cfg1_{tag}.npz", depth_sub=npy(d[:, :, ::4, ::4]), conf_sub=npy(c[:, :, ::4, ::4]),
+         depth_sum=np.float64(d.double().sum().item()), conf_sum=np.float64(c.double().sum().item()),
+         depth_row=npy(d[0, 0, 257]), conf_row=npy(c[0, 0, 257]))
+
+
+# ----------------------------------------------------------------------------
+# 6. training step: forward (train mode) + full_loss + backward
+# ----------------------------------------------------------------------------
+def golden_train(weights):
+    gen = torch.Generator().manual_seed(21)
+    b, v, h, w, iters = 2, 3, 64, 96, 2
+    sample = synthetic.make_sample(batch=b, num_views=v, height=h, width=w, seed=4)
+    gt0 = 500.0 + 300.0 * torch.rand((b, 1, h, w), generator=gen)
+    gt2 = gt0[:, :, ::4, ::4].contiguous()
+    m0 = (torch.rand((b, 1, h, w), generator=gen) > 0.2).float()
+    m2 = m0[:, :, ::4, ::4].contiguous()
+    arrays = {"imgs": npy(sample["imgs"]["level_0"]), "gt0": npy(gt0), "gt2": npy(gt2), "m0": npy(m0),
+              "m2": npy(m2), "depth_min": npy(sample["depth_min"]), "depth_max": npy(sample["depth_max"]),
+              "iteration": np.int64(iters)}
+    for l in (1, 2, 3):
+        arrays[f"proj.level_{l}"] = npy(sample["proj_matrices"][f"level_{l}"])
+    for regress in (True, False):
+        model = build_reference(weights, iters, test=False)
+        out = model(sample["imgs"], sample["proj_matrices"], sample["depth_min"], sample["depth_max"])
+        loss = ref_net.full_loss(out["depths"], out["depths_upsampled"], out["confidences"],
+                                 {"level_0": gt0, "level_2": gt2}, {"level_0": m0, "level_2": m2},
+                                 sample["depth_min"], sample["depth_max"], regress)
+        loss.backward()
+        tag = "regress" if regress else "noregress"
+        arrays[f"{tag}.loss"] = np.float64(loss.item())
+        names, norms = [], []
+        for k, p in model.named_parameters():
+            names.append(k)
+            norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+        arrays[f"{tag}.grad_names"] = np.array(names)
+        arrays[f"{tag}.grad_norms"] = np.array(norms, dtype=np.float64)
+        if regress:
+            arrays["train.depths_upsampled"] = npy(out["depths_upsampled"][0])
+            arrays["train.confidence_upsampled"] = npy(out["confidence_upsampled"])
+            arrays["train.initial"] = npy(out["depths"]["initial"][0])
+            for i, d in enumerate(out["depths"]["combine"]):
+                arrays[f"train.combine{i}"] = npy(d)
+            for i, cf in enumerate(out["confidences"]):
+                arrays[f"train.conf{i}"] = npy(cf)
+            arrays["train.best_last"] = npy(torch.argmax(out["depths"]["probability"][-1], 1, keepdim=True))
+            arrays["train.running_mean_conv1"] = npy(model.feature_net.conv1.bn.running_mean)
+        print(f"  train {tag}: loss {loss.item():.6f}")
+    save("train_small.npz", **arrays)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    w0, wd = golden_weights()
+    golden_warp()
+    golden_upsample()
+    record_e2e(w0, "seed0")
+    record_e2e(wd, "dtu")
+    golden_cfg1(w0, "seed0")
+    golden_cfg1(wd, "dtu")
+    golden_cfg1(wd, "dtu", scene=True)
+    golden_train(w0)
+
+
+if __name__ == "__main__":
+    main()
