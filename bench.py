@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Benchmark of the IterMVS hot path on MI355X: depth-maps/s at BASELINE cfg 1/2
+(1 reference + 4 source views, 640x512, 4 GRU iterations, test mode).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of ``Pipeline(test=True).forward`` over one batch of synthetic reference
+views that is already resident in HBM.  One process per GPU, reference views sharded over the
+ranks with no data-path collective (weak scaling); the timed region is bracketed by a barrier +
+device synchronise and the maximum over ranks is reported.  Rank 0 prints ONE JSON line with
+the throughput, the HBM roofline of the dominant hand-written kernel (itermvs_corr_iter, timed
+with HIP events on its launch stream inside the timed region) and a CPU baseline (the oracle,
+``kind: port``, timed on this box's host cores over a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+
+
+def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int):
+    """DESIGN.md 'Algorithmic bytes': every required tensor moved once, fp32.
+    Returns (bytes per corr_iter launch, bytes per corr_init launch, bytes per depth map)."""
+    p1, p2, p3 = (h // 2) * (w // 2), (h // 4) * (w // 4), (h // 8) * (w // 8)
+    e = 4
+    it = batch * (s * (16 * p1 + 32 * p2 + 48 * p3) * e     # source pyramids, each view once
+                  + 96 * p2 * e                             # packed reference features at 1/4 res
+                  + p2 * 4                                  # normalised depth (hypotheses built in-kernel)
+                  + s * p2 * 4                              # view weights
+                  + 80 * p2 * 4)                            # [B,10,8,H/4,W/4] aggregated correlations out
+    init = batch * (s * 48 * p3 * e + 48 * p3 * e           # level-3 source + reference features
+                    + s * 8 * 32 * p3 * 4)                  # per-view correlation volume out
+    return it, init, (init + iters * it) / batch
+
+
+def cpu_baseline(args, target_seconds: float = 15.0):
+    """Time the CPU oracle (port of the reference's PyTorch-CPU path) on the same workload."""
+    import torch
+    from itermvs_amd import synthetic
+    from oracle import itermvs_oracle as O
+
+    weights = synthetic.random_state_dict(0)
+    s = synthetic.make_sample(batch=1, num_views=args.views, height=args.height, width=args.width, seed=0)
+    run = lambda: O.pipeline_forward(weights, s["imgs"], s["proj_matrices"], s["depth_min"], s["depth_max"],
+                                     iteration=args.iters, test=True)
+    with torch.no_grad():
+        run()                                   # warm-up
+        t0 = time.perf_counter()
+        run()
+        first = time.perf_counter() - t0
+        n = max(2, min(20, int(target_seconds / max(first, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            run()
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "depth-maps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} depth maps of the same cfg-1 workload after 2 warm-ups "
+                      f"(oracle/itermvs_oracle.py, torch-CPU, {os.cpu_count()} logical CPUs on the box)",
+            "s_per_depth_map": dt / n}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--views", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=1, help="reference views per step and GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from itermvs_amd import ops, shard, synthetic
+    from itermvs_amd.net import Pipeline
+
+    rank, local_rank, world = shard.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    model = Pipeline(iteration=args.iters, test=True)
+    model.load_state_dict(synthetic.random_state_dict(0))
+    model = model.to(dev).eval()
+
+    # this rank's shard of the synthetic reference views, resident in HBM before timing starts
+    n_resident = 4
+    samples = []
+    for i in range(n_resident):
+        s = synthetic.make_sample(batch=args.batch, num_views=args.views, height=args.height, width=args.width,
+                                  seed=rank * n_resident + i)
+        samples.append(({k: v.to(dev) for k, v in s["imgs"].items()},
+                        {k: v.to(dev) for k, v in s["proj_matrices"].items()},
+                        s["depth_min"].to(dev), s["depth_max"].to(dev)))
+
+    sink = []
+
+    def step(i: int) -> None:
+        imgs, projs, dmin, dmax = samples[i % n_resident]
+        out = model(imgs, projs, dmin, dmax)
+        sink[:] = [out["depths_upsampled"], out["confidence_upsampled"]]
+
+    # HIP-event pairs around the fused kernels' launches (on their launch stream); the samples of
+    # the warm-up steps are dropped so the figures cover exactly the timed region
+    per_step = args.iters + 1
+    ops.profile_enable((args.steps + args.warmup) * per_step + 8)
+    elapsed = shard.timed_steps(step, args.steps, args.warmup)
+    prof = ops.profile_collect(max_samples=(args.steps + args.warmup) * per_step + 8)[args.warmup * per_step:]
+    ops.profile_enable(0)
+    maps = world * args.steps * args.batch
+    value = maps / elapsed
+
+    s_views = args.views - 1
+    b_iter, b_init, b_map = algorithmic_bytes(s_views, args.height, args.width, args.batch, args.iters)
+    t_iter = [ms for kind, ms in prof if kind == 1]
+    t_init = [ms for kind, ms in prof if kind == 2]
+    roofline = None
+    if t_iter:
+        avg_ms = sum(t_iter) / len(t_iter)
+        achieved = b_iter / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "itermvs_corr_iter (corr_iter_kernel<32>)", "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": b_iter, "avg_launch_ms": avg_ms, "launches_timed": len(t_iter),
+                    "timing": "hipEvent pairs on the launch stream inside the timed region"}
+        if t_init:
+            init_ms = sum(t_init) / len(t_init)
+            roofline["corr_init"] = {"avg_launch_ms": init_ms, "algorithmic_bytes_per_launch": b_init,
+                                     "achieved": b_init / (init_ms * 1e-3) / 1e9}
+
+    if rank == 0:
+        result = {
+            "metric": "depth-maps/sec (ref-views/s) at 5-view 640x512, 4 iters",
+            "value": value, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE cfg 2 (= cfg 1 on 1xMI355X): 1 ref + {s_views} src views, "
+                                   f"{args.width}x{args.height}, {args.iters} GRU iterations, test mode, "
+                                   f"random-init weights, {args.batch} ref view(s) per step and GPU",
+                       "views": args.views, "height": args.height, "width": args.width, "iterations": args.iters,
+                       "batch_per_gpu": args.batch, "parallelism": f"ref-view sharding x{world}, no collective",
+                       "algorithmic_MB_per_depth_map": b_map / 1e6},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args)
+            result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
+        print(json.dumps(result), flush=True)
+    shard.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,231 @@
+/*
+ * itermvs_hip.h -- C ABI of libitermvs_hip.so (hand-written gfx950 HIP kernels for the
+ * IterMVS matching hot path).
+ *
+ * The reference (FangjinhuaWang/IterMVS) has NO native / FFI interface: its hot path is
+ * Python calling stock PyTorch ops.  The entry points below are therefore the seams of the
+ * reference's Python functions, lowered to plain pointers + sizes; each one cites the
+ * reference code it replaces (paths relative to the reference repository).  The ctypes
+ * binding a maintainer of the reference would add is shown in INTEGRATION.md and lives in
+ * itermvs_amd/_lib.py.
+ *
+ * Conventions:
+ *   - every function ENQUEUES work on `stream` and returns immediately: no allocation, no
+ *     synchronisation, no global mutable state (re-entrant across streams / threads);
+ *   - all tensors are caller-owned DEVICE buffers of fp32 unless stated, borrowed for the
+ *     duration of the enqueue; inputs are never written;
+ *   - return value 0 = ok, negative = itermvs_status (bad dims, null pointer, unsupported
+ *     channel count, misalignment); nothing is thrown;
+ *   - `void* stream` is a hipStream_t (NULL = default stream).
+ */
+#ifndef ITERMVS_HIP_H
+#define ITERMVS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ITERMVS_ABI_VERSION 3
+#define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
+#define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
+#define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
+#define ITERMVS_PROB_BINS 256  /* models/itermvs.py:134 */
+#define ITERMVS_WINDOW_RADIUS 4 /* models/itermvs.py:135 */
+
+typedef enum itermvs_status {
+    ITERMVS_OK = 0,
+    ITERMVS_ERR_NULL = -1,        /* required pointer is NULL                     */
+    ITERMVS_ERR_DIMS = -2,        /* non-positive / inconsistent dimension        */
+    ITERMVS_ERR_CHANNELS = -3,    /* C not in {16,32,48} (C/G must be 2,4,6)      */
+    ITERMVS_ERR_VIEWS = -4,       /* S < 1 or S > ITERMVS_MAX_SRC                 */
+    ITERMVS_ERR_ALIGN = -5,       /* pointer / stride not aligned for vector path */
+    ITERMVS_ERR_LAYOUT = -6,      /* fused kernels need channels-last features    */
+    ITERMVS_ERR_LAUNCH = -7       /* hipLaunchKernel failed (see hipGetLastError) */
+} itermvs_status;
+
+/* library / ABI identification */
+int itermvs_version(void);
+const char* itermvs_error_string(int status);
+
+/* A 4-D feature map addressed with ELEMENT strides, so NCHW and channels-last (NHWC) views
+ * of torch tensors are both accepted.  The fused kernels require sc == 1 (channels-last). */
+typedef struct itermvs_fmap {
+    const float* data;
+    int64_t sb, sc, sy, sx;   /* strides of batch, channel, row, column (elements) */
+    int32_t C, H, W;
+    int32_t _pad;
+} itermvs_fmap;
+
+/* The S source-view feature maps of one pyramid level: per-view base pointers sharing one
+ * set of element strides (views of a [B,V,...] tensor or separately allocated maps). */
+typedef struct itermvs_level_src {
+    const float* view[ITERMVS_MAX_SRC];
+    int64_t sb, sc, sy, sx;
+    int32_t C, H, W;
+    int32_t _pad;
+} itermvs_level_src;
+
+/* ------------------------------------------------------------------------------------------
+ * itermvs_compose_proj -- models/module.py:77-90
+ *   proj = src_proj @ inverse(ref_proj); rot = proj[:3,:3]; trans = proj[:3,3]
+ * `mats` is [n_sets, V, 4, 4] row-major (view 0 = reference); `out` is [n_sets, V-1, 12]
+ * holding rows of [rot | trans].  Inverse and product are evaluated in fp64 and rounded
+ * once to fp32.  `nan_flag` (device int32, may be NULL) is OR-ed with 1 when a result is
+ * NaN -- the deferred form of the reference's host-side asserts (module.py:83,87).
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_compose_proj(const float* mats, int32_t n_sets, int32_t V, float* out,
+                         int32_t* nan_flag, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * itermvs_warp -- models/module.py:68-125  differentiable_warping(src_fea, src_proj,
+ *   ref_proj, depth_samples, return_mask)
+ * Plain (un-fused) seam: writes the warped volume out[B,C,N,H,W] (contiguous) and, when
+ * `mask` != NULL, the validity mask [B,N,H,W] as uint8.  `proj` = [B,12] from
+ * itermvs_compose_proj.  Any strides / any C.  Kept for API completeness and unit tests;
+ * the engine itself never materialises the warped volume.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_warp(const itermvs_fmap* src, const float* proj, const float* depth,
+                 int32_t B, int32_t N, int32_t H, int32_t W, float* out, uint8_t* mask,
+                 void* stream);
+
+/* gradient of itermvs_warp w.r.t. src (grid math is no_grad in the reference, module.py:77):
+ * grad_src[B,C,H1,W1] (contiguous NCHW, must be zero-filled) += scatter of grad_out[B,C,N,H,W] */
+int itermvs_warp_backward(const float* grad_out, const float* proj, const float* depth,
+                          int32_t B, int32_t C, int32_t N, int32_t H, int32_t W,
+                          int32_t H1, int32_t W1, float* grad_src, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * itermvs_ref_quarter -- models/itermvs.py:95-98
+ * Reference-view features of the three pyramid levels resampled onto the 1/4 grid and packed
+ * channels-last: out[B,H,W,C1+C2+C3] (level 1: x0.5 bilinear == 2x2 mean; level 2: copy;
+ * level 3: x2 bilinear, align_corners=False).  H,W = size of level 2.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_ref_quarter(const itermvs_fmap* ref_l1, const itermvs_fmap* ref_l2,
+                        const itermvs_fmap* ref_l3, int32_t B, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * itermvs_corr_iter -- models/itermvs.py:84-120 (Evaluation.forward, iteration branch, up to
+ * but excluding CorrNet) fused with module.py:68-125 and, optionally, the hypothesis
+ * construction of itermvs.py:290-293.
+ * For every 1/4-res pixel, level l in {1,2,3}, hypothesis n, group g:
+ *   out_l[b,n,g,y,x] = sum_s w[b,s,y,x] * corr_s / (1e-5 + sum_s w[b,s,y,x]),
+ *   corr_s = mean_{c in group g} warp(src_l[s])[c] * ref_q[c]
+ * No warped volume / cost volume is written to memory.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct itermvs_corr_iter_params {
+    int32_t B, S, H, W;                        /* sample grid = level-2 size              */
+    int32_t N[3];                              /* hypotheses per level (reference: 4,4,2) */
+    int32_t _pad0;
+    itermvs_level_src src[3];                  /* [level-1]; channels-last (sc == 1)      */
+    const float* ref_q;                        /* [B,H,W,C1+C2+C3] from itermvs_ref_quarter */
+    const float* proj;                         /* [3,B,S,12] from itermvs_compose_proj    */
+    const float* view_w;                       /* [B,S,H,W] contiguous                    */
+    const float* depth[3];                     /* explicit hypotheses [B,N_l,H,W] or NULL */
+    const float* norm_depth;                   /* normalised depth at norm_depth[b*norm_depth_sb + y*W + x]; used where depth[l] == NULL */
+    int64_t norm_depth_sb;                     /* batch stride (elements) of norm_depth   */
+    float offsets[3][ITERMVS_MAX_HYP];         /* normalised offsets corr_interval*interval_scale (itermvs.py:229-235) */
+    const float* inv_depth_min;                /* device [B]  1/depth_min                 */
+    const float* inv_depth_max;                /* device [B]  1/depth_max                 */
+    float* out[3];                             /* [B,N_l,8,H,W] contiguous (CorrNet input [B*N,8,H,W]) */
+} itermvs_corr_iter_params;
+
+int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * itermvs_corr_init -- models/itermvs.py:48-51 (+ :11-19 DepthInitialization when depth==NULL)
+ * Per-view group correlation at level 3 for all N hypotheses:
+ *   out[b,s,n,g,y,x]  (== PixelViewWeight input [B*S*N, 8, H, W])
+ * ------------------------------------------------------------------------------------------ */
+typedef struct itermvs_corr_init_params {
+    int32_t B, S, H, W, N;                     /* sample grid = level-3 size; N = 32      */
+    int32_t _pad0;
+    itermvs_level_src src;                     /* level-3 source features, channels-last  */
+    itermvs_fmap ref;                          /* level-3 reference features (any strides) */
+    const float* proj;                         /* [B,S,12]                                */
+    const float* depth;                        /* [B,N,H,W] or NULL (generate uniform inverse depth) */
+    const float* inv_depth_min;                /* device [B] */
+    const float* inv_depth_max;                /* device [B] */
+    float* out;                                /* [B,S,N,8,H,W] */
+} itermvs_corr_init_params;
+
+int itermvs_corr_init(const itermvs_corr_init_params* p, void* stream);
+
+/* itermvs_view_aggregate -- models/itermvs.py:59-69
+ *   out[b,n,g,p] = sum_s corr[b,s,n,g,p] * w[b,s,p] / (1e-5 + sum_s w[b,s,p])
+ * corr [B,S,N,8,P], w [B,S,P] (PixelViewWeight output at 1/8 res), out [B,N,8,P]. */
+int itermvs_view_aggregate(const float* corr, const float* w, int32_t S, int32_t B, int32_t N,
+                           int32_t P, float* out, void* stream);
+
+/* itermvs_softmax_max -- models/itermvs.py:347-348 (PixelViewWeight tail)
+ *   out[m,p] = max_n softmax_n(x[m,n,p]);  x [M,N,P] contiguous, out [M,P]. */
+int itermvs_softmax_max(const float* x, int32_t M, int32_t N, int32_t P, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * itermvs_prob_regress -- models/itermvs.py:171-190 and :201-219
+ *   p = softmax(logits over 256 bins); k* = first argmax p; window k*-4..k*+4 clamped to
+ *   [0,255] (duplicates kept); nd = (sum k p_k / (1e-6 + sum p_k)) / 255
+ * logits [B,256,H,W] addressed with element strides (sb, sc, sp) where p = y*W+x must be
+ * linear (sp = stride between neighbouring pixels).  Outputs (each may be NULL):
+ *   nd_out0 / nd_out1: two destinations for the normalised depth, written at
+ *     nd_outX[b*nd_sbX + p] (lets the GRU input buffers be filled in place);
+ *   prob [B,256,P] contiguous (training / API parity);  best [B,P] int64 arg-max index.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_prob_regress(const float* logits, int64_t sb, int64_t sc, int64_t sp, int32_t B,
+                         int32_t P, float* nd_out0, int64_t nd_sb0, float* nd_out1,
+                         int64_t nd_sb1, float* prob, int64_t* best, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ConvGRU gates -- models/module.py:59-66 (the three 3x3 dilated convolutions stay in MIOpen)
+ * itermvs_gru_rh :  rh[b,c,p] = sigmoid(zr[b,32+c,p]) * h[b,c,p]           (r * h, :63-64)
+ * itermvs_gru_out:  h[b,c,p]  = (1-z) * h + z * tanh(q),  z = sigmoid(zr[b,c,p])   (:62,64,65)
+ * zr = [B,2*hid,P] (z pre-activations then r pre-activations), q = [B,hid,P];
+ * h / rh are addressed as base + b*sb + c*P + p so they can live inside the [B,43,P]
+ * concatenated GRU input buffers.  itermvs_gru_out updates h in place and, when h_copy != NULL,
+ * also stores the new state contiguously at h_copy[B,hid,P] (input of the MIOpen head convs).
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_gru_rh(const float* zr, const float* h, int64_t h_sb, float* rh, int64_t rh_sb,
+                   int32_t B, int32_t hid, int32_t P, void* stream);
+int itermvs_gru_out(const float* zr, const float* q, float* h, int64_t h_sb, float* h_copy,
+                    int32_t B, int32_t hid, int32_t P, void* stream);
+
+/* itermvs_pack_scores -- models/itermvs.py:122-124,193: concatenates the three CorrNet outputs
+ * ([B,N_l,P] each) into channels [ch0, ch0+N0+N1+N2) of up to two [B,Ctot,P] buffers. */
+int itermvs_pack_scores(const float* s0, const float* s1, const float* s2, const int32_t N[3],
+                        int32_t B, int32_t P, float* dst0, float* dst1, int64_t dst_sb,
+                        int32_t ch0, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * itermvs_convex_upsample -- models/itermvs.py:262-264 (softmax over the 9 taps) +
+ * models/module.py:127-140 (upsample) + models/module.py:148-152 (depth_unnormalization)
+ *   logits [B,144,H,W] (element strides sb,sc,sy,sx; channel = k*16 + i*4 + j)
+ *   nd     [B,1,H,W] at nd + b*nd_sb + y*W + x
+ *   depth  [B,1,4H,4W] contiguous = 1/(inv_max + up*(inv_min-inv_max));
+ *   when `norm_out` != NULL the un-normalised convex combination is also stored there.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_convex_upsample(const float* logits, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                            const float* nd, int64_t nd_sb, const float* inv_depth_min,
+                            const float* inv_depth_max, int32_t B, int32_t H, int32_t W,
+                            float* depth, float* norm_out, void* stream);
+
+/* itermvs_bilinear_up -- F.interpolate(x, scale_factor=s, mode='bilinear') for integer s
+ * (models/itermvs.py:56,161,323): x [M,H,W] -> out [M,s*H,s*W]; `act`: 0 none, 1 tanh
+ * (hidden_init, itermvs.py:162). */
+int itermvs_bilinear_up(const float* x, int32_t M, int32_t H, int32_t W, int32_t scale,
+                        int32_t act, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optional per-launch timing (HIP events recorded on the launch stream around the kernels of
+ * itermvs_corr_iter / itermvs_corr_init).  Used by bench.py for the roofline figure.
+ * itermvs_profile_enable(n) allocates n event pairs (n = 0 disables and frees);
+ * itermvs_profile_collect synchronises the events and returns the number of samples copied:
+ * kind[i] (1 = corr_iter, 2 = corr_init) and ms[i].
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_profile_enable(int32_t capacity);
+int itermvs_profile_collect(int32_t* kind, float* ms, int32_t max_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ITERMVS_HIP_H */

@@ -1,0 +1,128 @@
+"""ctypes binding of libitermvs_hip.so (the C ABI declared in include/itermvs_hip.h).
+
+This is the binding a maintainer of the reference would add next to ``models/module.py`` to
+call the HIP path.  Loading fails LOUDLY: there is no CPU or PyTorch
+fallback anywhere in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+MAX_SRC = 16
+MAX_HYP = 8
+GROUPS = 8
+ABI_VERSION = 3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libitermvs_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class FMap(C.Structure):
+    """itermvs_fmap"""
+    _fields_ = [("data", C.c_void_p), ("sb", C.c_int64), ("sc", C.c_int64), ("sy", C.c_int64),
+                ("sx", C.c_int64), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("_pad", C.c_int32)]
+
+
+class LevelSrc(C.Structure):
+    """itermvs_level_src"""
+    _fields_ = [("view", C.c_void_p * MAX_SRC), ("sb", C.c_int64), ("sc", C.c_int64), ("sy", C.c_int64),
+                ("sx", C.c_int64), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("_pad", C.c_int32)]
+
+
+class CorrIterParams(C.Structure):
+    """itermvs_corr_iter_params"""
+    _fields_ = [("B", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("N", C.c_int32 * 3), ("_pad0", C.c_int32),
+                ("src", LevelSrc * 3),
+                ("ref_q", C.c_void_p), ("proj", C.c_void_p), ("view_w", C.c_void_p),
+                ("depth", C.c_void_p * 3), ("norm_depth", C.c_void_p), ("norm_depth_sb", C.c_int64),
+                ("offsets", (C.c_float * MAX_HYP) * 3),
+                ("inv_depth_min", C.c_void_p), ("inv_depth_max", C.c_void_p),
+                ("out", C.c_void_p * 3)]
+
+
+class CorrInitParams(C.Structure):
+    """itermvs_corr_init_params"""
+    _fields_ = [("B", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("N", C.c_int32),
+                ("_pad0", C.c_int32),
+                ("src", LevelSrc), ("ref", FMap),
+                ("proj", C.c_void_p), ("depth", C.c_void_p),
+                ("inv_depth_min", C.c_void_p), ("inv_depth_max", C.c_void_p), ("out", C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/itermvs_hip.h declares
+PROTOTYPES = {
+    "itermvs_version": (C.c_int, []),
+    "itermvs_error_string": (C.c_char_p, [C.c_int]),
+    "itermvs_compose_proj": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "itermvs_warp": (C.c_int, [C.POINTER(FMap), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "itermvs_warp_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p, C.c_void_p]),
+    "itermvs_ref_quarter": (C.c_int, [C.POINTER(FMap)] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
+    "itermvs_corr_iter": (C.c_int, [C.POINTER(CorrIterParams), C.c_void_p]),
+    "itermvs_corr_init": (C.c_int, [C.POINTER(CorrInitParams), C.c_void_p]),
+    "itermvs_view_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_void_p, C.c_void_p]),
+    "itermvs_softmax_max": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "itermvs_prob_regress": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "itermvs_gru_rh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                 C.c_int32, C.c_void_p]),
+    "itermvs_gru_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_void_p]),
+    "itermvs_pack_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "itermvs_convex_upsample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "itermvs_bilinear_up": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                      C.c_void_p]),
+    "itermvs_profile_enable": (C.c_int, [C.c_int32]),
+    "itermvs_profile_collect": (C.c_int, [C.POINTER(C.c_int32), c_float_p, C.c_int32]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and type every entry point.  Raises HipLibraryError if the
+    library is missing, cannot be loaded, lacks a declared symbol or has another ABI version."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C itermvs_amd/csrc`).  The IterMVS engine has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.itermvs_version()
+    if got != ABI_VERSION:
+        raise HipLibraryError(f"ABI mismatch: library reports {got}, binding expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    """Map a non-zero C return to RuntimeError (SURVEY.md 8(b) error convention)."""
+    if status != 0:
+        msg = load().itermvs_error_string(status).decode()
+        raise RuntimeError(f"{what} failed: {msg} (status {status})")

@@ -1,0 +1,113 @@
+// Shared device helpers for libitermvs_hip.so (gfx950 / CDNA4, wave64).
+// Built with -ffp-contract=off: every a*b+c below is two roundings unless written as fmaf(),
+// so the coordinate math follows the reference's op-by-op fp32 evaluation.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "itermvs_hip.h"
+
+#define ITERMVS_RETURN_IF(cond, code) \
+    do {                              \
+        if (cond) return (code);      \
+    } while (0)
+
+static inline int itermvs_launch_status() {
+    return hipGetLastError() == hipSuccess ? ITERMVS_OK : ITERMVS_ERR_LAUNCH;
+}
+
+// timing hooks (profile.cpp)
+void itermvs_profile_begin(int kind, hipStream_t stream);
+void itermvs_profile_end(int kind, hipStream_t stream);
+
+namespace itermvs {
+
+// Source-map sampling position of one (pixel, hypothesis, view): models/module.py:99-115
+// followed by grid_sample's align_corners=True un-normalisation (GridSampler.h:31).
+struct WarpGeom {
+    float xr, yr;       // W1/W, H1/H                        (module.py:95-96)
+    float half_w, half_h;  // (W1-1)/2, (H1-1)/2            (module.py:112-113)
+    float w1m1, h1m1;   // W1-1, H1-1
+    float gw, gh;       // sample-grid W, H as float         (module.py:106-107)
+};
+
+__device__ __forceinline__ WarpGeom make_geom(int W, int H, int W1, int H1) {
+    WarpGeom g;
+    g.xr = (float)((double)W1 / (double)W);
+    g.yr = (float)((double)H1 / (double)H);
+    g.half_w = (float)((double)(W1 - 1) / 2.0);
+    g.half_h = (float)((double)(H1 - 1) / 2.0);
+    g.w1m1 = (float)(W1 - 1);
+    g.h1m1 = (float)(H1 - 1);
+    g.gw = (float)W;
+    g.gh = (float)H;
+    return g;
+}
+
+// rot @ (xs, ys, 1): k-ordered fma chain like a BLAS dot (module.py:99)
+__device__ __forceinline__ void ray_dir(const float* __restrict__ m, float xs, float ys, float& rx,
+                                        float& ry, float& rz) {
+    rx = fmaf(m[1], ys, m[0] * xs) + m[2];
+    ry = fmaf(m[5], ys, m[4] * xs) + m[6];
+    rz = fmaf(m[9], ys, m[8] * xs) + m[10];
+}
+
+// returns the un-normalised source coordinates (ix, iy); `valid` follows module.py:105,110-111
+__device__ __forceinline__ void project(const WarpGeom& g, const float* __restrict__ m, float rx, float ry,
+                                        float rz, float d, float& ix, float& iy, bool* valid) {
+    float X = rx * d + m[3];
+    float Y = ry * d + m[7];
+    float Z = rz * d + m[11];
+    const bool front = Z > 1e-2f;
+    if (!front) {  // module.py:105-108: sample-grid W/H, not the source map's
+        X = g.gw;
+        Y = g.gh;
+        Z = 1.0f;
+    }
+    const float px = X / Z;
+    const float py = Y / Z;
+    if (valid) *valid = front && px >= 0.0f && px < g.gw && py >= 0.0f && py < g.gh;
+    const float gx = px / g.half_w - 1.0f;
+    const float gy = py / g.half_h - 1.0f;
+    ix = ((gx + 1.0f) * 0.5f) * g.w1m1;
+    iy = ((gy + 1.0f) * 0.5f) * g.h1m1;
+}
+
+// The four bilinear taps of grid_sample(bilinear, zeros, align_corners=True): clamped integer
+// coordinates plus weights already zeroed for out-of-range taps (NaN/inf -> all zero).
+struct Taps {
+    int x0, x1, y0, y1;
+    float nw, ne, sw, se;
+};
+
+__device__ __forceinline__ Taps make_taps(float ix, float iy, int W1, int H1) {
+    Taps t;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const float fx1 = fx0 + 1.0f, fy1 = fy0 + 1.0f;
+    const float wmax = (float)(W1 - 1), hmax = (float)(H1 - 1);
+    const bool vx0 = fx0 >= 0.0f && fx0 <= wmax;
+    const bool vx1 = fx1 >= 0.0f && fx1 <= wmax;
+    const bool vy0 = fy0 >= 0.0f && fy0 <= hmax;
+    const bool vy1 = fy1 >= 0.0f && fy1 <= hmax;
+    const float ax = fx1 - ix, bx = ix - fx0;
+    const float ay = fy1 - iy, by = iy - fy0;
+    t.nw = (vx0 && vy0) ? ax * ay : 0.0f;
+    t.ne = (vx1 && vy0) ? bx * ay : 0.0f;
+    t.sw = (vx0 && vy1) ? ax * by : 0.0f;
+    t.se = (vx1 && vy1) ? bx * by : 0.0f;
+    t.x0 = vx0 ? (int)fx0 : 0;
+    t.x1 = vx1 ? (int)fx1 : 0;
+    t.y0 = vy0 ? (int)fy0 : 0;
+    t.y1 = vy1 ? (int)fy1 : 0;
+    return t;
+}
+
+// models/module.py:148-152
+__device__ __forceinline__ float unnormalize_depth(float nd, float inv_min, float inv_max) {
+    return 1.0f / (inv_max + nd * (inv_min - inv_max));
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace itermvs

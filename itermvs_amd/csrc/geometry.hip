@@ -1,0 +1,226 @@
+// Camera composition, the plain (un-fused) warp seam and reference-feature resampling.
+#include "common.hpp"
+
+namespace itermvs {
+
+// ---------------------------------------------------------------------------------------------
+// compose_proj: out[set, s-1, 0:12] = rows of (src_s @ inverse(ref))[:3, :4]   (module.py:77-90)
+// One thread per (set, source view); 4x4 Gauss-Jordan with partial pivoting in fp64.
+// ---------------------------------------------------------------------------------------------
+__global__ void compose_proj_kernel(const float* __restrict__ mats, int n_sets, int V, float* __restrict__ out,
+                                    int* __restrict__ nan_flag) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = V - 1;
+    if (t >= n_sets * S) return;
+    const int set = t / S, s = t - set * S + 1;
+    const float* ref = mats + (size_t)set * V * 16;
+    const float* src = ref + (size_t)s * 16;
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            a[i][j] = (double)ref[i * 4 + j];
+            a[i][4 + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        double best = fabs(a[c][c]);
+        for (int r = c + 1; r < 4; ++r)
+            if (fabs(a[r][c]) > best) {
+                best = fabs(a[r][c]);
+                piv = r;
+            }
+        if (piv != c)
+            for (int j = 0; j < 8; ++j) {
+                double tmp = a[c][j];
+                a[c][j] = a[piv][j];
+                a[piv][j] = tmp;
+            }
+        const double inv = 1.0 / a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+        for (int r = 0; r < 4; ++r)
+            if (r != c) {
+                const double f = a[r][c];
+                for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+            }
+    }
+    bool bad = false;
+    float* o = out + (size_t)t * 12;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc += (double)src[i * 4 + k] * a[k][4 + j];
+            const float v = (float)acc;
+            bad |= (v != v);
+            o[i * 4 + j] = v;
+        }
+    if (bad && nan_flag) atomicOr(nan_flag, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// warp: thread per (b, n, y, x); loops over channels.  out[B,C,N,H,W]      (module.py:68-125)
+// ---------------------------------------------------------------------------------------------
+__global__ void warp_kernel(itermvs_fmap src, const float* __restrict__ proj, const float* __restrict__ depth,
+                            int B, int N, int H, int W, float* __restrict__ out, uint8_t* __restrict__ mask) {
+    const int64_t total = (int64_t)B * N * H * W;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int x = (int)(t % W);
+    const int y = (int)((t / W) % H);
+    const int n = (int)((t / ((int64_t)W * H)) % N);
+    const int b = (int)(t / ((int64_t)W * H * N));
+    const WarpGeom g = make_geom(W, H, src.W, src.H);
+    const float* m = proj + (size_t)b * 12;
+    float rx, ry, rz, ix, iy;
+    ray_dir(m, (float)x * g.xr, (float)y * g.yr, rx, ry, rz);
+    bool valid;
+    project(g, m, rx, ry, rz, depth[t], ix, iy, &valid);
+    if (mask) mask[t] = valid ? 1 : 0;
+    const Taps tp = make_taps(ix, iy, src.W, src.H);
+    const float* base = src.data + (int64_t)b * src.sb;
+    const int64_t o00 = tp.y0 * src.sy + tp.x0 * src.sx, o01 = tp.y0 * src.sy + tp.x1 * src.sx;
+    const int64_t o10 = tp.y1 * src.sy + tp.x0 * src.sx, o11 = tp.y1 * src.sy + tp.x1 * src.sx;
+    const int64_t plane = (int64_t)N * H * W;
+    float* o = out + ((int64_t)b * src.C * N + n) * H * W + (int64_t)y * W + x;
+    for (int c = 0; c < src.C; ++c) {
+        const float* f = base + c * src.sc;
+        const float v = fmaf(tp.se, f[o11], fmaf(tp.sw, f[o10], fmaf(tp.ne, f[o01], tp.nw * f[o00])));
+        o[c * plane] = v;
+    }
+}
+
+// gradient w.r.t. the source map: scatter-add of the four taps (fp32 atomics)
+__global__ void warp_backward_kernel(const float* __restrict__ gout, const float* __restrict__ proj,
+                                     const float* __restrict__ depth, int B, int C, int N, int H, int W, int H1,
+                                     int W1, float* __restrict__ gsrc) {
+    const int64_t total = (int64_t)B * N * H * W;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int x = (int)(t % W);
+    const int y = (int)((t / W) % H);
+    const int n = (int)((t / ((int64_t)W * H)) % N);
+    const int b = (int)(t / ((int64_t)W * H * N));
+    const WarpGeom g = make_geom(W, H, W1, H1);
+    const float* m = proj + (size_t)b * 12;
+    float rx, ry, rz, ix, iy;
+    ray_dir(m, (float)x * g.xr, (float)y * g.yr, rx, ry, rz);
+    project(g, m, rx, ry, rz, depth[t], ix, iy, nullptr);
+    const Taps tp = make_taps(ix, iy, W1, H1);
+    const int64_t plane = (int64_t)N * H * W;
+    const float* go = gout + ((int64_t)b * C * N + n) * H * W + (int64_t)y * W + x;
+    float* gs = gsrc + (int64_t)b * C * H1 * W1;
+    for (int c = 0; c < C; ++c) {
+        const float gv = go[c * plane];
+        float* f = gs + (int64_t)c * H1 * W1;
+        if (tp.nw != 0.0f) atomicAdd(f + tp.y0 * W1 + tp.x0, gv * tp.nw);
+        if (tp.ne != 0.0f) atomicAdd(f + tp.y0 * W1 + tp.x1, gv * tp.ne);
+        if (tp.sw != 0.0f) atomicAdd(f + tp.y1 * W1 + tp.x0, gv * tp.sw);
+        if (tp.se != 0.0f) atomicAdd(f + tp.y1 * W1 + tp.x1, gv * tp.se);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ref_quarter: out[b, y, x, 0:C1 | C1:C1+C2 | C1+C2:] on the level-2 grid   (itermvs.py:95-98)
+// thread per (b, y, x, channel quad); writes float4 (C1, C2, C3 are multiples of 4).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ld(const itermvs_fmap& f, int b, int c, int y, int x) {
+    return f.data[b * f.sb + c * f.sc + y * f.sy + x * f.sx];
+}
+
+// F.interpolate(scale_factor=2, bilinear, align_corners=False) source index / weight
+__device__ __forceinline__ void up2_axis(int d, int n_in, int& i0, int& i1, float& l0, float& l1) {
+    float s = ((float)d + 0.5f) * 0.5f - 0.5f;
+    s = s < 0.0f ? 0.0f : s;
+    i0 = (int)s;
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+__global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fmap r3, int B, float* __restrict__ out) {
+    const int H = r2.H, W = r2.W;
+    const int CQ = r1.C + r2.C + r3.C;
+    const int quads = CQ / 4;
+    const int64_t total = (int64_t)B * H * W * quads;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int q = (int)(t % quads);
+    const int x = (int)((t / quads) % W);
+    const int y = (int)((t / ((int64_t)quads * W)) % H);
+    const int b = (int)(t / ((int64_t)quads * W * H));
+    int c = q * 4;
+    float v[4];
+    if (c < r1.C) {
+        // x0.5 bilinear == weights 0.5/0.5 on rows 2y,2y+1 and columns 2x,2x+1
+        for (int k = 0; k < 4; ++k) {
+            const float top = ld(r1, b, c + k, 2 * y, 2 * x) * 0.5f + ld(r1, b, c + k, 2 * y, 2 * x + 1) * 0.5f;
+            const float bot = ld(r1, b, c + k, 2 * y + 1, 2 * x) * 0.5f + ld(r1, b, c + k, 2 * y + 1, 2 * x + 1) * 0.5f;
+            v[k] = top * 0.5f + bot * 0.5f;
+        }
+    } else if (c < r1.C + r2.C) {
+        c -= r1.C;
+        for (int k = 0; k < 4; ++k) v[k] = ld(r2, b, c + k, y, x);
+    } else {
+        c -= r1.C + r2.C;
+        int y0, y1, x0, x1;
+        float hy0, hy1, hx0, hx1;
+        up2_axis(y, r3.H, y0, y1, hy0, hy1);
+        up2_axis(x, r3.W, x0, x1, hx0, hx1);
+        for (int k = 0; k < 4; ++k) {
+            const float top = ld(r3, b, c + k, y0, x0) * hx0 + ld(r3, b, c + k, y0, x1) * hx1;
+            const float bot = ld(r3, b, c + k, y1, x0) * hx0 + ld(r3, b, c + k, y1, x1) * hx1;
+            v[k] = top * hy0 + bot * hy1;
+        }
+    }
+    reinterpret_cast<float4*>(out)[t] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+}  // namespace itermvs
+
+using namespace itermvs;
+
+extern "C" int itermvs_compose_proj(const float* mats, int32_t n_sets, int32_t V, float* out, int32_t* nan_flag,
+                                    void* stream) {
+    ITERMVS_RETURN_IF(!mats || !out, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(n_sets < 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(V < 2 || V - 1 > ITERMVS_MAX_SRC, ITERMVS_ERR_VIEWS);
+    const int total = n_sets * (V - 1);
+    hipLaunchKernelGGL(compose_proj_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, mats, n_sets, V,
+                       out, nan_flag);
+    return itermvs_launch_status();
+}
+
+extern "C" int itermvs_warp(const itermvs_fmap* src, const float* proj, const float* depth, int32_t B, int32_t N,
+                            int32_t H, int32_t W, float* out, uint8_t* mask, void* stream) {
+    ITERMVS_RETURN_IF(!src || !src->data || !proj || !depth || !out, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(B < 1 || N < 1 || H < 1 || W < 1 || src->C < 1 || src->H < 1 || src->W < 1, ITERMVS_ERR_DIMS);
+    const int64_t total = (int64_t)B * N * H * W;
+    hipLaunchKernelGGL(warp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *src, proj,
+                       depth, B, N, H, W, out, mask);
+    return itermvs_launch_status();
+}
+
+extern "C" int itermvs_warp_backward(const float* grad_out, const float* proj, const float* depth, int32_t B, int32_t C,
+                                     int32_t N, int32_t H, int32_t W, int32_t H1, int32_t W1, float* grad_src,
+                                     void* stream) {
+    ITERMVS_RETURN_IF(!grad_out || !proj || !depth || !grad_src, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(B < 1 || C < 1 || N < 1 || H < 1 || W < 1 || H1 < 1 || W1 < 1, ITERMVS_ERR_DIMS);
+    const int64_t total = (int64_t)B * N * H * W;
+    hipLaunchKernelGGL(warp_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, proj, depth, B, C, N, H, W, H1, W1, grad_src);
+    return itermvs_launch_status();
+}
+
+extern "C" int itermvs_ref_quarter(const itermvs_fmap* r1, const itermvs_fmap* r2, const itermvs_fmap* r3, int32_t B,
+                                   float* out, void* stream) {
+    ITERMVS_RETURN_IF(!r1 || !r2 || !r3 || !r1->data || !r2->data || !r3->data || !out, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(B < 1 || r2->H < 1 || r2->W < 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(r1->H != 2 * r2->H || r1->W != 2 * r2->W || r2->H != 2 * r3->H || r2->W != 2 * r3->W,
+                      ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF((r1->C % 4) || (r2->C % 4) || (r3->C % 4), ITERMVS_ERR_CHANNELS);
+    ITERMVS_RETURN_IF(((uintptr_t)out) % 16, ITERMVS_ERR_ALIGN);
+    const int64_t total = (int64_t)B * r2->H * r2->W * ((r1->C + r2->C + r3->C) / 4);
+    hipLaunchKernelGGL(ref_quarter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *r1,
+                       *r2, *r3, B, out);
+    return itermvs_launch_status();
+}

@@ -1,0 +1,222 @@
+"""MI355X inference engine for the IterMVS matching hot path (test mode of ``Pipeline``).
+
+Data flow per batch of reference views (all buffers stay resident in HBM):
+
+    FeatureNet (MIOpen, BN folded, all B*V views in one batch)           net.py:36-65
+      -> channels-last pyramids f1 [BV,16,H/2,W/2], f2 [BV,32,H/4,W/4], f3 [BV,48,H/8,W/8]
+    K  compose_proj      src @ inv(ref) for 3 levels x S views            module.py:77-90
+    K  ref_quarter       reference features on the 1/4 grid, packed       itermvs.py:95-98
+    K  corr_init         per-view group correlation, 32 hypotheses        itermvs.py:48-51
+       PixelViewWeight convs (MIOpen) + K softmax_max + K bilinear_up     itermvs.py:333-350,56
+    K  view_aggregate    view-weighted mean                               itermvs.py:59-69
+       CorrNet (MIOpen) -> hidden_init convs -> K bilinear_up(tanh)       itermvs.py:159-164
+       depth_head (MIOpen) -> K prob_regress                              itermvs.py:171-190
+    per iteration:
+    K  corr_iter         samples + warp + gather + group corr + view mean, 3 levels, 1 launch
+       3 x CorrNet (MIOpen) -> K pack_scores -> GRU convs (MIOpen) + K gru_rh / gru_out
+       depth_head (MIOpen) -> K prob_regress (probability volume never stored)
+    K  convex_upsample   9-tap softmax + convex x4 + un-normalise         module.py:127-152
+    K  bilinear_up x4    confidence                                       itermvs.py:323
+
+``K`` = hand-written HIP kernel behind the C ABI (itermvs_amd.ops).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Mapping, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+Tensor = torch.Tensor
+
+INIT_SAMPLES = 32          # itermvs.py:237
+HIDDEN = 32                # net.py:72
+# itermvs.py:229-235: corr_interval * interval_scale, evaluated in fp32 like the reference
+_INTERVALS = {1: (-2.0, -2.0 / 3, 2.0 / 3, 2.0), 2: (-8.0, -8.0 / 3, 8.0 / 3, 8.0), 3: (-32.0, 32.0)}
+
+
+def sample_offsets() -> Dict[int, Tuple[float, ...]]:
+    out = {}
+    for l, vals in _INTERVALS.items():
+        t = torch.tensor(vals, dtype=torch.float32) * (1.0 / 256)
+        out[l] = tuple(float(v) for v in t)
+    return out
+
+
+def fold_batchnorm(w: Mapping[str, Tensor], prefix: str, eps: float = 1e-5) -> Tuple[Tensor, Tensor]:
+    """conv (no bias) followed by eval-mode BatchNorm -> (weight, bias) of one conv."""
+    scale = w[prefix + "bn.weight"] / torch.sqrt(w[prefix + "bn.running_var"] + eps)
+    weight = w[prefix + "conv.weight"] * scale.view(-1, 1, 1, 1)
+    bias = w[prefix + "bn.bias"] - w[prefix + "bn.running_mean"] * scale
+    return weight.contiguous(), bias.contiguous()
+
+
+class InferenceEngine:
+    def __init__(self, weights: Mapping[str, Tensor], iteration: int):
+        w = {k: v.detach() for k, v in weights.items()}
+        dev = w["feature_net.conv1.conv.weight"].device
+        if dev.type != "cuda":
+            raise RuntimeError("InferenceEngine needs the model on an MI355X (model.cuda()); no CPU fallback")
+        self.device = dev
+        self.iteration = iteration
+        self.w = w
+        fn = "feature_net."
+        self.cbr: Dict[str, Tuple[Tensor, Tensor]] = {}
+        names = ["conv1."] + [f"layer{l}.{b}.{c}." for l in (1, 2, 3) for b, cs in ((0, ("conv1", "conv2", "downsample")),
+                                                                                     (1, ("conv1", "conv2"))) for c in cs]
+        for n in names:
+            self.cbr[n] = fold_batchnorm(w, fn + n)
+        g = "iter_mvs.update.gru."
+        self.w_zr = torch.cat([w[g + "convz.weight"], w[g + "convr.weight"]], 0).contiguous()
+        self.b_zr = torch.cat([w[g + "convz.bias"], w[g + "convr.bias"]], 0).contiguous()
+        self.offsets = sample_offsets()
+        self._ws: Dict[tuple, dict] = {}
+
+    # -- dense stacks on MIOpen ---------------------------------------------------------------
+    def _cbr(self, x: Tensor, name: str, stride: int, relu: bool) -> Tensor:
+        wt, b = self.cbr[name]
+        y = F.conv2d(x, wt, b, stride=stride, padding=1)
+        return F.relu_(y) if relu else y
+
+    def _res(self, x: Tensor, name: str, stride: int) -> Tensor:
+        y = self._cbr(self._cbr(x, name + "conv1.", stride, True), name + "conv2.", 1, False)
+        if stride != 1:
+            x = self._cbr(x, name + "downsample.", stride, False)
+        return F.relu_(y.add_(x))
+
+    def feature_net(self, x: Tensor) -> Dict[int, Tensor]:
+        """net.py:36-65 with BN folded; x [M,3,H,W] -> NCHW pyramids {1,2,3}."""
+        w, p = self.w, "feature_net."
+        f0 = self._cbr(x, "conv1.", 1, True)
+        f1 = self._res(self._res(f0, "layer1.0.", 2), "layer1.1.", 1)
+        f2 = self._res(self._res(f1, "layer2.0.", 2), "layer2.1.", 1)
+        f3 = self._res(self._res(f2, "layer3.0.", 2), "layer3.1.", 1)
+        o3 = F.conv2d(f3, w[p + "output3.weight"], w[p + "output3.bias"], padding=1)
+        mid = F.interpolate(f3, scale_factor=2, mode="bilinear").add_(F.conv2d(f2, w[p + "inner2.weight"], w[p + "inner2.bias"]))
+        o2 = F.conv2d(mid, w[p + "output2.weight"], w[p + "output2.bias"], padding=1)
+        mid = F.interpolate(mid, scale_factor=2, mode="bilinear").add_(F.conv2d(f1, w[p + "inner1.weight"], w[p + "inner1.bias"]))
+        o1 = F.conv2d(mid, w[p + "output1.weight"], w[p + "output1.bias"], padding=1)
+        return {1: o1, 2: o2, 3: o3}
+
+    def corr_net(self, x: Tensor, level: int) -> Tensor:
+        """itermvs.py:352-381 on [M,8,h,w] -> [M,1,h,w]."""
+        w, p = self.w, f"iter_mvs.evaluation.corr_conv1.{level - 1}."
+        c0 = F.relu_(F.conv2d(x, w[p + "conv0.conv.weight"], padding=1))
+        c1 = F.relu_(F.conv2d(c0, w[p + "conv1.conv.weight"], stride=2, padding=1))
+        c2 = F.relu_(F.conv2d(c1, w[p + "conv2.conv.weight"], stride=2, padding=1))
+        u1 = F.conv_transpose2d(c2, w[p + "conv3.weight"], stride=2, padding=1, output_padding=1).add_(c1)
+        u0 = F.conv_transpose2d(u1, w[p + "conv4.weight"], stride=2, padding=1, output_padding=1).add_(c0)
+        return F.conv2d(u0, w[p + "conv5.weight"], w[p + "conv5.bias"], padding=1)
+
+    def depth_head(self, hidden: Tensor) -> Tensor:
+        w, p = self.w, "iter_mvs.update.depth_head."
+        x = F.relu_(F.conv2d(hidden, w[p + "0.weight"], padding=2, dilation=2))
+        x = F.relu_(F.conv2d(x, w[p + "2.weight"]))
+        return F.conv2d(x, w[p + "4.weight"], w[p + "4.bias"])
+
+    def confidence(self, hidden: Tensor) -> Tensor:
+        w, p = self.w, "iter_mvs.update.confidence_head."
+        x = F.relu_(F.conv2d(hidden, w[p + "0.weight"], padding=2, dilation=2))
+        return torch.sigmoid_(F.conv2d(x, w[p + "2.weight"], w[p + "2.bias"]))
+
+    # -- workspace ------------------------------------------------------------------------------
+    def _workspace(self, b: int, h: int, w: int) -> dict:
+        key = (b, h, w)
+        ws = self._ws.get(key)
+        if ws is None:
+            dev = self.device
+            nx = 1 + sum(len(v) for v in self.offsets.values())          # GRU input channels: depth + 10 scores
+            ws = {
+                "hx": torch.zeros((b, HIDDEN + nx, h, w), device=dev),     # [h | nd | scores]  (module.py:60)
+                "hx2": torch.zeros((b, HIDDEN + nx, h, w), device=dev),    # [r*h | nd | scores] (module.py:64)
+                "hidden": torch.empty((b, HIDDEN, h, w), device=dev),
+                "agg": [torch.empty((b, len(self.offsets[l]), 8, h, w), device=dev) for l in (1, 2, 3)],
+                "nan_flag": torch.zeros((1,), device=dev, dtype=torch.int32),
+            }
+            self._ws[key] = ws
+        return ws
+
+    # -- one batch of reference views -----------------------------------------------------------
+    def run(self, imgs: Tensor, projs: Dict[int, Tensor], depth_min: Tensor, depth_max: Tensor,
+            trace: dict = None) -> Tuple[Tensor, Tensor]:
+        """imgs [B,V,3,H,W]; projs[l] [B,V,4,4] (l = 1..3); depth_min/max [B]
+        -> (depth [B,1,H,W], confidence [B,1,H,W]) like itermvs.py:326-327 / net.py:125-128."""
+        b, v, _, hh, ww = imgs.shape
+        s = v - 1
+        w = self.w
+        feats = self.feature_net(imgs.reshape(b * v, 3, hh, ww))
+        cl = {l: ops.channels_last(f) for l, f in feats.items()}
+        per_view = {l: cl[l].view(b, v, *cl[l].shape[1:]) for l in (1, 2, 3)}
+        src = {l: [per_view[l][:, i] for i in range(1, v)] for l in (1, 2, 3)}
+        ref = {l: per_view[l][:, 0] for l in (1, 2, 3)}
+        h, wd = feats[2].shape[2:]
+        h3, w3 = feats[3].shape[2:]
+        ws = self._workspace(b, h, wd)
+        hx, hx2, hidden = ws["hx"], ws["hx2"], ws["hidden"]
+
+        proj = ops.compose_proj(torch.stack([projs[1], projs[2], projs[3]]).reshape(3 * b, v, 4, 4),
+                                ws["nan_flag"]).view(3, b, s, 12)
+        inv_min = (1.0 / depth_min).contiguous()
+        inv_max = (1.0 / depth_max).contiguous()
+
+        # convex up-sampling logits from the reference level-2 feature (itermvs.py:262-263)
+        ref2_nchw = feats[2].view(b, v, *feats[2].shape[1:])[:, 0]
+        u = "iter_mvs.upsample."
+        up_logits = F.conv2d(F.relu_(F.conv2d(ref2_nchw, w[u + "0.weight"], padding=1)), w[u + "2.weight"])
+
+        ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
+
+        # ---- initialisation (itermvs.py:270-276) ------------------------------------------
+        corr_v = ops.corr_init(src[3], ref[3], proj[2], inv_min, inv_max, INIT_SAMPLES)       # [B,S,32,8,h3,w3]
+        pv = "iter_mvs.evaluation.pixel_view_weight."
+        x = F.relu_(F.conv2d(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), w[pv + "conv.0.conv.weight"], padding=1))
+        x = F.conv2d(x, w[pv + "conv.1.weight"], w[pv + "conv.1.bias"])
+        vw = ops.softmax_max(x.view(b * s, INIT_SAMPLES, h3, w3))                               # [B*S,1,h3,w3]
+        view_w = ops.bilinear_up(vw, 2).view(b, s, h, wd)                                       # itermvs.py:56-57,71
+        agg0 = ops.view_aggregate(corr_v, vw.view(b, s, h3, w3))                                # [B,32,8,h3,w3]
+        score0 = self.corr_net(agg0.view(b * INIT_SAMPLES, 8, h3, w3), 3).view(b, INIT_SAMPLES, h3, w3)
+        hi = "iter_mvs.update.hidden_init_head."
+        x = F.conv2d(F.relu_(F.conv2d(score0, w[hi + "0.weight"], padding=1)), w[hi + "2.weight"], w[hi + "2.bias"])
+        hidden0 = ops.bilinear_up(x, 2, act="tanh")                                             # itermvs.py:161-163
+        hidden.copy_(hidden0)
+        hx[:, :HIDDEN].copy_(hidden0)
+        logits = self.depth_head(hidden)
+        _, _, best = ops.prob_regress(logits, nd_out=[(hx, HIDDEN), (hx2, HIDDEN)], want_best=trace is not None)
+        if trace is not None:
+            trace.update(feats=feats, proj=proj, ref_q=ref_q, corr_views=corr_v, view_weights=view_w, init_agg=agg0,
+                         init_score=score0, hidden0=hidden0.clone(), logits0=logits, nd0=hx[:, HIDDEN:HIDDEN + 1].clone(),
+                         best0=best, up_logits=up_logits, iters=[])
+
+        # ---- iterations (itermvs.py:288-324) -----------------------------------------------
+        g = "iter_mvs.update.gru."
+        conf = None
+        for it in range(self.iteration):
+            aggs = ops.corr_iter(src, ref_q, proj, view_w, inv_min, inv_max,
+                                 norm_depth=hx[:, HIDDEN:HIDDEN + 1], offsets=self.offsets, out=ws["agg"])
+            scores = [self.corr_net(a.view(-1, 8, h, wd), l).view(b, -1, h, wd) for l, a in zip((1, 2, 3), aggs)]
+            ops.pack_scores(scores, hx, hx2, HIDDEN + 1)
+            zr = F.conv2d(hx, self.w_zr, self.b_zr, padding=2, dilation=2)
+            ops.gru_rh(zr, hx, hx2, HIDDEN)
+            q = F.conv2d(hx2, w[g + "convq.weight"], w[g + "convq.bias"], padding=2, dilation=2)
+            nd_in = hx[:, HIDDEN:HIDDEN + 1].clone() if trace is not None else None
+            ops.gru_out(zr, q, hx, hidden, HIDDEN)
+            if it == self.iteration - 1:
+                conf = self.confidence(hidden)                                                  # itermvs.py:197-199
+            logits = self.depth_head(hidden)
+            _, _, best = ops.prob_regress(logits, nd_out=[(hx, HIDDEN), (hx2, HIDDEN)], want_best=trace is not None)
+            if trace is not None:
+                trace["iters"].append(dict(nd_in=nd_in, aggs=[a.clone() for a in aggs], score=torch.cat(scores, 1),
+                                           hidden=hidden.clone(), logits=logits, best=best,
+                                           nd=hx[:, HIDDEN:HIDDEN + 1].clone(), conf=conf))
+
+        depth_up = ops.convex_upsample(up_logits, hx, inv_min, inv_max, nd_channel=HIDDEN)      # itermvs.py:321-322
+        conf_up = ops.bilinear_up(conf, 4)                                                      # itermvs.py:323-324
+        return depth_up, conf_up
+
+    def check_projection_finite(self, b: int, h: int, w: int) -> None:
+        """Deferred form of the reference's NaN asserts (module.py:83,87); synchronises."""
+        ws = self._ws.get((b, h, w))
+        if ws is not None and int(ws["nan_flag"].item()) != 0:
+            raise AssertionError("nan in proj")

@@ -1,0 +1,126 @@
+"""``Pipeline`` / ``full_loss`` -- the drop-in counterpart of the reference's ``models/net.py``.
+
+Same constructor, ``forward`` signature, output dict keys and state-dict names as
+``models.net.Pipeline`` (net.py:68-128), so ``eval.py`` / ``train.py`` style drivers and the
+published checkpoints work unchanged.  What is inside is new:
+
+* parameters live in a name-addressed tree built from ``schema.state_dict_schema()`` (no
+  per-layer Python classes);
+* test mode runs the MI355X engine of ``itermvs_amd.engine`` -- fused HIP kernels through the C
+  ABI for warp+correlation, probability regression, GRU gates and convex up-sampling, MIOpen
+  for the dense 2-D convolutions, BatchNorm folded at load time, all views batched;
+* train mode (``itermvs_amd.train_graph``) is differentiable: HIP warp forward/backward
+  kernels inside ``torch.autograd.Function`` + PyTorch-ROCm autograd for the dense layers.
+
+There is no CPU path: CPU tensors raise ``RuntimeError`` (the oracle under ``oracle/`` is test
+infrastructure and is never imported from here).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Mapping
+
+import torch
+import torch.nn as nn
+
+from .schema import state_dict_schema, strip_module_prefix
+
+
+class _Node(nn.Module):
+    """Anonymous container node of the parameter tree."""
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, is_buffer: bool) -> None:
+    parts = dotted.split(".")
+    node = root
+    for part in parts[:-1]:
+        if part not in node._modules:
+            node.add_module(part, _Node())
+        node = node._modules[part]
+    if is_buffer:
+        node.register_buffer(parts[-1], tensor)
+    else:
+        node.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+def _default_init(name: str, shape) -> torch.Tensor:
+    """PyTorch's default Conv2d / BatchNorm2d initialisation (what the reference trains from)."""
+    if name.endswith("num_batches_tracked"):
+        return torch.zeros((), dtype=torch.int64)
+    if name.endswith("running_mean") or name.endswith("bn.bias"):
+        return torch.zeros(shape)
+    if name.endswith("running_var") or name.endswith("bn.weight"):
+        return torch.ones(shape)
+    schema = state_dict_schema()
+    wname = name if name.endswith("weight") else name[: -len("bias")] + "weight"
+    wshape = schema[wname]
+    transposed = wname.endswith("conv3.weight") or wname.endswith("conv4.weight")  # ConvTranspose2d
+    fan_in = (wshape[0] if transposed else wshape[1]) * wshape[2] * wshape[3]
+    bound = 1.0 / math.sqrt(fan_in)
+    return (torch.rand(shape) * 2 - 1) * bound
+
+
+class Pipeline(nn.Module):
+    """net.py:68-128.  ``Pipeline(iteration=4, test=False)``;
+    ``forward(imgs, proj_matrices, depth_min, depth_max)``."""
+
+    def __init__(self, iteration: int = 4, test: bool = False):
+        super().__init__()
+        self.feature_dim = [8, 16, 32, 48]
+        self.hidden_dim = 32
+        self.iteration = iteration
+        self.test = test
+        for name, shape in state_dict_schema().items():
+            is_buffer = "running_" in name or name.endswith("num_batches_tracked")
+            _attach(self, name, _default_init(name, shape), is_buffer)
+        self._engine = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
+
+    # -- weights ----------------------------------------------------------------------------
+    def invalidate(self) -> None:
+        """Drop the folded / re-laid-out inference weights (after any parameter change)."""
+        self._engine = None
+
+    def load_checkpoint_state(self, state: Mapping[str, torch.Tensor], strict: bool = True):
+        """Load a reference checkpoint's ``state_dict['model']`` (keys may carry ``module.``)."""
+        return self.load_state_dict(strip_module_prefix(state), strict=strict)
+
+    def train(self, mode: bool = True):
+        self.invalidate()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def weights(self) -> Dict[str, torch.Tensor]:
+        return self.state_dict(keep_vars=True)
+
+    # -- forward ----------------------------------------------------------------------------
+    def forward(self, imgs, proj_matrices, depth_min, depth_max):
+        x = imgs["level_0"]
+        if not x.is_cuda:
+            raise RuntimeError("itermvs_amd.Pipeline runs on an MI355X only (HIP kernels, no CPU fallback); "
+                               "move the sample with tocuda() first")
+        h, w = x.shape[-2:]
+        if h % 32 or w % 32:
+            raise RuntimeError(f"image height and width must be multiples of 32, got {h}x{w}")
+        projs = {l: proj_matrices[f"level_{l}"].float() for l in (1, 2, 3)}
+        depth_min = depth_min.float()
+        depth_max = depth_max.float()
+        if self.test:
+            from .engine import InferenceEngine
+            if self._engine is None:
+                self._engine = InferenceEngine(self.weights(), self.iteration)
+            with torch.no_grad():
+                depth_up, conf_up = self._engine.run(x.float(), projs, depth_min, depth_max)
+            return {"depths_upsampled": depth_up, "confidence_upsampled": conf_up}
+        from .train_graph import train_forward
+        return train_forward(self.weights(), x.float(), projs, depth_min, depth_max, self.iteration,
+                             bn_training=self.training)
+
+
+def full_loss(depths, depths_upsampled, confidences, depths_gt, mask, depth_min, depth_max, regress=True):
+    """net.py:131-190 (same signature); see ``itermvs_amd.train_graph.full_loss``."""
+    from .train_graph import full_loss as _impl
+    return _impl(depths, depths_upsampled, confidences, depths_gt, mask, depth_min, depth_max, regress)

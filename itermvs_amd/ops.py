@@ -1,0 +1,321 @@
+"""Tensor-level wrappers over the C ABI (one per entry point of include/itermvs_hip.h).
+
+Every function takes CUDA (ROCm) float32 tensors, enqueues the HIP kernel on torch's current
+stream and returns freshly allocated outputs (or writes into ``out=`` buffers).  There is no
+CPU path: a CPU tensor raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import MAX_HYP, MAX_SRC, CorrInitParams, CorrIterParams, FMap, LevelSrc, check
+
+Tensor = torch.Tensor
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: Tensor, name: str) -> Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA/ROCm tensor - the IterMVS HIP engine has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def fmap(t: Tensor, name: str = "fmap") -> FMap:
+    """Describe a [B,C,H,W] tensor (any strides) as an ``itermvs_fmap``."""
+    _dev(t, name)
+    if t.dim() != 4:
+        raise RuntimeError(f"{name}: expected [B,C,H,W]")
+    sb, sc, sy, sx = t.stride()
+    return FMap(t.data_ptr(), sb, sc, sy, sx, t.shape[1], t.shape[2], t.shape[3], 0)
+
+
+def level_src(views: Sequence[Tensor], name: str = "src") -> LevelSrc:
+    """S source-view maps [B,C,H1,W1] sharing shape and strides -> ``itermvs_level_src``."""
+    if not 1 <= len(views) <= MAX_SRC:
+        raise RuntimeError(f"{name}: need 1..{MAX_SRC} source views, got {len(views)}")
+    v0 = _dev(views[0], name)
+    ls = LevelSrc()
+    for i, v in enumerate(views):
+        _dev(v, name)
+        if v.shape != v0.shape or v.stride() != v0.stride():
+            raise RuntimeError(f"{name}: all source views must share shape and strides")
+        ls.view[i] = v.data_ptr()
+    ls.sb, ls.sc, ls.sy, ls.sx = v0.stride()
+    ls.C, ls.H, ls.W = v0.shape[1], v0.shape[2], v0.shape[3]
+    return ls
+
+
+def channels_last(t: Tensor) -> Tensor:
+    """Return ``t`` in channels-last memory format (no copy if it already is)."""
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+# ------------------------------------------------------------------------------------------
+def compose_proj(mats: Tensor, nan_flag: Optional[Tensor] = None) -> Tensor:
+    """module.py:77-90.  mats [n,V,4,4] (view 0 = reference) -> [n,V-1,12] rows of [rot|trans]."""
+    mats = _dev(mats, "mats").contiguous()
+    n, v = mats.shape[0], mats.shape[1]
+    out = torch.empty((n, v - 1, 12), device=mats.device, dtype=torch.float32)
+    check(_lib.load().itermvs_compose_proj(mats.data_ptr(), n, v, out.data_ptr(), _ptr(nan_flag), _stream()),
+          "itermvs_compose_proj")
+    return out
+
+
+class _WarpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, proj12, depth, want_mask):
+        b, c, h1, w1 = src.shape
+        _, n, h, w = depth.shape
+        depth = depth.contiguous()
+        out = torch.empty((b, c, n, h, w), device=src.device, dtype=torch.float32)
+        mask = torch.empty((b, n, h, w), device=src.device, dtype=torch.uint8) if want_mask else None
+        fm = fmap(src, "src_fea")
+        check(_lib.load().itermvs_warp(C.byref(fm), proj12.data_ptr(), depth.data_ptr(), b, n, h, w, out.data_ptr(),
+                                       _ptr(mask), _stream()), "itermvs_warp")
+        ctx.save_for_backward(proj12, depth)
+        ctx.src_shape = (b, c, h1, w1)
+        ctx.mark_non_differentiable(*([mask] if want_mask else []))
+        return (out, mask) if want_mask else out
+
+    @staticmethod
+    def backward(ctx, gout, *_):
+        proj12, depth = ctx.saved_tensors
+        b, c, h1, w1 = ctx.src_shape
+        _, n, h, w = depth.shape
+        gsrc = torch.zeros((b, c, h1, w1), device=gout.device, dtype=torch.float32)
+        gout = gout.contiguous()
+        check(_lib.load().itermvs_warp_backward(gout.data_ptr(), proj12.data_ptr(), depth.data_ptr(), b, c, n, h, w,
+                                                h1, w1, gsrc.data_ptr(), _stream()), "itermvs_warp_backward")
+        return gsrc, None, None, None
+
+
+def warp(src_fea: Tensor, proj12: Tensor, depth_samples: Tensor, return_mask: bool = False):
+    """module.py:68-125 on a pre-composed projection [B,12]: -> [B,C,N,H,W] (and bool mask)."""
+    _dev(src_fea, "src_fea"); _dev(depth_samples, "depth_samples")
+    proj12 = _dev(proj12, "proj").contiguous()
+    res = _WarpFn.apply(src_fea, proj12, depth_samples, return_mask)
+    if return_mask:
+        return res[0], res[1].bool()
+    return res
+
+
+def ref_quarter(ref1: Tensor, ref2: Tensor, ref3: Tensor) -> Tensor:
+    """itermvs.py:95-98: reference features of levels 1..3 on the 1/4 grid, [B,H,W,C1+C2+C3]."""
+    b, _, h, w = ref2.shape
+    cq = ref1.shape[1] + ref2.shape[1] + ref3.shape[1]
+    out = torch.empty((b, h, w, cq), device=ref2.device, dtype=torch.float32)
+    f1, f2, f3 = fmap(ref1, "ref1"), fmap(ref2, "ref2"), fmap(ref3, "ref3")
+    check(_lib.load().itermvs_ref_quarter(C.byref(f1), C.byref(f2), C.byref(f3), b, out.data_ptr(), _stream()),
+          "itermvs_ref_quarter")
+    return out
+
+
+def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, view_w: Tensor,
+              inv_min: Tensor, inv_max: Tensor, depth: Optional[Dict[int, Tensor]] = None,
+              norm_depth: Optional[Tensor] = None, offsets: Optional[Dict[int, Sequence[float]]] = None,
+              out: Optional[List[Tensor]] = None) -> List[Tensor]:
+    """itermvs.py:84-120 fused (see include/itermvs_hip.h).  ``src[l]`` = S channels-last maps of
+    level l; ``proj`` [3,B,S,12]; ``view_w`` [B,S,H,W]; hypotheses either explicit
+    ``depth[l]`` [B,N_l,H,W] or generated from ``norm_depth`` [B,1,H,W] + ``offsets[l]``.
+    Returns the three aggregated group correlations [B,N_l,8,H,W]."""
+    b, h, w, _ = ref_q.shape
+    s = len(src[1])
+    p = CorrIterParams()
+    p.B, p.S, p.H, p.W = b, s, h, w
+    keep = []
+    outs: List[Tensor] = []
+    for i, l in enumerate((1, 2, 3)):
+        p.src[i] = level_src(src[l], f"src level {l}")
+        if depth is not None and depth.get(l) is not None:
+            d = _dev(depth[l], "depth").contiguous()
+            keep.append(d)
+            n = d.shape[1]
+            p.depth[i] = d.data_ptr()
+        else:
+            if offsets is None or norm_depth is None:
+                raise RuntimeError("corr_iter: give either depth[l] or norm_depth + offsets[l]")
+            n = len(offsets[l])
+            p.depth[i] = None
+            for k, o in enumerate(offsets[l]):
+                p.offsets[i][k] = o
+        if n > MAX_HYP:
+            raise RuntimeError(f"corr_iter: at most {MAX_HYP} hypotheses per level")
+        p.N[i] = n
+        o = out[i] if out is not None else torch.empty((b, n, 8, h, w), device=ref_q.device, dtype=torch.float32)
+        outs.append(o)
+        p.out[i] = o.data_ptr()
+    if norm_depth is not None:
+        # [B,1,H,W] view, possibly one channel of a wider contiguous [B,Ct,H,W] buffer
+        _dev(norm_depth, "norm_depth")
+        if norm_depth.stride(3) != 1 or norm_depth.stride(2) != w:
+            norm_depth = norm_depth.contiguous()
+        p.norm_depth = norm_depth.data_ptr()
+        p.norm_depth_sb = norm_depth.stride(0)
+    proj = _dev(proj, "proj").contiguous()
+    view_w = _dev(view_w, "view_w").contiguous()
+    p.ref_q, p.proj, p.view_w = _dev(ref_q, "ref_q").data_ptr(), proj.data_ptr(), view_w.data_ptr()
+    p.inv_depth_min, p.inv_depth_max = _dev(inv_min, "inv_min").data_ptr(), _dev(inv_max, "inv_max").data_ptr()
+    check(_lib.load().itermvs_corr_iter(C.byref(p), _stream()), "itermvs_corr_iter")
+    return outs
+
+
+def corr_init(src3: Sequence[Tensor], ref3: Tensor, proj: Tensor, inv_min: Tensor, inv_max: Tensor,
+              num_samples: int = 32, depth: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """itermvs.py:48-51 (+ :11-19): per-view group correlation, [B,S,N,8,H,W]."""
+    b, _, h, w = ref3.shape
+    s = len(src3)
+    p = CorrInitParams()
+    p.B, p.S, p.H, p.W, p.N = b, s, h, w, num_samples
+    p.src = level_src(src3, "src level 3")
+    p.ref = fmap(ref3, "ref3")
+    proj = _dev(proj, "proj").contiguous()
+    p.proj = proj.data_ptr()
+    if depth is not None:
+        depth = _dev(depth, "depth").contiguous()
+        p.N = depth.shape[1]
+        p.depth = depth.data_ptr()
+    p.inv_depth_min, p.inv_depth_max = _dev(inv_min, "inv_min").data_ptr(), _dev(inv_max, "inv_max").data_ptr()
+    if out is None:
+        out = torch.empty((b, s, p.N, 8, h, w), device=ref3.device, dtype=torch.float32)
+    p.out = out.data_ptr()
+    check(_lib.load().itermvs_corr_init(C.byref(p), _stream()), "itermvs_corr_init")
+    return out
+
+
+def view_aggregate(corr: Tensor, w: Tensor) -> Tensor:
+    """itermvs.py:59-69.  corr [B,S,N,8,H,W], w [B,S,H,W] -> [B,N,8,H,W]."""
+    b, s, n, g, h, wd = corr.shape
+    corr = _dev(corr, "corr").contiguous()
+    w = _dev(w, "w").contiguous()
+    out = torch.empty((b, n, g, h, wd), device=corr.device, dtype=torch.float32)
+    check(_lib.load().itermvs_view_aggregate(corr.data_ptr(), w.data_ptr(), s, b, n, h * wd, out.data_ptr(), _stream()),
+          "itermvs_view_aggregate")
+    return out
+
+
+def softmax_max(x: Tensor) -> Tensor:
+    """itermvs.py:347-348.  x [M,N,H,W] -> max over N of softmax over N, [M,1,H,W]."""
+    x = _dev(x, "x").contiguous()
+    m, n, h, w = x.shape
+    out = torch.empty((m, 1, h, w), device=x.device, dtype=torch.float32)
+    check(_lib.load().itermvs_softmax_max(x.data_ptr(), m, n, h * w, out.data_ptr(), _stream()), "itermvs_softmax_max")
+    return out
+
+
+def prob_regress(logits: Tensor, nd_out: Optional[Sequence[Tuple[Tensor, int]]] = None, want_prob: bool = False,
+                 want_best: bool = False):
+    """itermvs.py:171-190 / 201-219.  logits [B,256,H,W] (NCHW or channels-last).
+    ``nd_out``: up to two (buffer [B,Ct,H,W] contiguous, channel) destinations written in place;
+    default: a fresh [B,1,H,W].  Returns (nd, prob | None, best | None)."""
+    _dev(logits, "logits")
+    b, k, h, w = logits.shape
+    if k != 256:
+        raise RuntimeError("prob_regress: expects 256 bins")
+    sb, sc, sy, sx = logits.stride()
+    if sy != w * sx:
+        logits = logits.contiguous()
+        sb, sc, sy, sx = logits.stride()
+    p = h * w
+    nd = None
+    dests = []
+    if nd_out is None:
+        nd = torch.empty((b, 1, h, w), device=logits.device, dtype=torch.float32)
+        dests.append((nd.data_ptr(), p))
+    else:
+        for buf, ch in nd_out:
+            _dev(buf, "nd_out")
+            assert buf.is_contiguous() and buf.shape[2:] == (h, w)
+            dests.append((buf.data_ptr() + 4 * ch * p, buf.shape[1] * p))
+    while len(dests) < 2:
+        dests.append((None, 0))
+    prob = torch.empty((b, 256, h, w), device=logits.device, dtype=torch.float32) if want_prob else None
+    best = torch.empty((b, 1, h, w), device=logits.device, dtype=torch.int64) if want_best else None
+    check(_lib.load().itermvs_prob_regress(logits.data_ptr(), sb, sc, sx, b, p, dests[0][0], dests[0][1], dests[1][0],
+                                           dests[1][1], _ptr(prob), _ptr(best), _stream()), "itermvs_prob_regress")
+    return nd, prob, best
+
+
+def gru_rh(zr: Tensor, h_buf: Tensor, rh_buf: Tensor, hid: int = 32) -> None:
+    """module.py:63-64: rh_buf[:, :hid] = sigmoid(zr[:, hid:]) * h_buf[:, :hid]  (buffers [B,Ct,H,W])."""
+    b, _, h, w = zr.shape
+    p = h * w
+    assert zr.is_contiguous() and h_buf.is_contiguous() and rh_buf.is_contiguous()
+    check(_lib.load().itermvs_gru_rh(_dev(zr, "zr").data_ptr(), _dev(h_buf, "h").data_ptr(), h_buf.shape[1] * p,
+                                     _dev(rh_buf, "rh").data_ptr(), rh_buf.shape[1] * p, b, hid, p, _stream()),
+          "itermvs_gru_rh")
+
+
+def gru_out(zr: Tensor, q: Tensor, h_buf: Tensor, h_copy: Optional[Tensor] = None, hid: int = 32) -> None:
+    """module.py:62,65: h_buf[:, :hid] = (1-z)*h + z*tanh(q), in place; ``h_copy`` [B,hid,H,W]
+    optionally receives a contiguous copy of the new state."""
+    b, _, h, w = zr.shape
+    p = h * w
+    assert zr.is_contiguous() and q.is_contiguous() and h_buf.is_contiguous()
+    assert h_copy is None or (h_copy.is_contiguous() and h_copy.shape == (b, hid, h, w))
+    check(_lib.load().itermvs_gru_out(_dev(zr, "zr").data_ptr(), _dev(q, "q").data_ptr(), _dev(h_buf, "h").data_ptr(),
+                                      h_buf.shape[1] * p, _ptr(h_copy), b, hid, p, _stream()), "itermvs_gru_out")
+
+
+def pack_scores(scores: Sequence[Tensor], dst0: Tensor, dst1: Optional[Tensor], ch0: int) -> None:
+    """itermvs.py:124,193: write the three CorrNet outputs [B,N_l,H,W] into channels ch0.. of the buffers."""
+    b, _, h, w = scores[0].shape
+    n = (C.c_int32 * 3)(*[s.shape[1] for s in scores])
+    sc = [_dev(s, "score").contiguous() for s in scores]
+    assert dst0.is_contiguous() and (dst1 is None or (dst1.is_contiguous() and dst1.shape == dst0.shape))
+    check(_lib.load().itermvs_pack_scores(sc[0].data_ptr(), sc[1].data_ptr(), sc[2].data_ptr(), n, b, h * w,
+                                          dst0.data_ptr(), _ptr(dst1), dst0.shape[1] * h * w, ch0, _stream()),
+          "itermvs_pack_scores")
+
+
+def convex_upsample(logits: Tensor, nd: Tensor, inv_min: Tensor, inv_max: Tensor, nd_channel: int = 0,
+                    want_norm: bool = False):
+    """itermvs.py:262-264 + module.py:127-140 + :148-152.  logits [B,144,H,W] (raw, pre-softmax),
+    nd = buffer [B,Ct,H,W] whose channel ``nd_channel`` holds the normalised depth.
+    -> depth [B,1,4H,4W] (and the normalised up-sampled map if ``want_norm``)."""
+    _dev(logits, "logits"); _dev(nd, "nd")
+    b, k, h, w = logits.shape
+    assert k == 144 and nd.is_contiguous()
+    sb, sc, sy, sx = logits.stride()
+    depth = torch.empty((b, 1, 4 * h, 4 * w), device=logits.device, dtype=torch.float32)
+    norm = torch.empty_like(depth) if want_norm else None
+    check(_lib.load().itermvs_convex_upsample(logits.data_ptr(), sb, sc, sy, sx, nd.data_ptr() + 4 * nd_channel * h * w,
+                                              nd.shape[1] * h * w, _dev(inv_min, "inv_min").data_ptr(),
+                                              _dev(inv_max, "inv_max").data_ptr(), b, h, w, depth.data_ptr(),
+                                              _ptr(norm), _stream()), "itermvs_convex_upsample")
+    return (depth, norm) if want_norm else depth
+
+
+def bilinear_up(x: Tensor, scale: int, act: str = "none") -> Tensor:
+    """F.interpolate(x, scale_factor=scale, mode='bilinear') (+ tanh): x [B,C,H,W] -> [B,C,sH,sW]."""
+    x = _dev(x, "x").contiguous()
+    b, c, h, w = x.shape
+    out = torch.empty((b, c, scale * h, scale * w), device=x.device, dtype=torch.float32)
+    check(_lib.load().itermvs_bilinear_up(x.data_ptr(), b * c, h, w, scale, {"none": 0, "tanh": 1}[act], out.data_ptr(),
+                                          _stream()), "itermvs_bilinear_up")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+def profile_enable(capacity: int) -> None:
+    check(_lib.load().itermvs_profile_enable(capacity), "itermvs_profile_enable")
+
+
+def profile_collect(max_samples: int = 4096):
+    """-> list of (kind, milliseconds); kind 1 = corr_iter, 2 = corr_init."""
+    kinds = (C.c_int32 * max_samples)()
+    ms = (C.c_float * max_samples)()
+    n = _lib.load().itermvs_profile_collect(kinds, ms, max_samples)
+    return [(kinds[i], ms[i]) for i in range(n)]

@@ -1,0 +1,84 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, independent reference views.
+
+The reference drives its GPUs with single-process ``nn.DataParallel`` (eval.py:119) and, at the
+``--batch_size 1`` of every eval script, only ever uses GPU 0.  Reference views are independent
+units (eval.py:129-151 carries no state between samples), so the MI355X design shards the list
+of reference views rank-strided over ``torch.distributed`` ranks with NO data-path collective;
+RCCL (backend "nccl") is used only for the start/stop barriers and the max-over-ranks timing.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Callable, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Rank-strided partition: rank r owns items r, r+world, ...  (SURVEY.md 8(e))."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of size {world}")
+    return list(range(rank, n_items, world))
+
+
+def shard_counts(n_items: int, world: int) -> List[int]:
+    return [len(range(r, n_items, world)) for r in range(world)]
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1-process default)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_distributed(backend: str = None) -> Tuple[int, int, int]:
+    """Join the process group when launched by ``torch.distributed.run``; no-op for 1 process."""
+    rank, local_rank, world = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def barrier(device_sync: bool = True) -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    if device_sync and torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def timed_steps(step: Callable[[int], None], steps: int, warmup: int) -> float:
+    """Run ``warmup`` untimed then exactly ``steps`` timed calls of ``step(i)``, bracketed by a
+    barrier + device synchronise on both sides; returns the MAX elapsed seconds over all ranks."""
+    for i in range(warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return max_over_ranks(elapsed)
+
+
+def max_over_ranks(value: float) -> float:
+    if dist.is_available() and dist.is_initialized():
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return value
+
+
+def sum_over_ranks(value: float) -> float:
+    if dist.is_available() and dist.is_initialized():
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+    return value

@@ -46,7 +46,7 @@ class Golden:
 
     def __getitem__(self, k):
         a = self._z[k]
-        return torch.from_numpy(np.ascontiguousarray(a)) if a.dtype.kind in "fiub" else a
+        return torch.from_numpy(a.copy()) if a.dtype.kind in "fiub" else a
 
 
 _cache = {}

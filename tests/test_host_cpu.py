@@ -1,0 +1,129 @@
+"""CPU-only checks: the C-ABI library loads and exports everything include/itermvs_hip.h
+declares, argument validation returns the documented error codes without touching a GPU, the
+state-dict schema equals the published checkpoint's, and the product path refuses CPU tensors."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, load_weights
+
+
+def test_library_exports_every_declared_symbol():
+    from itermvs_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "itermvs_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(itermvs_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no prototypes parsed from the header"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.itermvs_version() == _lib.ABI_VERSION
+    m = re.search(r"#define ITERMVS_ABI_VERSION (\d+)", header)
+    assert int(m.group(1)) == _lib.ABI_VERSION
+
+
+def test_struct_layout_matches_header_sizes():
+    """ctypes mirrors of the C structs: sizes follow from the header's field lists."""
+    from itermvs_amd import _lib
+    assert C.sizeof(_lib.FMap) == 8 + 4 * 8 + 4 * 4
+    assert C.sizeof(_lib.LevelSrc) == 16 * 8 + 4 * 8 + 4 * 4
+    assert C.sizeof(_lib.CorrIterParams) == 8 * 4 + 3 * C.sizeof(_lib.LevelSrc) + 3 * 8 + 3 * 8 + 8 + 8 + 3 * 8 * 4 + 2 * 8 + 3 * 8
+    assert C.sizeof(_lib.CorrInitParams) == 6 * 4 + C.sizeof(_lib.LevelSrc) + C.sizeof(_lib.FMap) + 5 * 8
+
+
+def test_argument_validation_error_codes():
+    """Validation happens before any launch, so these calls are safe without a GPU."""
+    from itermvs_amd import _lib
+    lib = _lib.load()
+    assert lib.itermvs_error_string(0) == b"ok"
+    assert lib.itermvs_compose_proj(None, 1, 2, None, None, None) == -1            # ERR_NULL
+    assert lib.itermvs_corr_iter(None, None) == -1
+    buf = (C.c_float * 64)()
+    addr = C.addressof(buf)
+    assert lib.itermvs_compose_proj(addr, 0, 2, addr, None, None) == -2            # ERR_DIMS
+    assert lib.itermvs_compose_proj(addr, 1, 40, addr, None, None) == -4           # ERR_VIEWS
+    assert lib.itermvs_softmax_max(addr, 0, 4, 4, addr, None) == -2
+    p = _lib.CorrInitParams()
+    p.B, p.S, p.H, p.W, p.N = 1, 1, 4, 4, 32
+    p.ref.data = addr; p.proj = addr; p.inv_depth_min = addr; p.inv_depth_max = addr; p.out = addr
+    p.src.view[0] = addr
+    p.src.C, p.src.H, p.src.W = 20, 4, 4
+    p.src.sb, p.src.sc, p.src.sy, p.src.sx = 320, 1, 80, 20
+    assert lib.itermvs_corr_init(C.byref(p), None) == -3                           # ERR_CHANNELS
+    p.src.C = 48; p.src.sc = 16
+    assert lib.itermvs_corr_init(C.byref(p), None) == -6                           # ERR_LAYOUT (not channels-last)
+    p.src.sc = 1; p.src.sx = 50
+    assert lib.itermvs_corr_init(C.byref(p), None) == -5                           # ERR_ALIGN
+    p.S = 17
+    assert lib.itermvs_corr_init(C.byref(p), None) == -4                           # ERR_VIEWS
+    for code in range(-7, 1):
+        assert len(lib.itermvs_error_string(code)) > 0
+
+
+def test_schema_equals_published_checkpoint(weights_dtu):
+    from itermvs_amd.schema import check_state_dict, state_dict_schema, strip_module_prefix
+    check_state_dict(weights_dtu)
+    assert len(state_dict_schema()) == 150
+    n_params = sum(int(torch.tensor(shp).prod()) if shp else 1 for k, shp in state_dict_schema().items()
+                   if "running" not in k and "num_batches" not in k)
+    assert n_params == 343685
+    pref = {"module." + k: v for k, v in weights_dtu.items()}
+    assert set(strip_module_prefix(pref)) == set(weights_dtu)
+    with pytest.raises(KeyError):
+        check_state_dict({k: v for k, v in list(weights_dtu.items())[:-1]})
+
+
+def test_pipeline_state_dict_names_and_cpu_rejection(weights_dtu):
+    from itermvs_amd import synthetic
+    from itermvs_amd.net import Pipeline
+    from itermvs_amd.schema import state_dict_schema
+    m = Pipeline(iteration=4, test=True)
+    assert list(m.state_dict().keys()) == list(state_dict_schema().keys())
+    assert sum(p.numel() for p in m.parameters()) == 343685
+    m.load_checkpoint_state({"module." + k: v for k, v in weights_dtu.items()})    # eval.py:124-125 format
+    assert torch.equal(m.state_dict()["iter_mvs.update.gru.convq.bias"], weights_dtu["iter_mvs.update.gru.convq.bias"])
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in list(weights_dtu.items())[:-1]})       # strict, like the reference
+    s = synthetic.make_sample(batch=1, num_views=3, height=64, width=96, seed=0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(s["imgs"], s["proj_matrices"], s["depth_min"], s["depth_max"])
+
+
+def test_ops_refuse_cpu_tensors():
+    from itermvs_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.bilinear_up(torch.zeros(1, 1, 4, 4), 2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.compose_proj(torch.eye(4).repeat(1, 2, 1, 1))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "itermvs_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("the oracle under ``oracle/``", ""), fn
+
+
+def test_synthetic_inputs_are_deterministic_and_dtu_shaped():
+    from itermvs_amd import synthetic
+    a = synthetic.make_sample(1, 5, 64, 96, seed=3)
+    b = synthetic.make_sample(1, 5, 64, 96, seed=3)
+    assert torch.equal(a["imgs"]["level_0"], b["imgs"]["level_0"])
+    assert a["imgs"]["level_2"].shape == (1, 5, 3, 16, 24)
+    p0, p1 = a["proj_matrices"]["level_0"][0, 0], a["proj_matrices"]["level_1"][0, 0]
+    assert torch.allclose(p1[:2], p0[:2] / 2) and torch.equal(p1[2:], p0[2:])     # K rows 0-1 halve per level
+    assert torch.equal(p0[3], torch.tensor([0.0, 0.0, 0.0, 1.0]))
+    w0 = synthetic.random_state_dict(0)
+    assert all(torch.equal(w0[k], v) for k, v in load_weights("seed0").items())   # matches the golden weights
+    sc = synthetic.make_scene_sample(3, 64, 96, seed=1)
+    assert 425 < float(sc["depth_gt"].min()) and float(sc["depth_gt"].max()) < 935
+
+
+def test_bench_algorithmic_bytes_match_design():
+    import bench
+    it, init, per_map = bench.algorithmic_bytes(4, 512, 640, 1, 4)
+    assert abs(it / 1e6 - 50.2) < 0.3 and abs(per_map / 1e6 - 229.0) < 3.0

@@ -1,0 +1,328 @@
+"""HIP kernels (through the C ABI, itermvs_amd.ops) vs golden vectors from the reference and
+vs the CPU oracle on identical inputs.  Needs an MI355X: run with ``-m gpu``."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden, load_weights
+from oracle import itermvs_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def ops():
+    from itermvs_amd import ops as _ops
+    return _ops
+
+
+def cu(t):
+    return t.to(DEV)
+
+
+def maxdiff(a, b):
+    return float((a.detach().cpu().float() - b.detach().cpu().float()).abs().max())
+
+
+def proj12_cpu(src_proj, ref_proj):
+    """the reference's own fp32 projection (module.py:77-90) as [B,12] rows of [rot|trans]"""
+    return O.compose_projection(src_proj, ref_proj)[:, :3, :4].reshape(-1, 12).contiguous()
+
+
+WARP_CASES = ["l1", "l2_b2", "l3", "init", "l1_behind", "l3_behind"]
+
+
+def test_compose_proj_matches_fp64_and_reference():
+    g = golden("e2e_small_seed0.npz")
+    for l in (1, 2, 3):
+        mats = g[f"proj.level_{l}"]                       # [B,V,4,4]
+        out = ops().compose_proj(cu(mats)).cpu()          # [B,V-1,12]
+        for b in range(mats.shape[0]):
+            inv = torch.inverse(mats[b, 0].double())
+            for s in range(1, mats.shape[1]):
+                exact = (mats[b, s].double() @ inv)[:3, :4].reshape(12)
+                got = out[b, s - 1].double()
+                assert float(((got - exact).abs() / exact.abs().clamp(min=1e-3)).max()) < 1e-6
+                ref32 = proj12_cpu(mats[b:b + 1, s], mats[b:b + 1, 0])[0].double()
+                assert float(((got - ref32).abs() / ref32.abs().clamp(min=1.0)).max()) < 1e-4
+
+
+def test_compose_proj_nan_flag():
+    mats = torch.eye(4).repeat(1, 3, 1, 1).clone()
+    mats[0, 0] = 0.0                                      # singular reference -> inf/nan
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops().compose_proj(cu(mats), flag)
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("case", WARP_CASES)
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_warp_seam(case, layout):
+    g = golden("warp_cases.npz")
+    src, depth = g[f"{case}.src"], g[f"{case}.depth"]
+    p12 = proj12_cpu(g[f"{case}.src_proj"], g[f"{case}.ref_proj"])
+    s = cu(src)
+    if layout == "nhwc":
+        s = s.contiguous(memory_format=torch.channels_last)
+    warped, mask = ops().warp(s, cu(p12), cu(depth), return_mask=True)
+    ref = g[f"{case}.warped"]
+    assert warped.shape == ref.shape
+    assert maxdiff(warped, ref) <= 5e-5 * max(1.0, float(ref.abs().max()))
+    assert float((mask.cpu() != g[f"{case}.mask"].bool()).float().mean()) < 1e-3
+    zr = ref.abs().sum(1) == 0
+    zo = warped.cpu().abs().sum(1) == 0
+    assert float((zr != zo).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("case", ["l1", "l2_b2", "l1_behind"])
+def test_differentiable_warping_api_and_backward(case):
+    """module.py:68 signature incl. the projection composed on the device, and d/d(src_fea)."""
+    from itermvs_amd.module import differentiable_warping
+    g = golden("warp_cases.npz")
+    src = cu(g[f"{case}.src"]).requires_grad_(True)
+    warped = differentiable_warping(src, cu(g[f"{case}.src_proj"]), cu(g[f"{case}.ref_proj"]), cu(g[f"{case}.depth"]))
+    ref = g[f"{case}.warped"]
+    assert maxdiff(warped, ref) <= 3e-4 * max(1.0, float(ref.abs().max()))
+    gen = torch.Generator().manual_seed(1)
+    gout = torch.randn(ref.shape, generator=gen)
+    warped.backward(cu(gout))
+    src_c = g[f"{case}.src"].clone().requires_grad_(True)
+    O.differentiable_warping(src_c, g[f"{case}.src_proj"], g[f"{case}.ref_proj"], g[f"{case}.depth"]).backward(gout)
+    scale = float(src_c.grad.abs().max())
+    assert maxdiff(src.grad, src_c.grad) <= 1e-3 * scale
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_ref_quarter(layout):
+    g = golden("e2e_small_seed0.npz")
+    ref = {l: g[f"feat.level{l}"][:, 0] for l in (1, 2, 3)}
+    want = O.ref_feature_quarter(ref)
+    want = torch.cat([want[1], want[2], want[3]], 1).permute(0, 2, 3, 1)
+    fm = {l: cu(ref[l]) for l in ref}
+    if layout == "nhwc":
+        fm = {l: t.contiguous(memory_format=torch.channels_last) for l, t in fm.items()}
+    got = ops().ref_quarter(fm[1], fm[2], fm[3])
+    assert got.shape == want.shape
+    assert maxdiff(got, want) <= 1e-6 * max(1.0, float(want.abs().max()))
+
+
+def _small(tag):
+    g = golden(f"e2e_small_{tag}.npz")
+    feats = {l: g[f"feat.level{l}"] for l in (1, 2, 3)}                    # [B,V,C,h,w]
+    b, v = feats[1].shape[:2]
+    cl = {l: cu(feats[l].reshape(b * v, *feats[l].shape[2:])).contiguous(memory_format=torch.channels_last)
+          for l in (1, 2, 3)}
+    pv = {l: cl[l].view(b, v, *cl[l].shape[1:]) for l in (1, 2, 3)}
+    src = {l: [pv[l][:, i] for i in range(1, v)] for l in (1, 2, 3)}
+    ref = {l: pv[l][:, 0] for l in (1, 2, 3)}
+    projs = torch.stack([g[f"proj.level_{l}"] for l in (1, 2, 3)])         # [3,B,V,4,4]
+    p12 = torch.stack([torch.stack([proj12_cpu(projs[i][:, s], projs[i][:, 0]) for s in range(1, v)], 1)
+                       for i in range(3)])                                   # [3,B,S,12] reference fp32 projections
+    inv_min = cu(1.0 / g["depth_min"])
+    inv_max = cu(1.0 / g["depth_max"])
+    return g, src, ref, cu(p12), inv_min, inv_max
+
+
+@pytest.mark.parametrize("tag", ["seed0", "dtu"])
+def test_corr_init_and_aggregate(tag):
+    g, src, ref, p12, inv_min, inv_max = _small(tag)
+    corr = ops().corr_init(src[3], ref[3], p12[2], inv_min, inv_max, 32)    # [B,S,32,8,h,w]
+    b, s = corr.shape[:2]
+    for i in range(s):
+        want = g[f"init.corr_view{i}"]                                      # [B,8,32,h,w]
+        got = corr[:, i].permute(0, 2, 1, 3, 4)
+        assert maxdiff(got, want) <= 2e-5 * max(1.0, float(want.abs().max())), i
+    # explicit hypotheses give the same result as in-kernel DepthInitialization
+    corr2 = ops().corr_init(src[3], ref[3], p12[2], inv_min, inv_max, depth=cu(g["init.samples"]))
+    assert maxdiff(corr, corr2) <= 1e-5 * max(1.0, float(corr.abs().max()))
+    # view-weighted aggregation against the reference's CorrNet input, using oracle view weights
+    w = load_weights(tag)
+    vws = [O.pixel_view_weight(w, g[f"init.corr_view{i}"]) for i in range(s)]       # [B,1,h,w] each
+    vw = torch.cat(vws, 1)                                                  # [B,S,h,w]
+    agg = ops().view_aggregate(corr, cu(vw))                                # [B,32,8,h,w]
+    want = g["init.agg"].permute(0, 2, 1, 3, 4)
+    assert maxdiff(agg, want) <= 5e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_softmax_max():
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn((6, 32, 8, 12), generator=gen) * 3
+    want = torch.softmax(x, 1).max(1, keepdim=True)[0]
+    assert maxdiff(ops().softmax_max(cu(x)), want) <= 1e-6
+
+
+@pytest.mark.parametrize("tag", ["seed0", "dtu"])
+@pytest.mark.parametrize("mode", ["explicit", "generated"])
+def test_corr_iter(tag, mode):
+    g, src, ref, p12, inv_min, inv_max = _small(tag)
+    ref_q = ops().ref_quarter(ref[1], ref[2], ref[3])
+    vw = cu(g["init.view_weights"])
+    from itermvs_amd.engine import sample_offsets
+    for it in range(int(g.np("iteration"))):
+        if mode == "explicit":
+            depth = {l: cu(g[f"iter{it}.samples.level{l}"]) for l in (1, 2, 3)}
+            aggs = ops().corr_iter(src, ref_q, p12, vw, inv_min, inv_max, depth=depth)
+        else:
+            aggs = ops().corr_iter(src, ref_q, p12, vw, inv_min, inv_max, norm_depth=cu(g[f"iter{it}.nd_in"]),
+                                   offsets=sample_offsets())
+        for i, l in enumerate((1, 2, 3)):
+            want = g[f"iter{it}.agg.level{l}"].permute(0, 2, 1, 3, 4)       # [B,N,8,h,w]
+            assert aggs[i].shape == want.shape
+            assert maxdiff(aggs[i], want) <= 5e-5 * max(1.0, float(want.abs().max())), (it, l)
+
+
+@pytest.mark.parametrize("tag", ["seed0", "dtu"])
+def test_prob_regress_bit_exact_indices(tag):
+    g = golden(f"e2e_small_{tag}.npz")
+    keys = [("logits0", "best0", "nd0")] + [(f"iter{it}.logits", f"iter{it}.best", f"iter{it}.nd")
+                                            for it in range(int(g.np("iteration")))]
+    for lk, bk, nk in keys:
+        logits = g[lk]
+        for layout in ("nchw", "nhwc"):
+            x = cu(logits)
+            if layout == "nhwc":
+                x = x.contiguous(memory_format=torch.channels_last)
+            nd, prob, best = ops().prob_regress(x, want_prob=True, want_best=True)
+            assert torch.equal(best.cpu(), g[bk]), (lk, layout)              # pixel indices bit-exact
+            assert maxdiff(nd, g[nk]) <= 1e-6
+            assert maxdiff(prob, torch.softmax(logits, 1)) <= 1e-6
+    # in-place destinations inside wider buffers
+    b, _, h, w = g["logits0"].shape
+    buf0 = torch.zeros((b, 5, h, w), device=DEV)
+    buf1 = torch.zeros((b, 5, h, w), device=DEV)
+    ops().prob_regress(cu(g["logits0"]), nd_out=[(buf0, 3), (buf1, 1)])
+    assert maxdiff(buf0[:, 3:4], g["nd0"]) <= 1e-6 and maxdiff(buf1[:, 1:2], g["nd0"]) <= 1e-6
+    assert float(buf0[:, :3].abs().max()) == 0.0 and float(buf1[:, 2:].abs().max()) == 0.0
+
+
+def test_prob_regress_edges():
+    """arg-max at the borders (window clamps, duplicates double-counted) and exact ties (first max)."""
+    b, h, w = 1, 2, 40
+    logits = torch.full((b, 256, h, w), -5.0)
+    for x in range(w):
+        logits[0, min(255, x * 7), 0, x] = 3.0          # peaks incl. bins 0..3 (left clamp)
+        logits[0, 255 - (x % 6), 1, x] = 3.0            # right clamp
+    logits[0, 10, 0, 5] = 3.0                            # tie with bin 35 -> first (10) wins
+    logits[0, 200, 1, 7] = 3.0
+    p = torch.softmax(logits, 1)
+    nd_ref, best_ref = O.window_regression(p)
+    nd, _, best = ops().prob_regress(cu(logits), want_best=True)
+    assert torch.equal(best.cpu(), best_ref)
+    assert maxdiff(nd, nd_ref) <= 1e-6
+
+
+@pytest.mark.parametrize("tag", ["seed0", "dtu"])
+def test_gru_gates(tag):
+    g = golden(f"e2e_small_{tag}.npz")
+    w = load_weights(tag)
+    it = 0
+    h_in, nd_in, score = g[f"iter{it}.hidden_in"], g[f"iter{it}.nd_in"], g[f"iter{it}.score"]
+    want = g[f"iter{it}.hidden"]
+    b, _, hh, ww = h_in.shape
+    hx = cu(torch.cat([h_in, nd_in, score], 1)).contiguous()
+    hx2 = hx.clone()
+    hx2[:, :32] = 0
+    p = "iter_mvs.update.gru."
+    w_zr = cu(torch.cat([w[p + "convz.weight"], w[p + "convr.weight"]], 0))
+    b_zr = cu(torch.cat([w[p + "convz.bias"], w[p + "convr.bias"]], 0))
+    zr = F.conv2d(hx, w_zr, b_zr, padding=2, dilation=2)
+    ops().gru_rh(zr, hx, hx2)
+    q = F.conv2d(hx2, cu(w[p + "convq.weight"]), cu(w[p + "convq.bias"]), padding=2, dilation=2)
+    hcopy = torch.empty((b, 32, hh, ww), device=DEV)
+    ops().gru_out(zr, q, hx, hcopy)
+    assert maxdiff(hx[:, :32], want) <= 2e-5
+    assert maxdiff(hcopy, want) <= 2e-5
+    assert maxdiff(hx[:, 32:], torch.cat([nd_in, score], 1)) == 0.0
+
+
+def test_pack_scores():
+    gen = torch.Generator().manual_seed(2)
+    s = [torch.randn((2, n, 6, 10), generator=gen) for n in (4, 4, 2)]
+    d0 = torch.zeros((2, 43, 6, 10), device=DEV)
+    d1 = torch.zeros((2, 43, 6, 10), device=DEV)
+    ops().pack_scores([cu(t) for t in s], d0, d1, 33)
+    want = torch.cat(s, 1)
+    assert maxdiff(d0[:, 33:], want) == 0.0 and maxdiff(d1[:, 33:], want) == 0.0
+    assert float(d0[:, :33].abs().max()) == 0.0
+
+
+def test_convex_upsample():
+    g = golden("upsample.npz")
+    x = g["x"]
+    b, _, h, w = x.shape
+    buf = torch.zeros((b, 3, h, w), device=DEV)
+    buf[:, 1:2] = cu(x)
+    inv_min, inv_max = cu(g["inv_min"].view(-1)), cu(g["inv_max"].view(-1))
+    for layout in ("nchw", "nhwc"):
+        lg = cu(g["logits"])
+        if layout == "nhwc":
+            lg = lg.contiguous(memory_format=torch.channels_last)
+        depth, norm = ops().convex_upsample(lg, buf, inv_min, inv_max, nd_channel=1, want_norm=True)
+        assert maxdiff(norm, g["up"]) <= 1e-6
+        assert float(((depth.cpu() - g["depth"]).abs() / g["depth"]).max()) <= 1e-6
+    from itermvs_amd.module import upsample, depth_unnormalization, depth_normalization
+    wsm = torch.softmax(g["logits"].view(b, 1, 9, 4, 4, h, w), dim=2)
+    assert maxdiff(upsample(cu(x), cu(wsm)), g["up"]) <= 2e-6
+    d = depth_unnormalization(cu(g["up"]), cu(g["inv_min"]), cu(g["inv_max"]))
+    assert float(((d.cpu() - g["depth"]).abs() / g["depth"]).max()) <= 1e-6
+    assert maxdiff(depth_normalization(cu(g["depth"]), cu(g["inv_min"]), cu(g["inv_max"])), g["renorm"]) <= 1e-5
+
+
+def test_bilinear_up():
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn((2, 5, 7, 9), generator=gen)
+    for s in (2, 4):
+        assert maxdiff(ops().bilinear_up(cu(x), s), F.interpolate(x, scale_factor=s, mode="bilinear")) <= 1e-6
+    assert maxdiff(ops().bilinear_up(cu(x), 2, act="tanh"), torch.tanh(F.interpolate(x, scale_factor=2, mode="bilinear"))) <= 1e-6
+
+
+def test_ragged_sizes_and_many_views():
+    """pixel count not a multiple of the tile, non-integer map/grid ratios, S = 10 source views
+    (the pair.txt maximum), B = 2."""
+    gen = torch.Generator().manual_seed(12)
+    from itermvs_amd import synthetic
+    b, v = 2, 11
+    sm = synthetic.make_sample(b, v, 96, 160, seed=5)
+    h, w = 23, 37                                              # 851 pixels
+    sizes = {1: (46, 74), 2: (23, 37), 3: (12, 19)}
+    chans = {1: 16, 2: 32, 3: 48}
+    feats = {l: torch.randn((b, v, chans[l]) + sizes[l], generator=gen) for l in (1, 2, 3)}
+    ref_q = torch.randn((b, h, w, 96), generator=gen)
+    projs = torch.stack([sm["proj_matrices"][f"level_{l}"] for l in (1, 2, 3)])
+    p12 = torch.stack([torch.stack([proj12_cpu(projs[i][:, s], projs[i][:, 0]) for s in range(1, v)], 1)
+                       for i in range(3)])
+    vw = torch.rand((b, v - 1, h, w), generator=gen)
+    depth = {l: 425 + 510 * torch.rand((b, n, h, w), generator=gen) for l, n in ((1, 4), (2, 4), (3, 2))}
+    cl = {l: cu(feats[l].reshape(b * v, *feats[l].shape[2:])).contiguous(memory_format=torch.channels_last)
+          for l in feats}
+    pv = {l: cl[l].view(b, v, *cl[l].shape[1:]) for l in feats}
+    src = {l: [pv[l][:, i] for i in range(1, v)] for l in feats}
+    inv_min, inv_max = cu(torch.full((b,), 1 / 425.0)), cu(torch.full((b,), 1 / 935.0))
+    aggs = ops().corr_iter(src, cu(ref_q), cu(p12), cu(vw), inv_min, inv_max, depth={l: cu(d) for l, d in depth.items()})
+    off = {1: 0, 2: 16, 3: 48}
+    for i, l in enumerate((1, 2, 3)):
+        refl = ref_q[..., off[l]:off[l] + chans[l]].permute(0, 3, 1, 2)
+        acc, wsum = 0, 1e-5
+        for s in range(1, v):
+            m = torch.cat([p12[i][:, s - 1].view(b, 3, 4), torch.zeros(b, 1, 4)], 1)
+            ix, iy, _ = O.warp_source_coords(m, depth[l], sizes[l][0], sizes[l][1])
+            corr = O.group_correlation(O.bilinear_gather(feats[l][:, s], ix, iy), refl)
+            wv = vw[:, s - 1].view(b, 1, 1, h, w)
+            acc = acc + corr * wv
+            wsum = wsum + wv
+        want = (acc / wsum).permute(0, 2, 1, 3, 4)
+        assert float((want != 0).float().mean()) > 0.3          # the case really samples inside the maps
+        assert maxdiff(aggs[i], want) <= 5e-5 * max(1.0, float(want.abs().max())), l
+
+
+def test_error_codes_on_gpu_tensors():
+    o = ops()
+    with pytest.raises(RuntimeError, match="CUDA"):
+        o.bilinear_up(torch.zeros(1, 1, 2, 2), 2)
+    x = torch.zeros((1, 20, 4, 4), device=DEV).contiguous(memory_format=torch.channels_last)   # C=20 unsupported
+    with pytest.raises(RuntimeError, match="channel"):
+        o.corr_init([x], x, torch.zeros((1, 1, 12), device=DEV), torch.ones(1, device=DEV), torch.ones(1, device=DEV))
+    y = torch.zeros((1, 48, 4, 4), device=DEV)                                                  # NCHW -> layout error
+    with pytest.raises(RuntimeError, match="channels-last"):
+        o.corr_init([y], y, torch.zeros((1, 1, 12), device=DEV), torch.ones(1, device=DEV), torch.ones(1, device=DEV))
