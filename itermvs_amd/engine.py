@@ -94,9 +94,9 @@ class InferenceEngine:
         f2 = self._res(self._res(f1, "layer2.0.", 2), "layer2.1.", 1)
         f3 = self._res(self._res(f2, "layer3.0.", 2), "layer3.1.", 1)
         o3 = F.conv2d(f3, w[p + "output3.weight"], w[p + "output3.bias"], padding=1)
-        mid = F.interpolate(f3, scale_factor=2, mode="bilinear").add_(F.conv2d(f2, w[p + "inner2.weight"], w[p + "inner2.bias"]))
+        mid = ops.bilinear_up(f3, 2).add_(F.conv2d(f2, w[p + "inner2.weight"], w[p + "inner2.bias"]))   # net.py:46
         o2 = F.conv2d(mid, w[p + "output2.weight"], w[p + "output2.bias"], padding=1)
-        mid = F.interpolate(mid, scale_factor=2, mode="bilinear").add_(F.conv2d(f1, w[p + "inner1.weight"], w[p + "inner1.bias"]))
+        mid = ops.bilinear_up(mid, 2).add_(F.conv2d(f1, w[p + "inner1.weight"], w[p + "inner1.bias"]))  # net.py:49
         o1 = F.conv2d(mid, w[p + "output1.weight"], w[p + "output1.bias"], padding=1)
         return {1: o1, 2: o2, 3: o3}
 
@@ -162,7 +162,8 @@ class InferenceEngine:
         inv_max = (1.0 / depth_max).contiguous()
 
         # convex up-sampling logits from the reference level-2 feature (itermvs.py:262-263)
-        ref2_nchw = feats[2].view(b, v, *feats[2].shape[1:])[:, 0]
+        # (packed copy: a strided batch-1 view would send MIOpen to its naive non-packed kernel)
+        ref2_nchw = feats[2][:1] if b == 1 else feats[2].view(b, v, *feats[2].shape[1:])[:, 0].contiguous()
         u = "iter_mvs.upsample."
         up_logits = F.conv2d(F.relu_(F.conv2d(ref2_nchw, w[u + "0.weight"], padding=1)), w[u + "2.weight"])
 

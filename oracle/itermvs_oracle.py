@@ -24,6 +24,10 @@ exact x2 / x0.5 / x4 bilinear cases used (align_corners=False), ``F.unfold`` +
 in the depth regression.  Dense 2-D convolutions call ``F.conv2d`` /
 ``F.conv_transpose2d``.
 
+All helper tensors are created on the device of the inputs, so the same restatement can be
+run with PyTorch-ROCm tensors by the diagnostics under tests/ ("what does the reference's
+algorithm give on this GPU with stock PyTorch ops").
+
 Weights are passed as a flat ``dict[str, Tensor]`` keyed like the reference's
 state_dict without the ``module.`` prefix.
 """
@@ -74,7 +78,7 @@ def initial_depth_samples(inv_min: Tensor, inv_max: Tensor, h: int, w: int,
                           num: int = INIT_SAMPLES) -> Tensor:
     """itermvs.py:11-19: ``num`` hypotheses uniform in inverse depth -> [B,num,h,w]."""
     b = inv_min.shape[0]
-    k = torch.arange(num, dtype=torch.float32).view(1, num, 1, 1)
+    k = torch.arange(num, dtype=torch.float32, device=inv_min.device).view(1, num, 1, 1)
     frac = k.expand(b, num, h, w) / (num - 1)
     return 1.0 / (inv_max + frac * (inv_min - inv_max))
 
@@ -92,7 +96,7 @@ def resize_bilinear(x: Tensor, scale: float) -> Tensor:
     oh, ow = int(math.floor(h * scale)), int(math.floor(w * scale))
 
     def axis(n_in: int, n_out: int):
-        d = torch.arange(n_out, dtype=torch.float32)
+        d = torch.arange(n_out, dtype=torch.float32, device=x.device)
         s = (d + 0.5) * (1.0 / scale) - 0.5
         s = torch.clamp(s, min=0.0)
         i0 = s.floor().to(torch.int64)
@@ -132,11 +136,12 @@ def warp_source_coords(proj: Tensor, depth: Tensor, h1: int, w1: int
     b, n, h, w = depth.shape
     rot = proj[:, :3, :3]
     trans = proj[:, :3, 3]
-    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32),
-                            torch.arange(w, dtype=torch.float32), indexing="ij")
+    dev = depth.device
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=dev),
+                            torch.arange(w, dtype=torch.float32, device=dev), indexing="ij")
     xs = xs * (w1 / w)                      # module.py:95-96 (python float ratio)
     ys = ys * (h1 / h)
-    pix = torch.stack((xs.reshape(-1), ys.reshape(-1), torch.ones(h * w)))  # [3,HW]
+    pix = torch.stack((xs.reshape(-1), ys.reshape(-1), torch.ones(h * w, device=dev)))  # [3,HW]
     ray = torch.matmul(rot, pix.unsqueeze(0).expand(b, 3, h * w))           # [B,3,HW]
     pts = ray.unsqueeze(2) * depth.reshape(b, 1, n, h * w)                  # [B,3,N,HW]
     pts = pts + trans.view(b, 3, 1, 1)
@@ -171,7 +176,7 @@ def bilinear_gather(src: Tensor, ix: Tensor, iy: Tensor) -> Tensor:
     w_sw = (fx1 - ix) * (iy - fy0)
     w_se = (ix - fx0) * (iy - fy0)
     flat = src.reshape(b, c, h1 * w1)
-    out = torch.zeros((b, c) + tuple(shp[1:]), dtype=src.dtype)
+    out = torch.zeros((b, c) + tuple(shp[1:]), dtype=src.dtype, device=src.device)
 
     def tap(fx: Tensor, fy: Tensor, wt: Tensor) -> None:
         inside = (fx >= 0) & (fx <= w1 - 1) & (fy >= 0) & (fy <= h1 - 1)   # NaN -> False
@@ -267,7 +272,7 @@ def evaluation_init(wts: Weights, ref_l3: Tensor, src_l3: Sequence[Tensor],
     score = corr_net(wts, agg, 3)                               # :70 (corr_conv1[-1])
     view_weights = torch.cat(weights_up, dim=1)
     prob = torch.softmax(score, dim=1)
-    k = torch.arange(n, dtype=torch.float32).view(1, n, 1, 1)
+    k = torch.arange(n, dtype=torch.float32, device=score.device).view(1, n, 1, 1)
     idx = (k * prob).sum(dim=1, keepdim=True)
     depth = depth_unnormalization(idx / (n - 1.0), inv_min, inv_max)
     depth = resize_bilinear(depth, 2.0)                         # :80-81
@@ -314,7 +319,7 @@ def iteration_depth_samples(nd: Tensor, inv_min: Tensor, inv_max: Tensor) -> Dic
     """itermvs.py:290-293: hypotheses around the current normalised depth."""
     out = {}
     for lvl in (1, 2, 3):
-        off = torch.tensor(CORR_INTERVAL[lvl], dtype=torch.float32).view(1, -1, 1, 1) * INTERVAL_SCALE
+        off = torch.tensor(CORR_INTERVAL[lvl], dtype=torch.float32, device=nd.device).view(1, -1, 1, 1) * INTERVAL_SCALE
         out[lvl] = depth_unnormalization(torch.clamp(nd + off, min=0, max=1), inv_min, inv_max)
     return out
 
@@ -352,7 +357,7 @@ def window_regression(prob: Tensor, radius: int = WINDOW_RADIUS) -> Tuple[Tensor
     bins = prob.shape[1]
     with torch.no_grad():
         best = torch.argmax(prob, dim=1, keepdim=True)
-        offs = torch.arange(-radius, radius + 1).view(1, -1, 1, 1)
+        offs = torch.arange(-radius, radius + 1, device=prob.device).view(1, -1, 1, 1)
         win = torch.clamp(best + offs, 0, bins - 1)             # int64 [B,9,H,W]
     num = 0
     den = 1e-6
@@ -398,9 +403,9 @@ def convex_upsample(x: Tensor, weight: Tensor, scale: int = 4) -> Tensor:
     out[b,0,s*y+i,s*x+j] = sum_k weight[b,0,k,i,j,y,x] * x_pad[y+k//3-1, x+k%3-1]
     with replicate padding (restates ReplicationPad2d + F.unfold)."""
     b, _, h, w = x.shape
-    yy = torch.arange(h).view(h, 1)
-    xx = torch.arange(w).view(1, w)
-    out = torch.zeros(b, 1, scale, scale, h, w, dtype=x.dtype)
+    yy = torch.arange(h, device=x.device).view(h, 1)
+    xx = torch.arange(w, device=x.device).view(1, w)
+    out = torch.zeros(b, 1, scale, scale, h, w, dtype=x.dtype, device=x.device)
     for k in range(9):
         ny = torch.clamp(yy + (k // 3 - 1), 0, h - 1)
         nx = torch.clamp(xx + (k % 3 - 1), 0, w - 1)
