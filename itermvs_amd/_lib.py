@@ -36,7 +36,7 @@ class LevelSrc(C.Structure):
 class CorrIterParams(C.Structure):
     """itermvs_corr_iter_params"""
     _fields_ = [("B", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("N", C.c_int32 * 3), ("_pad0", C.c_int32),
+                ("N", C.c_int32 * 3), ("impl", C.c_int32),
                 ("src", LevelSrc * 3),
                 ("ref_q", C.c_void_p), ("proj", C.c_void_p), ("view_w", C.c_void_p),
                 ("depth", C.c_void_p * 3), ("norm_depth", C.c_void_p), ("norm_depth_sb", C.c_int64),

@@ -20,6 +20,7 @@ static inline int itermvs_launch_status() {
 // timing hooks (profile.cpp)
 void itermvs_profile_begin(int kind, hipStream_t stream);
 void itermvs_profile_end(int kind, hipStream_t stream);
+void itermvs_profile_cancel();
 
 namespace itermvs {
 
@@ -51,6 +52,49 @@ __device__ __forceinline__ void ray_dir(const float* __restrict__ m, float xs, f
     rx = fmaf(m[1], ys, m[0] * xs) + m[2];
     ry = fmaf(m[5], ys, m[4] * xs) + m[6];
     rz = fmaf(m[9], ys, m[8] * xs) + m[10];
+}
+
+// x / y with one v_rcp_f32 and a one-step residual correction: q = x*r; q += (x - q*y)*r.
+// Correctly rounded except for rare half-ulp ties (the IEEE expansion is ~10 instructions and the
+// gather kernels are VALU-issue bound); -DITERMVS_EXACT_DIV restores plain IEEE division.
+__device__ __forceinline__ float div_rcp(float x, float y, float r) {
+#ifdef ITERMVS_EXACT_DIV
+    (void)r;
+    return x / y;
+#else
+    const float q = x * r;
+    return fmaf(fmaf(-q, y, x), r, q);
+#endif
+}
+__device__ __forceinline__ float rcp_approx(float y) { return __builtin_amdgcn_rcpf(y); }
+
+// same arithmetic as project() below with the three divisors' reciprocals shared / precomputed
+struct WarpRcp {
+    float r_half_w, r_half_h;
+};
+__device__ __forceinline__ WarpRcp make_rcp(const WarpGeom& g) {
+    WarpRcp r;
+    r.r_half_w = (float)(1.0 / (double)g.half_w);
+    r.r_half_h = (float)(1.0 / (double)g.half_h);
+    return r;
+}
+__device__ __forceinline__ void project_fast(const WarpGeom& g, const WarpRcp& rc, const float* __restrict__ m, float rx,
+                                             float ry, float rz, float d, float& ix, float& iy) {
+    float X = rx * d + m[3];
+    float Y = ry * d + m[7];
+    float Z = rz * d + m[11];
+    if (!(Z > 1e-2f)) {  // module.py:105-108
+        X = g.gw;
+        Y = g.gh;
+        Z = 1.0f;
+    }
+    const float rz1 = rcp_approx(Z);
+    const float px = div_rcp(X, Z, rz1);
+    const float py = div_rcp(Y, Z, rz1);
+    const float gx = div_rcp(px, g.half_w, rc.r_half_w) - 1.0f;   // module.py:112-113
+    const float gy = div_rcp(py, g.half_h, rc.r_half_h) - 1.0f;
+    ix = ((gx + 1.0f) * 0.5f) * g.w1m1;                           // GridSampler.h:31
+    iy = ((gy + 1.0f) * 0.5f) * g.h1m1;
 }
 
 // returns the un-normalised source coordinates (ix, iy); `valid` follows module.py:105,110-111

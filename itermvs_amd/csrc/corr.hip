@@ -14,6 +14,8 @@
 //   carries the view-weighted accumulators in registers.
 //   Results are transposed through LDS so the [B,N,8,H,W] planes CorrNet / PixelViewWeight
 //   consume are written as full rows of TILE pixels.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace itermvs {
@@ -22,52 +24,142 @@ constexpr int kThreads = 256;
 
 template <int CPG>
 struct Chunk {
-    static constexpr int VEC = (CPG == 6) ? 6 : 4;  // floats per lane
-    static constexpr int LPT = (CPG == 2) ? 4 : 8;  // lanes per tap == C / VEC
-    static constexpr int NG = (CPG == 2) ? 2 : 1;   // correlation groups per lane
+    // lane j of a (pixel, hypothesis) group owns the float4 at channel 4*j of every 16-channel block:
+    //   C=16: 4 lanes x 1 float4            (two correlation groups of 2 per lane)
+    //   C=32: 8 lanes x 1 float4            (one group of 4 per lane)
+    //   C=48: 4 lanes x 3 float4 (stride 16 channels): every load instruction of the group covers one
+    //         contiguous 64-byte run (one L1 access) -- a "6 floats per lane" layout costs 9 accesses
+    //         per tap instead of 3 and made the L1 tag rate the bound of the whole kernel.  The lane's
+    //         12 channels straddle the 6-channel correlation groups; partial sums are re-grouped with
+    //         four quad-local DPP moves (see blend_corr).
+    static constexpr int VEC = (CPG == 6) ? 12 : 4;  // floats per lane
+    static constexpr int LPT = (CPG == 4) ? 8 : 4;   // lanes per tap
+    static constexpr int NG = (CPG == 4) ? 1 : 2;    // correlation groups finalised per lane
 };
+
+// channel of element c of lane j's chunk
+template <int VEC>
+__device__ __forceinline__ int chunk_channel(int j, int c) {
+    return 16 * (c / 4) + 4 * j + (c % 4);
+}
 
 template <int VEC>
 __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[VEC]) {
-    if constexpr (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-        const float2 a = reinterpret_cast<const float2*>(p)[0];
-        const float2 b = reinterpret_cast<const float2*>(p)[1];
-        const float2 c = reinterpret_cast<const float2*>(p)[2];
-        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+#pragma unroll
+    for (int i = 0; i < VEC / 4; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(p + 16 * i);
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
     }
+}
+
+// v_mov_b32 dpp quad_perm: lane l of each quad reads lane ((CTRL >> 2*l) & 3) of the same quad
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+#define ITERMVS_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+
+// Everything about one bilinear footprint that is identical for the chunk lanes of a
+// (pixel, hypothesis): 32-bit element offsets of the two rows / two columns and the four weights
+// (already zero for out-of-range taps).  Computed by ONE lane and broadcast with shuffles.
+struct Footprint {
+    uint32_t r0, r1, c0, c1;
+    float nw, ne, sw, se;
+};
+
+__device__ __forceinline__ Footprint make_footprint(float ix, float iy, int W1, int H1, uint32_t sy, uint32_t sx) {
+    const Taps t = make_taps(ix, iy, W1, H1);
+    Footprint f;
+    f.r0 = (uint32_t)t.y0 * sy; f.r1 = (uint32_t)t.y1 * sy;
+    f.c0 = (uint32_t)t.x0 * sx; f.c1 = (uint32_t)t.x1 * sx;
+    f.nw = t.nw; f.ne = t.ne; f.sw = t.sw; f.se = t.se;
+    return f;
+}
+
+__device__ __forceinline__ Footprint shfl_footprint(const Footprint& f, int src_lane) {
+    Footprint o;
+    o.r0 = (uint32_t)__shfl((int)f.r0, src_lane, 64); o.r1 = (uint32_t)__shfl((int)f.r1, src_lane, 64);
+    o.c0 = (uint32_t)__shfl((int)f.c0, src_lane, 64); o.c1 = (uint32_t)__shfl((int)f.c1, src_lane, 64);
+    o.nw = __shfl(f.nw, src_lane, 64); o.ne = __shfl(f.ne, src_lane, 64);
+    o.sw = __shfl(f.sw, src_lane, 64); o.se = __shfl(f.se, src_lane, 64);
+    return o;
+}
+
+// group correlation of one lane's chunk for one view: bilinear blend of the four taps, product
+// with the reference chunk, mean over the channels of each group (itermvs.py:50-51).
+// `fb` is wave-uniform (SGPR base), tap offsets are 32-bit element offsets (saddr + voffset loads).
+template <int VEC>
+struct TapData {
+    float v00[VEC], v01[VEC], v10[VEC], v11[VEC];
+};
+
+// `fb` is wave-uniform (SGPR base), tap offsets are 32-bit element offsets (saddr + voffset loads).
+template <int VEC>
+__device__ __forceinline__ void load_taps(const float* __restrict__ fb, uint32_t joff, const Footprint& tp, TapData<VEC>& t) {
+    const uint32_t r0 = tp.r0 + joff, r1 = tp.r1 + joff;
+    load_vec<VEC>(fb + (r0 + tp.c0), t.v00);
+    load_vec<VEC>(fb + (r0 + tp.c1), t.v01);
+    load_vec<VEC>(fb + (r1 + tp.c0), t.v10);
+    load_vec<VEC>(fb + (r1 + tp.c1), t.v11);
 }
 
 // group correlation of one lane's chunk for one view: bilinear blend of the four taps, product
 // with the reference chunk, mean over the channels of each group (itermvs.py:50-51).
 template <int CPG>
-__device__ __forceinline__ void chunk_corr(const float* __restrict__ fb, int64_t sy, int64_t sx, const Taps& tp,
+__device__ __forceinline__ void blend_corr(const TapData<Chunk<CPG>::VEC>& t, const Footprint& tp,
                                            const float (&refv)[Chunk<CPG>::VEC], float (&corr)[Chunk<CPG>::NG]) {
     constexpr int VEC = Chunk<CPG>::VEC;
-    float v00[VEC], v01[VEC], v10[VEC], v11[VEC];
-    const float* r0 = fb + tp.y0 * sy;
-    const float* r1 = fb + tp.y1 * sy;
-    load_vec<VEC>(r0 + tp.x0 * sx, v00);
-    load_vec<VEC>(r0 + tp.x1 * sx, v01);
-    load_vec<VEC>(r1 + tp.x0 * sx, v10);
-    load_vec<VEC>(r1 + tp.x1 * sx, v11);
     float w[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c)
-        w[c] = fmaf(tp.se, v11[c], fmaf(tp.sw, v10[c], fmaf(tp.ne, v01[c], tp.nw * v00[c])));
+        w[c] = fmaf(tp.se, t.v11[c], fmaf(tp.sw, t.v10[c], fmaf(tp.ne, t.v01[c], tp.nw * t.v00[c])));
     if constexpr (CPG == 2) {
         corr[0] = fmaf(w[1], refv[1], w[0] * refv[0]) * 0.5f;
         corr[1] = fmaf(w[3], refv[3], w[2] * refv[2]) * 0.5f;
     } else if constexpr (CPG == 4) {
         corr[0] = fmaf(w[3], refv[3], fmaf(w[2], refv[2], fmaf(w[1], refv[1], w[0] * refv[0]))) * 0.25f;
     } else {
-        float s = w[0] * refv[0];
+        // lane j (= lane & 3) holds channels 16i + 4j + k (i = 0..2, k = 0..3); group g = channels
+        // 6g .. 6g+5.  lo_i / hi_i = products of the lower / upper channel pair of block i:
+        //   g0 = s0[j0] + lo0[j1]   g1 = hi0[j1] + s0[j2]      (s_i = lo_i + hi_i)
+        //   g2 = s0[j3] + lo1[j0]   g3 = hi1[j0] + s1[j1]
+        //   g4 = s1[j2] + lo1[j3]   g5 = hi1[j3] + s2[j0]
+        //   g6 = s2[j1] + lo2[j2]   g7 = hi2[j2] + s2[j3]
+        // lane d finalises groups 2d and 2d+1; each source lane selects what it owes and one
+        // quad_perm per term delivers it.
+        float lo[3], hi[3];
 #pragma unroll
-        for (int c = 1; c < 6; ++c) s = fmaf(w[c], refv[c], s);
-        corr[0] = s / 6.0f;
+        for (int i = 0; i < 3; ++i) {
+            lo[i] = fmaf(w[4 * i + 1], refv[4 * i + 1], w[4 * i] * refv[4 * i]);
+            hi[i] = fmaf(w[4 * i + 3], refv[4 * i + 3], w[4 * i + 2] * refv[4 * i + 2]);
+        }
+        const float s0 = lo[0] + hi[0], s1 = lo[1] + hi[1], s2 = lo[2] + hi[2];
+        const int j = threadIdx.x & 3;
+        const float ta = (j == 0 || j == 3) ? s0 : (j == 2 ? s1 : s2);
+        const float tb = (j == 1) ? lo[0] : (j == 2 ? lo[2] : lo[1]);
+        const float tc = (j == 1) ? hi[0] : (j == 2 ? hi[2] : hi[1]);
+        const float tdd = (j == 2) ? s0 : (j == 1 ? s1 : s2);
+        const float g_first = quad_perm<ITERMVS_QP(0, 3, 2, 1)>(ta) + quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tb);
+        const float g_second = quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tc) + quad_perm<ITERMVS_QP(2, 1, 0, 3)>(tdd);
+        corr[0] = g_first / 6.0f;
+        corr[1] = g_second / 6.0f;
     }
+}
+
+template <int CPG>
+__device__ __forceinline__ void chunk_corr(const float* __restrict__ fb, uint32_t joff, const Footprint& tp,
+                                           const float (&refv)[Chunk<CPG>::VEC], float (&corr)[Chunk<CPG>::NG]) {
+    TapData<Chunk<CPG>::VEC> t;
+    load_taps<Chunk<CPG>::VEC>(fb, joff, tp, t);
+    blend_corr<CPG>(t, tp, refv, corr);
+}
+
+// XCD-aware tile order: block k is observed to run on XCD k % 8 (a speed assumption only), so give
+// each XCD a contiguous band of pixel tiles; neighbouring tiles then share one L2 instead of having
+// every L2 fetch its own copy of the same source lines.  grid.x is a multiple of 8.
+__device__ __forceinline__ int xcd_tile(int tiles) {
+    const int per_xcd = (tiles + 7) / 8;
+    return (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -94,27 +186,33 @@ struct IterArgs {
     int B, S, H, W, CQ;
 };
 
-template <int CPG, int TILE>
+template <int CPG, int TILE, int U>
 __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLevel& L, int lvl, float* __restrict__ lds) {
     using K = Chunk<CPG>;
+    constexpr int LS = TILE + 1;  // padded LDS row: the transposed writes hit distinct banks
     const int N = L.N;
     const int b = blockIdx.z;
     const int P = a.H * a.W;
-    const int p0 = blockIdx.x * TILE;
+    const int tile = xcd_tile((P + TILE - 1) / TILE);
+    const int p0 = tile * TILE;
+    if (p0 >= P) return;          // padding blocks of the XCD-aligned grid (uniform per block)
     const int per_px = N * K::LPT;
     const int items = TILE * per_px;
     const WarpGeom g = make_geom(a.W, a.H, L.W1, L.H1);
+    const WarpRcp rc = make_rcp(g);
     const float inv_min = a.inv_min[b], inv_max = a.inv_max[b];
     const float* proj = a.proj + ((size_t)(lvl * a.B + b) * a.S) * 12;
+    const uint32_t sy = (uint32_t)L.sy, sx = (uint32_t)L.sx;
+    const int lane = threadIdx.x & 63;
 
 #pragma unroll 1
     for (int item = threadIdx.x; item < items; item += kThreads) {
         const int px = item / per_px;
         const int rem = item - px * per_px;
         const int n = rem / K::LPT;
-        const int j = rem - n * K::LPT;
+        const int j = rem - n * K::LPT;      // the LPT lanes of one (pixel, hypothesis) are adjacent lanes
         const int p = p0 + px;
-        if (p >= P) continue;
+        if (p >= P) continue;                // whole lane groups drop out together
         const int y = p / a.W, x = p - y * a.W;
 
         float d;
@@ -126,47 +224,73 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
             d = unnormalize_depth(ns, inv_min, inv_max);
         }
         float refv[K::VEC];
-        load_vec<K::VEC>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff + j * K::VEC, refv);
+        load_vec<K::VEC>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff + j * 4, refv);
 
         const float xs = (float)x * g.xr, ys = (float)y * g.yr;
         float acc[K::NG];
 #pragma unroll
         for (int q = 0; q < K::NG; ++q) acc[q] = 0.0f;
         float wsum = 1e-5f;  // itermvs.py:88
-        const int64_t boff = (int64_t)b * L.sb + j * K::VEC;
-        for (int s = 0; s < a.S; ++s) {
-            const float* m = proj + s * 12;
-            float rx, ry, rz, ix, iy;
-            ray_dir(m, xs, ys, rx, ry, rz);
-            project(g, m, rx, ry, rz, d, ix, iy, nullptr);
-            const Taps tp = make_taps(ix, iy, L.W1, L.H1);
-            float corr[K::NG];
-            chunk_corr<CPG>(L.src[s] + boff, L.sy, L.sx, tp, refv, corr);
-            const float w = a.view_w[((size_t)b * a.S + s) * P + p];
+        const uint32_t joff = (uint32_t)(j * 4);
+        const int gbase = lane - j;
+        // The projection and bilinear footprint of (pixel, hypothesis) in view s are the same for
+        // all LPT chunk lanes: lane j computes them for view s0 + j, then the group walks the batch of
+        // views and every lane fetches the footprint of view s0 + k from lane k (wavefront shuffles).
+        for (int s0 = 0; s0 < a.S; s0 += K::LPT) {
+            Footprint mine = {0u, 0u, 0u, 0u, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (s0 + j < a.S) {
+                const float* m = proj + (s0 + j) * 12;
+                float rx, ry, rz, ix, iy;
+                ray_dir(m, xs, ys, rx, ry, rz);
+                project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
+                mine = make_footprint(ix, iy, L.W1, L.H1, sy, sx);
+            }
+            const int nb = min(K::LPT, a.S - s0);
+            // U views at a time: all 4*U tap loads are issued before the first blend (memory-level
+            // parallelism; the per-wave critical path is what bounds this kernel, not bandwidth)
+            for (int k0 = 0; k0 < nb; k0 += U) {
+                Footprint tp[U];
+                TapData<K::VEC> td[U];
+                float wv[U];
 #pragma unroll
-            for (int q = 0; q < K::NG; ++q) acc[q] = acc[q] + corr[q] * w;  // itermvs.py:115
-            wsum = wsum + w;                                                // itermvs.py:116
+                for (int u = 0; u < U; ++u) {
+                    const int k = min(k0 + u, nb - 1);      // tail: re-reads the last view, result unused
+                    tp[u] = shfl_footprint(mine, gbase + k);
+                    load_taps<K::VEC>(L.src[s0 + k] + (int64_t)b * L.sb, joff, tp[u], td[u]);
+                    wv[u] = a.view_w[((size_t)b * a.S + s0 + k) * P + p];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (k0 + u < nb) {
+                        float corr[K::NG];
+                        blend_corr<CPG>(td[u], tp[u], refv, corr);
+#pragma unroll
+                        for (int q = 0; q < K::NG; ++q) acc[q] = acc[q] + corr[q] * wv[u];  // itermvs.py:115
+                        wsum = wsum + wv[u];                                                // itermvs.py:116
+                    }
+                }
+            }
         }
 #pragma unroll
-        for (int q = 0; q < K::NG; ++q) lds[(n * ITERMVS_GROUPS + j * K::NG + q) * TILE + px] = acc[q] / wsum;
+        for (int q = 0; q < K::NG; ++q) lds[(n * ITERMVS_GROUPS + j * K::NG + q) * LS + px] = acc[q] / wsum;
     }
     __syncthreads();
     const int rows = N * ITERMVS_GROUPS;
     for (int idx = threadIdx.x; idx < rows * TILE; idx += kThreads) {
         const int row = idx / TILE, px = idx - row * TILE;
-        if (p0 + px < P) L.out[((size_t)b * rows + row) * P + p0 + px] = lds[row * TILE + px];
+        if (p0 + px < P) L.out[((size_t)b * rows + row) * P + p0 + px] = lds[row * LS + px];
     }
 }
 
-template <int TILE>
+template <int TILE, int U>
 __global__ void __launch_bounds__(kThreads) corr_iter_kernel(const IterArgs a) {
-    __shared__ float lds[ITERMVS_MAX_HYP * ITERMVS_GROUPS * TILE];
+    __shared__ float lds[ITERMVS_MAX_HYP * ITERMVS_GROUPS * (TILE + 1)];
     const int lvl = blockIdx.y;
     const IterLevel& L = a.lv[lvl];
     switch (L.C) {
-        case 16: corr_iter_level<2, TILE>(a, L, lvl, lds); break;
-        case 32: corr_iter_level<4, TILE>(a, L, lvl, lds); break;
-        default: corr_iter_level<6, TILE>(a, L, lvl, lds); break;
+        case 16: corr_iter_level<2, TILE, U>(a, L, lvl, lds); break;
+        case 32: corr_iter_level<4, TILE, U>(a, L, lvl, lds); break;
+        default: corr_iter_level<6, TILE, U>(a, L, lvl, lds); break;
     }
 }
 
@@ -189,56 +313,76 @@ struct InitArgs {
 template <int CPG, int TILE>
 __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restrict__ lds) {
     using K = Chunk<CPG>;
+    constexpr int LS = TILE + 1;
     const int nblocks = (a.N + a.NB - 1) / a.NB;
     const int s = blockIdx.y / nblocks;
     const int n0 = (blockIdx.y - s * nblocks) * a.NB;
     const int nb = min(a.NB, a.N - n0);
     const int b = blockIdx.z;
     const int P = a.H * a.W;
-    const int p0 = blockIdx.x * TILE;
-    const int per_px = nb * K::LPT;
+    const int tile = xcd_tile((P + TILE - 1) / TILE);
+    const int p0 = tile * TILE;
+    if (p0 >= P) return;
+    const int ngrp = (nb + K::LPT - 1) / K::LPT;   // groups of LPT hypotheses
+    const int per_px = ngrp * K::LPT;
     const int items = TILE * per_px;
     const WarpGeom g = make_geom(a.W, a.H, a.W1, a.H1);
+    const WarpRcp rc = make_rcp(g);
     const float inv_min = a.inv_min[b], inv_max = a.inv_max[b];
     const float* m = a.proj + ((size_t)b * a.S + s) * 12;
     const float* fsrc = a.src[s] + (int64_t)b * a.sb;
+    const uint32_t sy = (uint32_t)a.sy, sx = (uint32_t)a.sx;
+    const int lane = threadIdx.x & 63;
 
 #pragma unroll 1
     for (int item = threadIdx.x; item < items; item += kThreads) {
         const int px = item / per_px;
         const int rem = item - px * per_px;
-        const int nl = rem / K::LPT;
-        const int j = rem - nl * K::LPT;
-        const int n = n0 + nl;
+        const int grp = rem / K::LPT;
+        const int j = rem - grp * K::LPT;
         const int p = p0 + px;
         if (p >= P) continue;
         const int y = p / a.W, x = p - y * a.W;
-        float d;
-        if (a.depth) {
-            d = a.depth[((size_t)b * a.N + n) * P + p];
-        } else {  // itermvs.py:13-17
-            const float frac = (float)n / (float)(a.N - 1);
-            d = 1.0f / (inv_max + frac * (inv_min - inv_max));
-        }
         float refv[K::VEC];
 #pragma unroll
         for (int c = 0; c < K::VEC; ++c)
-            refv[c] = a.ref.data[b * a.ref.sb + (j * K::VEC + c) * a.ref.sc + y * a.ref.sy + x * a.ref.sx];
-        float rx, ry, rz, ix, iy;
-        ray_dir(m, (float)x * g.xr, (float)y * g.yr, rx, ry, rz);
-        project(g, m, rx, ry, rz, d, ix, iy, nullptr);
-        const Taps tp = make_taps(ix, iy, a.W1, a.H1);
-        float corr[K::NG];
-        chunk_corr<CPG>(fsrc + j * K::VEC, a.sy, a.sx, tp, refv, corr);
+            refv[c] = a.ref.data[b * a.ref.sb + chunk_channel<K::VEC>(j, c) * a.ref.sc + y * a.ref.sy + x * a.ref.sx];
+        // lane j projects hypothesis grp*LPT + j once; the group then walks its LPT hypotheses and
+        // every lane reads the footprint of hypothesis k from lane k (wavefront shuffles)
+        const int nl_mine = grp * K::LPT + j;
+        Footprint mine = {0u, 0u, 0u, 0u, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (nl_mine < nb) {
+            const int n = n0 + nl_mine;
+            float d;
+            if (a.depth) {
+                d = a.depth[((size_t)b * a.N + n) * P + p];
+            } else {  // itermvs.py:13-17
+                const float frac = (float)n / (float)(a.N - 1);
+                d = 1.0f / (inv_max + frac * (inv_min - inv_max));
+            }
+            float rx, ry, rz, ix, iy;
+            ray_dir(m, (float)x * g.xr, (float)y * g.yr, rx, ry, rz);
+            project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
+            mine = make_footprint(ix, iy, a.W1, a.H1, sy, sx);
+        }
+        const uint32_t joff = (uint32_t)(j * 4);
+        const int gbase = lane - j;
+        const int cnt = min(K::LPT, nb - grp * K::LPT);
+        for (int k = 0; k < cnt; ++k) {
+            const Footprint tp = shfl_footprint(mine, gbase + k);
+            float corr[K::NG];
+            chunk_corr<CPG>(fsrc, joff, tp, refv, corr);
+            const int nl = grp * K::LPT + k;
 #pragma unroll
-        for (int q = 0; q < K::NG; ++q) lds[(nl * ITERMVS_GROUPS + j * K::NG + q) * TILE + px] = corr[q];
+            for (int q = 0; q < K::NG; ++q) lds[(nl * ITERMVS_GROUPS + j * K::NG + q) * LS + px] = corr[q];
+        }
     }
     __syncthreads();
     const int rows = nb * ITERMVS_GROUPS;
     float* o = a.out + (((size_t)b * a.S + s) * a.N + n0) * ITERMVS_GROUPS * P;
     for (int idx = threadIdx.x; idx < rows * TILE; idx += kThreads) {
         const int row = idx / TILE, px = idx - row * TILE;
-        if (p0 + px < P) o[(size_t)row * P + p0 + px] = lds[row * TILE + px];
+        if (p0 + px < P) o[(size_t)row * P + p0 + px] = lds[row * LS + px];
     }
 }
 
@@ -246,7 +390,7 @@ constexpr int kInitNB = 8;  // hypotheses per block
 
 template <int TILE>
 __global__ void __launch_bounds__(kThreads) corr_init_kernel(const InitArgs a) {
-    __shared__ float lds[kInitNB * ITERMVS_GROUPS * TILE];
+    __shared__ float lds[kInitNB * ITERMVS_GROUPS * (TILE + 1)];
     switch (a.C) {
         case 16: corr_init_body<2, TILE>(a, lds); break;
         case 32: corr_init_body<4, TILE>(a, lds); break;
@@ -291,11 +435,25 @@ __global__ void softmax_max_kernel(const float* __restrict__ x, int M, int N, in
 
 using namespace itermvs;
 
+int itermvs_corr_iter_lds(const itermvs_corr_iter_params* p, hipStream_t stream);  // corr_lds.hip
+
+// params->impl selects the kernel: 1 = direct gather (this file, robust to arbitrary depth maps),
+// 2 = LDS-staged tiles (corr_lds.hip, wins when neighbouring pixels have similar depth);
+// 0 = default, overridable with ITERMVS_CORR_ITER_IMPL=gather|lds for experiments.
+static int default_impl() {
+    static const int v = [] {
+        const char* e = getenv("ITERMVS_CORR_ITER_IMPL");
+        return (e && e[0] == 'l') ? 2 : 1;
+    }();
+    return v;
+}
+
 static int check_level(const itermvs_level_src& s, int S) {
     ITERMVS_RETURN_IF(s.C != 16 && s.C != 32 && s.C != 48, ITERMVS_ERR_CHANNELS);
     ITERMVS_RETURN_IF(s.H < 1 || s.W < 1, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(s.sc != 1, ITERMVS_ERR_LAYOUT);
     ITERMVS_RETURN_IF((s.sx % 4) || (s.sy % 4) || (s.sb % 4), ITERMVS_ERR_ALIGN);
+    ITERMVS_RETURN_IF(s.sx <= 0 || s.sy <= 0 || (int64_t)s.H * s.sy >= (int64_t)1 << 31, ITERMVS_ERR_DIMS);  // 32-bit tap offsets
     for (int v = 0; v < S; ++v) {
         ITERMVS_RETURN_IF(!s.view[v], ITERMVS_ERR_NULL);
         ITERMVS_RETURN_IF(((uintptr_t)s.view[v]) % 16, ITERMVS_ERR_ALIGN);
@@ -309,14 +467,25 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
     ITERMVS_RETURN_IF(p->S < 1 || p->S > ITERMVS_MAX_SRC, ITERMVS_ERR_VIEWS);
     ITERMVS_RETURN_IF(!p->ref_q || !p->proj || !p->view_w || !p->inv_depth_min || !p->inv_depth_max, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(((uintptr_t)p->ref_q) % 16, ITERMVS_ERR_ALIGN);
-    IterArgs a;
-    int coff = 0;
     for (int l = 0; l < 3; ++l) {
         const int rc = check_level(p->src[l], p->S);
         if (rc) return rc;
         ITERMVS_RETURN_IF(p->N[l] < 1 || p->N[l] > ITERMVS_MAX_HYP, ITERMVS_ERR_DIMS);
         ITERMVS_RETURN_IF(!p->out[l], ITERMVS_ERR_NULL);
         ITERMVS_RETURN_IF(!p->depth[l] && !p->norm_depth, ITERMVS_ERR_NULL);
+    }
+    if ((p->impl == 0 ? default_impl() : p->impl) == 2) {
+        itermvs_profile_begin(1, (hipStream_t)stream);
+        const int rc = itermvs_corr_iter_lds(p, (hipStream_t)stream);
+        if (rc <= 0) {
+            itermvs_profile_end(1, (hipStream_t)stream);
+            return rc;
+        }
+        itermvs_profile_cancel();   // not applicable (returns 1): fall through to the gather kernel
+    }
+    IterArgs a;
+    int coff = 0;
+    for (int l = 0; l < 3; ++l) {
         IterLevel& L = a.lv[l];
         for (int v = 0; v < ITERMVS_MAX_SRC; ++v) L.src[v] = p->src[l].view[v < p->S ? v : 0];
         L.sb = p->src[l].sb; L.sy = p->src[l].sy; L.sx = p->src[l].sx;
@@ -333,8 +502,16 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
     constexpr int TILE = 32;
     const int P = p->H * p->W;
     itermvs_profile_begin(1, (hipStream_t)stream);
-    hipLaunchKernelGGL(corr_iter_kernel<TILE>, dim3((P + TILE - 1) / TILE, 3, p->B), dim3(kThreads), 0,
-                       (hipStream_t)stream, a);
+    const dim3 grid((((P + TILE - 1) / TILE + 7) / 8) * 8, 3, p->B);
+    // measured on MI355X at cfg 1: issuing the tap loads of 2 / 4 views before the first blend costs
+    // more in occupancy (VGPRs 116 -> 162 / 228) than it wins in memory-level parallelism
+    // (25.9 us vs 30.3 / 33.0 us per launch), so one view at a time is the default; impl 3 / 4 keep the
+    // unrolled variants reachable for tools/kernel_bench.py.
+    switch (p->impl) {
+        case 3: hipLaunchKernelGGL((corr_iter_kernel<TILE, 2>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
+        case 4: hipLaunchKernelGGL((corr_iter_kernel<TILE, 4>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
+        default: hipLaunchKernelGGL((corr_iter_kernel<TILE, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
+    }
     itermvs_profile_end(1, (hipStream_t)stream);
     return itermvs_launch_status();
 }
@@ -358,7 +535,7 @@ extern "C" int itermvs_corr_init(const itermvs_corr_init_params* p, void* stream
     const int P = p->H * p->W;
     const int nblocks = (p->N + kInitNB - 1) / kInitNB;
     itermvs_profile_begin(2, (hipStream_t)stream);
-    hipLaunchKernelGGL(corr_init_kernel<TILE>, dim3((P + TILE - 1) / TILE, p->S * nblocks, p->B), dim3(kThreads), 0,
+    hipLaunchKernelGGL(corr_init_kernel<TILE>, dim3((((P + TILE - 1) / TILE + 7) / 8) * 8, p->S * nblocks, p->B), dim3(kThreads), 0,
                        (hipStream_t)stream, a);
     itermvs_profile_end(2, (hipStream_t)stream);
     return itermvs_launch_status();

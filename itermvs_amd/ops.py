@@ -126,7 +126,7 @@ def ref_quarter(ref1: Tensor, ref2: Tensor, ref3: Tensor) -> Tensor:
 def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, view_w: Tensor,
               inv_min: Tensor, inv_max: Tensor, depth: Optional[Dict[int, Tensor]] = None,
               norm_depth: Optional[Tensor] = None, offsets: Optional[Dict[int, Sequence[float]]] = None,
-              out: Optional[List[Tensor]] = None) -> List[Tensor]:
+              out: Optional[List[Tensor]] = None, impl: int = 0) -> List[Tensor]:
     """itermvs.py:84-120 fused (see include/itermvs_hip.h).  ``src[l]`` = S channels-last maps of
     level l; ``proj`` [3,B,S,12]; ``view_w`` [B,S,H,W]; hypotheses either explicit
     ``depth[l]`` [B,N_l,H,W] or generated from ``norm_depth`` [B,1,H,W] + ``offsets[l]``.
@@ -135,6 +135,7 @@ def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, vie
     s = len(src[1])
     p = CorrIterParams()
     p.B, p.S, p.H, p.W = b, s, h, w
+    p.impl = impl          # 0 default, 1 direct gather, 2 LDS-staged tiles
     keep = []
     outs: List[Tensor] = []
     for i, l in enumerate((1, 2, 3)):

@@ -154,7 +154,8 @@ def test_softmax_max():
 
 @pytest.mark.parametrize("tag", ["seed0", "dtu"])
 @pytest.mark.parametrize("mode", ["explicit", "generated"])
-def test_corr_iter(tag, mode):
+@pytest.mark.parametrize("impl", [1, 2])
+def test_corr_iter(tag, mode, impl):
     g, src, ref, p12, inv_min, inv_max = _small(tag)
     ref_q = ops().ref_quarter(ref[1], ref[2], ref[3])
     vw = cu(g["init.view_weights"])
@@ -162,10 +163,10 @@ def test_corr_iter(tag, mode):
     for it in range(int(g.np("iteration"))):
         if mode == "explicit":
             depth = {l: cu(g[f"iter{it}.samples.level{l}"]) for l in (1, 2, 3)}
-            aggs = ops().corr_iter(src, ref_q, p12, vw, inv_min, inv_max, depth=depth)
+            aggs = ops().corr_iter(src, ref_q, p12, vw, inv_min, inv_max, depth=depth, impl=impl)
         else:
             aggs = ops().corr_iter(src, ref_q, p12, vw, inv_min, inv_max, norm_depth=cu(g[f"iter{it}.nd_in"]),
-                                   offsets=sample_offsets())
+                                   offsets=sample_offsets(), impl=impl)
         for i, l in enumerate((1, 2, 3)):
             want = g[f"iter{it}.agg.level{l}"].permute(0, 2, 1, 3, 4)       # [B,N,8,h,w]
             assert aggs[i].shape == want.shape
@@ -277,7 +278,8 @@ def test_bilinear_up():
     assert maxdiff(ops().bilinear_up(cu(x), 2, act="tanh"), torch.tanh(F.interpolate(x, scale_factor=2, mode="bilinear"))) <= 1e-6
 
 
-def test_ragged_sizes_and_many_views():
+@pytest.mark.parametrize("impl", [1, 2])
+def test_ragged_sizes_and_many_views(impl):
     """pixel count not a multiple of the tile, non-integer map/grid ratios, S = 10 source views
     (the pair.txt maximum), B = 2."""
     gen = torch.Generator().manual_seed(12)
@@ -299,7 +301,8 @@ def test_ragged_sizes_and_many_views():
     pv = {l: cl[l].view(b, v, *cl[l].shape[1:]) for l in feats}
     src = {l: [pv[l][:, i] for i in range(1, v)] for l in feats}
     inv_min, inv_max = cu(torch.full((b,), 1 / 425.0)), cu(torch.full((b,), 1 / 935.0))
-    aggs = ops().corr_iter(src, cu(ref_q), cu(p12), cu(vw), inv_min, inv_max, depth={l: cu(d) for l, d in depth.items()})
+    aggs = ops().corr_iter(src, cu(ref_q), cu(p12), cu(vw), inv_min, inv_max, depth={l: cu(d) for l, d in depth.items()},
+                           impl=impl)
     off = {1: 0, 2: 16, 3: 48}
     for i, l in enumerate((1, 2, 3)):
         refl = ref_q[..., off[l]:off[l] + chans[l]].permute(0, 3, 1, 2)

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused correlation kernels on cfg-1-shaped inputs (GPU box only).
+
+Times back-to-back launches with HIP events (torch.cuda.Event on the launch stream) and checks
+that the kernel variants agree.  `--depth noise|smooth` selects the spatial statistics of the
+normalised depth map, which decide whether the LDS-staged tile kernel can stage its footprints.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from itermvs_amd import ops, synthetic  # noqa: E402
+from itermvs_amd.engine import sample_offsets  # noqa: E402
+
+
+def build(h, w, views, depth_kind, dev):
+    gen = torch.Generator().manual_seed(0)
+    s = views - 1
+    sm = synthetic.make_sample(1, views, h, w, seed=0)
+    feats = {1: torch.randn((views, 16, h // 2, w // 2), generator=gen), 2: torch.randn((views, 32, h // 4, w // 4), generator=gen),
+             3: torch.randn((views, 48, h // 8, w // 8), generator=gen)}
+    cl = {l: f.to(dev).contiguous(memory_format=torch.channels_last) for l, f in feats.items()}
+    src = {l: [cl[l][i:i + 1] for i in range(1, views)] for l in cl}
+    ref = {l: cl[l][0:1] for l in cl}
+    projs = torch.stack([sm["proj_matrices"][f"level_{l}"] for l in (1, 2, 3)]).to(dev)
+    proj = ops.compose_proj(projs.reshape(3, views, 4, 4)).view(3, 1, s, 12)
+    hq, wq = h // 4, w // 4
+    if depth_kind == "noise":
+        nd = torch.rand((1, 1, hq, wq), generator=gen)
+    else:
+        yy, xx = torch.meshgrid(torch.linspace(0, 1, hq), torch.linspace(0, 1, wq), indexing="ij")
+        nd = (0.3 + 0.3 * xx + 0.1 * yy + 0.002 * torch.randn((hq, wq), generator=gen)).view(1, 1, hq, wq)
+    vw = torch.rand((1, s, hq, wq), generator=gen)
+    inv_min = torch.tensor([1 / 425.0], device=dev)
+    inv_max = torch.tensor([1 / 935.0], device=dev)
+    ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
+    return dict(src=src, ref=ref, ref_q=ref_q, proj=proj, nd=nd.to(dev), vw=vw.to(dev), inv_min=inv_min, inv_max=inv_max)
+
+
+def time_it(fn, n=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3      # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--views", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda")
+    offs = sample_offsets()
+    for kind in ("noise", "smooth"):
+        d = build(args.height, args.width, args.views, kind, dev)
+        outs = {}
+        for impl in (1, 3, 4, 2):
+            buf = [torch.empty((1, len(offs[l]), 8, args.height // 4, args.width // 4), device=dev) for l in (1, 2, 3)]
+            run = lambda: ops.corr_iter(d["src"], d["ref_q"], d["proj"], d["vw"], d["inv_min"], d["inv_max"],
+                                        norm_depth=d["nd"], offsets=offs, out=buf, impl=impl)
+            us = time_it(run)
+            outs[impl] = [b.clone() for b in buf]
+            print(f"corr_iter depth={kind:6s} impl={impl}: {us:8.2f} us/launch")
+        diff = max(float((a - b).abs().max()) for a, b in zip(outs[1], outs[2]))
+        scale = max(float(a.abs().max()) for a in outs[1])
+        print(f"  impl 1 vs 2: max abs diff {diff:.3e} (scale {scale:.2f})")
+    d = build(args.height, args.width, args.views, "noise", dev)
+    us = time_it(lambda: ops.corr_init(d["src"][3], d["ref"][3], d["proj"][2], d["inv_min"], d["inv_max"], 32))
+    print(f"corr_init: {us:8.2f} us/launch")
+
+
+if __name__ == "__main__":
+    main()
