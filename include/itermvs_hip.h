@@ -216,6 +216,42 @@ int itermvs_bilinear_up(const float* x, int32_t M, int32_t H, int32_t W, int32_t
                         int32_t act, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * itermvs_conv2d -- the small-channel 2-D convolutions of the path, with fused epilogues:
+ *   nn.Conv2d / ConvBnReLU (BN folded) / ConvReLU      models/module.py:6-30
+ *   ResidualBlock's relu(x + y)                        models/module.py:33-50
+ *   nn.ConvTranspose2d(3, stride 2, pad 1, out_pad 1)  models/itermvs.py:359-363 (CorrNet)
+ *   ConvGRU gates                                      models/module.py:59-66
+ * fp32, contiguous [C,H,W] planes; `in_sn` / `out_sn` / ... are BATCH strides in elements, so
+ * inputs and outputs may be channel slices of wider buffers.  `weight` is PACKED [Cin][k][k][Cout]
+ * (conv weight.permute(1,2,3,0); transposed-conv weight.permute(0,2,3,1)).  Up to three weight sets
+ * per launch: batch items [0,seg_end[0]) use set 0, [seg_end[0],seg_end[1]) set 1, the rest set 2
+ * (the three CorrNets of one iteration in one launch).
+ * Epilogue `act`: 0 v+add | 1 relu(v+add) | 2 sigmoid | 3 tanh | 4 sigmoid(v)*aux1 (r*h) |
+ *                 5 (1-aux2)*aux1 + aux2*tanh(v)  (GRU state update; aux1 = h, aux2 = z).
+ * `out2` (optional) receives a second, contiguous [N,Cout,H,W] copy of the result.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct itermvs_conv_params {
+    const float* in;
+    float* out;
+    float* out2;
+    const float* add;
+    const float* aux1;
+    const float* aux2;
+    int64_t in_sn, out_sn, add_sn, aux1_sn, aux2_sn;
+    const float* weight[3];
+    const float* bias[3];                      /* [Cout] or NULL */
+    int32_t seg_end[3];
+    int32_t n_seg;
+    int32_t N, Cin, Hin, Win, Cout;
+    int32_t ksize, stride, pad, dilation;      /* ksize 1 or 3 */
+    int32_t transposed;                        /* 1: ConvTranspose2d(3, stride 2, pad 1, output_padding 1) */
+    int32_t act;
+    int32_t _pad;
+} itermvs_conv_params;
+
+int itermvs_conv2d(const itermvs_conv_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optional per-launch timing (HIP events recorded on the launch stream around the kernels of
  * itermvs_corr_iter / itermvs_corr_init).  Used by bench.py for the roofline figure.
  * itermvs_profile_enable(n) allocates n event pairs (n = 0 disables and frees);

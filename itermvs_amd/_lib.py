@@ -54,6 +54,18 @@ class CorrInitParams(C.Structure):
                 ("inv_depth_min", C.c_void_p), ("inv_depth_max", C.c_void_p), ("out", C.c_void_p)]
 
 
+class ConvParams(C.Structure):
+    """itermvs_conv_params"""
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p), ("add", C.c_void_p),
+                ("aux1", C.c_void_p), ("aux2", C.c_void_p),
+                ("in_sn", C.c_int64), ("out_sn", C.c_int64), ("add_sn", C.c_int64), ("aux1_sn", C.c_int64),
+                ("aux2_sn", C.c_int64),
+                ("weight", C.c_void_p * 3), ("bias", C.c_void_p * 3), ("seg_end", C.c_int32 * 3), ("n_seg", C.c_int32),
+                ("N", C.c_int32), ("Cin", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cout", C.c_int32),
+                ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dilation", C.c_int32),
+                ("transposed", C.c_int32), ("act", C.c_int32), ("_pad", C.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/itermvs_hip.h declares
 PROTOTYPES = {
     "itermvs_version": (C.c_int, []),
@@ -81,6 +93,7 @@ PROTOTYPES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "itermvs_bilinear_up": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                       C.c_void_p]),
+    "itermvs_conv2d": (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
     "itermvs_profile_enable": (C.c_int, [C.c_int32]),
     "itermvs_profile_collect": (C.c_int, [C.POINTER(C.c_int32), c_float_p, C.c_int32]),
 }

@@ -1,0 +1,226 @@
+// Direct 2-D convolutions for the SMALL-channel layers of the hot path (CorrNet 8..32 channels,
+// PixelViewWeight, ConvGRU 43->32, heads, FeatureNet 3..48 channels) -- models/itermvs.py:333-381,
+// models/module.py:6-66, models/net.py:7-66.
+//
+// Why not MIOpen: at these sizes (0.05-1 GFLOP per layer) the library kernels are launch/latency
+// bound (15-60 us each, plus NCHW<->NHWC transposes it inserts and separate bias / ReLU / add
+// kernels); a step of the reference network spends 94 % of its GPU time there (profiles/r01_*).
+//
+// Design (fp32, NCHW planes, wave64):
+//   * thread = one output pixel (2x2 output pixels for the stride-2 transposed conv), lanes run
+//     along x so every input tap is one coalesced 256-byte wave load;
+//   * a block handles CT output channels held in CT accumulators per thread; the CT weights of a
+//     (ci, ky, kx) are contiguous in the packed [Cin][k][k][Cout] layout and wave-uniform, so they
+//     are fetched with scalar loads and enter v_fmac as SGPR operands: the inner loop is pure
+//     VALU FMA, one vector load per CT FMAs;
+//   * bias, residual add, ReLU / sigmoid / tanh and the ConvGRU gate formulas are fused in the
+//     epilogue (module.py:59-66), so activations are written exactly once;
+//   * up to three weight sets per launch: the three CorrNets of one iteration (levels 1..3, batch
+//     items [0,4), [4,8), [8,10)) run as ONE launch per layer instead of three.
+// Numerics: plain fp32 fma chains in (ci, ky, kx) order -- same class of rounding as any other
+// convolution back-end; parity is checked against F.conv2d in tests/test_conv_gpu.py.
+#include "common.hpp"
+
+namespace itermvs {
+
+struct ConvArgs {
+    const float* in;
+    float* out;
+    float* out2;          // optional second copy of the result (contiguous [N,Cout,P])
+    const float* add;     // residual, added before the activation
+    const float* aux1;    // epilogue operand (h for the GRU forms)
+    const float* aux2;    // epilogue operand (z for the GRU update)
+    int64_t in_sn, out_sn, add_sn, aux1_sn, aux2_sn;
+    const float* weight[3];
+    const float* bias[3];
+    int seg_end[3];
+    int N, Cin, Hin, Win, Cout, Hout, Wout;
+    int stride, pad, dil, act;
+};
+
+__device__ __forceinline__ float epilogue(float v, int act, float add, float a1, float a2) {
+    v += add;
+    switch (act) {
+        case 1: return fmaxf(v, 0.0f);
+        case 2: return sigmoidf_(v);
+        case 3: return tanhf(v);
+        case 4: return sigmoidf_(v) * a1;                       // r * h            (module.py:63-64)
+        case 5: return (1.0f - a2) * a1 + a2 * tanhf(v);        // (1-z) h + z q    (module.py:64-65)
+        default: return v;
+    }
+}
+
+template <int CT, int KS>
+__global__ void __launch_bounds__(256) conv_direct_kernel(const ConvArgs a) {
+    const int P = a.Hout * a.Wout;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int co0 = blockIdx.y * CT;
+    const int n = blockIdx.z;
+    const int seg = (n >= a.seg_end[0]) + (n >= a.seg_end[1]);
+    const float* __restrict__ w = a.weight[seg] + co0;
+    const float* __restrict__ bias = a.bias[seg];
+    if (p >= P) return;
+    const int oy = p / a.Wout, ox = p - oy * a.Wout;
+
+    int off[KS * KS];
+    bool ok[KS * KS];
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const int iy = oy * a.stride - a.pad + ky * a.dil;
+            const int ix = ox * a.stride - a.pad + kx * a.dil;
+            const bool in = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            ok[ky * KS + kx] = in;
+            off[ky * KS + kx] = in ? iy * a.Win + ix : 0;
+        }
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = bias ? bias[co0 + c] : 0.0f;
+
+    const float* __restrict__ ip = a.in + (int64_t)n * a.in_sn;
+    const int plane = a.Hin * a.Win;
+    const int wstep = KS * KS * a.Cout;
+    for (int ci = 0; ci < a.Cin; ++ci) {
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) {
+            const float v = ok[t] ? ip[off[t]] : 0.0f;
+            const float* __restrict__ wt = w + t * a.Cout;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = fmaf(v, wt[c], acc[c]);
+        }
+        ip += plane;
+        w += wstep;
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int64_t ch = (int64_t)(co0 + c) * P + p;
+        const float ad = a.add ? a.add[(int64_t)n * a.add_sn + ch] : 0.0f;
+        const float a1 = a.aux1 ? a.aux1[(int64_t)n * a.aux1_sn + ch] : 0.0f;
+        const float a2 = a.aux2 ? a.aux2[(int64_t)n * a.aux2_sn + ch] : 0.0f;
+        const float r = epilogue(acc[c], a.act, ad, a1, a2);
+        a.out[(int64_t)n * a.out_sn + ch] = r;
+        if (a.out2) a.out2[((int64_t)n * a.Cout) * P + ch] = r;
+    }
+}
+
+// ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1): thread = input pixel (y, x) -> the
+// 2x2 output block at (2y, 2x); all 9 taps are useful:
+//   out(2y  ,2x  ) = in(y,x) W11
+//   out(2y  ,2x+1) = in(y,x) W12 + in(y,x+1) W10
+//   out(2y+1,2x  ) = in(y,x) W21 + in(y+1,x) W01
+//   out(2y+1,2x+1) = in(y,x) W22 + in(y,x+1) W20 + in(y+1,x) W02 + in(y+1,x+1) W00
+template <int CT>
+__global__ void __launch_bounds__(256) deconv_s2_kernel(const ConvArgs a) {
+    const int Pin = a.Hin * a.Win;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int co0 = blockIdx.y * CT;
+    const int n = blockIdx.z;
+    const int seg = (n >= a.seg_end[0]) + (n >= a.seg_end[1]);
+    const float* __restrict__ w = a.weight[seg] + co0;
+    const float* __restrict__ bias = a.bias[seg];
+    if (p >= Pin) return;
+    const int y = p / a.Win, x = p - y * a.Win;
+    const bool hx = x + 1 < a.Win, hy = y + 1 < a.Hin;
+    const int o01 = hx ? p + 1 : p, o10 = hy ? p + a.Win : p, o11 = (hx && hy) ? p + a.Win + 1 : p;
+
+    float acc[4][CT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[q][c] = bias ? bias[co0 + c] : 0.0f;
+
+    const float* __restrict__ ip = a.in + (int64_t)n * a.in_sn;
+    const int wstep = 9 * a.Cout;
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const float v00 = ip[p];
+        const float v01 = hx ? ip[o01] : 0.0f;
+        const float v10 = hy ? ip[o10] : 0.0f;
+        const float v11 = (hx && hy) ? ip[o11] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            // packed weight index: (ky*3 + kx)*Cout + c
+            acc[0][c] = fmaf(v00, w[4 * a.Cout + c], acc[0][c]);
+            acc[1][c] = fmaf(v01, w[3 * a.Cout + c], fmaf(v00, w[5 * a.Cout + c], acc[1][c]));
+            acc[2][c] = fmaf(v10, w[1 * a.Cout + c], fmaf(v00, w[7 * a.Cout + c], acc[2][c]));
+            acc[3][c] = fmaf(v11, w[0 * a.Cout + c],
+                             fmaf(v10, w[2 * a.Cout + c], fmaf(v01, w[6 * a.Cout + c], fmaf(v00, w[8 * a.Cout + c], acc[3][c]))));
+        }
+        ip += Pin;
+        w += wstep;
+    }
+    const int P = a.Hout * a.Wout;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int op = (2 * y + (q >> 1)) * a.Wout + 2 * x + (q & 1);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int64_t ch = (int64_t)(co0 + c) * P + op;
+            const float ad = a.add ? a.add[(int64_t)n * a.add_sn + ch] : 0.0f;
+            a.out[(int64_t)n * a.out_sn + ch] = epilogue(acc[q][c], a.act, ad, 0.0f, 0.0f);
+        }
+    }
+}
+
+template <int KS>
+static int launch_direct(const ConvArgs& a, int ct, hipStream_t stream) {
+    const int P = a.Hout * a.Wout;
+    const dim3 grid((P + 255) / 256, a.Cout / ct, a.N);
+    switch (ct) {
+        case 32: hipLaunchKernelGGL((conv_direct_kernel<32, KS>), grid, dim3(256), 0, stream, a); break;
+        case 16: hipLaunchKernelGGL((conv_direct_kernel<16, KS>), grid, dim3(256), 0, stream, a); break;
+        case 8: hipLaunchKernelGGL((conv_direct_kernel<8, KS>), grid, dim3(256), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((conv_direct_kernel<4, KS>), grid, dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL((conv_direct_kernel<1, KS>), grid, dim3(256), 0, stream, a); break;
+    }
+    return itermvs_launch_status();
+}
+
+}  // namespace itermvs
+
+using namespace itermvs;
+
+extern "C" int itermvs_conv2d(const itermvs_conv_params* p, void* stream) {
+    ITERMVS_RETURN_IF(!p, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(!p->in || !p->out || !p->weight[0], ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(p->N < 1 || p->Cin < 1 || p->Cout < 1 || p->Hin < 1 || p->Win < 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(p->ksize != 1 && p->ksize != 3, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(p->n_seg < 1 || p->n_seg > 3 || p->act < 0 || p->act > 5, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF((p->act == 4 || p->act == 5) && !p->aux1, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(p->act == 5 && !p->aux2, ITERMVS_ERR_NULL);
+    ConvArgs a;
+    a.in = p->in; a.out = p->out; a.out2 = p->out2; a.add = p->add; a.aux1 = p->aux1; a.aux2 = p->aux2;
+    a.in_sn = p->in_sn; a.out_sn = p->out_sn; a.add_sn = p->add_sn; a.aux1_sn = p->aux1_sn; a.aux2_sn = p->aux2_sn;
+    for (int i = 0; i < 3; ++i) {
+        const int k = i < p->n_seg ? i : p->n_seg - 1;
+        ITERMVS_RETURN_IF(!p->weight[k], ITERMVS_ERR_NULL);
+        a.weight[i] = p->weight[k];
+        a.bias[i] = p->bias[k];
+        a.seg_end[i] = i < p->n_seg - 1 ? p->seg_end[i] : p->N;
+    }
+    a.N = p->N; a.Cin = p->Cin; a.Hin = p->Hin; a.Win = p->Win; a.Cout = p->Cout;
+    a.stride = p->stride; a.pad = p->pad; a.dil = p->dilation; a.act = p->act;
+    // largest channel tile that divides Cout
+    int ct = 1;
+    for (int c : {32, 16, 8, 4})
+        if (p->Cout % c == 0) { ct = c; break; }
+    if (p->transposed) {
+        ITERMVS_RETURN_IF(p->ksize != 3 || p->stride != 2 || p->pad != 1 || p->act > 1, ITERMVS_ERR_DIMS);
+        a.Hout = 2 * p->Hin; a.Wout = 2 * p->Win;
+        if (ct > 16) ct = 16;       // 4 output pixels x CT accumulators per thread
+        const dim3 grid((p->Hin * p->Win + 255) / 256, p->Cout / ct, p->N);
+        switch (ct) {
+            case 16: hipLaunchKernelGGL((deconv_s2_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+            case 8: hipLaunchKernelGGL((deconv_s2_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+            case 4: hipLaunchKernelGGL((deconv_s2_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+            default: hipLaunchKernelGGL((deconv_s2_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        }
+        return itermvs_launch_status();
+    }
+    ITERMVS_RETURN_IF(p->stride < 1 || p->dilation < 1 || p->pad < 0, ITERMVS_ERR_DIMS);
+    const int span = (p->ksize - 1) * p->dilation + 1;
+    a.Hout = (p->Hin + 2 * p->pad - span) / p->stride + 1;
+    a.Wout = (p->Win + 2 * p->pad - span) / p->stride + 1;
+    ITERMVS_RETURN_IF(a.Hout < 1 || a.Wout < 1, ITERMVS_ERR_DIMS);
+    return p->ksize == 3 ? launch_direct<3>(a, ct, (hipStream_t)stream) : launch_direct<1>(a, ct, (hipStream_t)stream);
+}

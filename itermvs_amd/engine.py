@@ -54,7 +54,12 @@ def fold_batchnorm(w: Mapping[str, Tensor], prefix: str, eps: float = 1e-5) -> T
 
 
 class InferenceEngine:
-    def __init__(self, weights: Mapping[str, Tensor], iteration: int):
+    """``backend``: "hip" (default) runs every convolution in the hand-written direct-conv kernels
+    (itermvs_conv2d, fused bias / ReLU / residual / GRU-gate epilogues, the three CorrNets of an
+    iteration batched per layer); "miopen" keeps the dense layers on PyTorch-ROCm/MIOpen (the
+    round-1 baseline, kept for A/B measurements)."""
+
+    def __init__(self, weights: Mapping[str, Tensor], iteration: int, backend: str = None):
         w = {k: v.detach() for k, v in weights.items()}
         dev = w["feature_net.conv1.conv.weight"].device
         if dev.type != "cuda":
@@ -73,6 +78,28 @@ class InferenceEngine:
         self.b_zr = torch.cat([w[g + "convz.bias"], w[g + "convr.bias"]], 0).contiguous()
         self.offsets = sample_offsets()
         self._ws: Dict[tuple, dict] = {}
+        import os
+        self.backend = backend or os.environ.get("ITERMVS_CONV_BACKEND", "hip")
+        if self.backend not in ("hip", "miopen"):
+            raise ValueError(f"unknown conv backend {self.backend!r}")
+        self.pk: Dict[str, Tensor] = {}
+        if self.backend == "hip":
+            self._pack_weights()
+
+    def _pack_weights(self) -> None:
+        """[Cout,Cin,k,k] -> packed [Cin,k,k,Cout] once, BatchNorm already folded."""
+        w, pk = self.w, self.pk
+        for n, (wt, _) in self.cbr.items():
+            pk["feature_net." + n] = ops.pack_conv_weight(wt)
+        for k, v in w.items():
+            if not k.endswith("weight") or v.dim() != 4 or ".bn." in k or k.startswith("feature_net.") and ".conv." in k:
+                continue
+            transposed = k.endswith("conv3.weight") or k.endswith("conv4.weight")
+            pk[k] = ops.pack_conv_weight(v, transposed=transposed)
+
+    def _conv(self, x: Tensor, name: str, bias: bool = False, **kw) -> Tensor:
+        """one layer by state-dict name (``name`` + "weight"/"bias")"""
+        return ops.conv2d(x, self.pk[name + "weight"], self.w[name + "bias"] if bias else None, **kw)
 
     # -- dense stacks on MIOpen ---------------------------------------------------------------
     def _cbr(self, x: Tensor, name: str, stride: int, relu: bool) -> Tensor:
@@ -86,9 +113,28 @@ class InferenceEngine:
             x = self._cbr(x, name + "downsample.", stride, False)
         return F.relu_(y.add_(x))
 
+    def _cbr_hip(self, x: Tensor, name: str, stride: int, act: str, add: Tensor = None) -> Tensor:
+        return ops.conv2d(x, self.pk["feature_net." + name], self.cbr[name][1], stride=stride, act=act, add=add)
+
+    def _res_hip(self, x: Tensor, name: str, stride: int) -> Tensor:
+        y = self._cbr_hip(x, name + "conv1.", stride, "relu")
+        sc = x if stride == 1 else self._cbr_hip(x, name + "downsample.", stride, "none")
+        return self._cbr_hip(y, name + "conv2.", 1, "relu", add=sc)          # relu(x + y), module.py:50
+
     def feature_net(self, x: Tensor) -> Dict[int, Tensor]:
         """net.py:36-65 with BN folded; x [M,3,H,W] -> NCHW pyramids {1,2,3}."""
         w, p = self.w, "feature_net."
+        if self.backend == "hip":
+            f0 = self._cbr_hip(x, "conv1.", 1, "relu")
+            f1 = self._res_hip(self._res_hip(f0, "layer1.0.", 2), "layer1.1.", 1)
+            f2 = self._res_hip(self._res_hip(f1, "layer2.0.", 2), "layer2.1.", 1)
+            f3 = self._res_hip(self._res_hip(f2, "layer3.0.", 2), "layer3.1.", 1)
+            o3 = self._conv(f3, p + "output3.", bias=True)
+            mid = self._conv(f2, p + "inner2.", bias=True, ksize=1, pad=0, add=ops.bilinear_up(f3, 2))     # net.py:46
+            o2 = self._conv(mid, p + "output2.", bias=True)
+            mid = self._conv(f1, p + "inner1.", bias=True, ksize=1, pad=0, add=ops.bilinear_up(mid, 2))    # net.py:49
+            o1 = self._conv(mid, p + "output1.", bias=True)
+            return {1: o1, 2: o2, 3: o3}
         f0 = self._cbr(x, "conv1.", 1, True)
         f1 = self._res(self._res(f0, "layer1.0.", 2), "layer1.1.", 1)
         f2 = self._res(self._res(f1, "layer2.0.", 2), "layer2.1.", 1)
@@ -100,8 +146,22 @@ class InferenceEngine:
         o1 = F.conv2d(mid, w[p + "output1.weight"], w[p + "output1.bias"], padding=1)
         return {1: o1, 2: o2, 3: o3}
 
+    def corr_nets(self, x: Tensor, levels, seg_end=(), out: Tensor = None, out2: Tensor = None) -> Tensor:
+        """itermvs.py:352-381 for one or three levels in ONE launch per layer: x [M,8,h,w] whose batch
+        items [0,seg_end[0]) / [seg_end[0],seg_end[1]) / rest belong to levels[0..2] -> [M,1,h,w]."""
+        ps = [f"iter_mvs.evaluation.corr_conv1.{l - 1}." for l in levels]
+        wl = lambda n: [self.pk[p + n] for p in ps]
+        c0 = ops.conv2d(x, wl("conv0.conv.weight"), None, act="relu", seg_end=seg_end)
+        c1 = ops.conv2d(c0, wl("conv1.conv.weight"), None, stride=2, act="relu", seg_end=seg_end)
+        c2 = ops.conv2d(c1, wl("conv2.conv.weight"), None, stride=2, act="relu", seg_end=seg_end)
+        u1 = ops.conv2d(c2, wl("conv3.weight"), None, transposed=True, stride=2, add=c1, seg_end=seg_end)
+        u0 = ops.conv2d(u1, wl("conv4.weight"), None, transposed=True, stride=2, add=c0, seg_end=seg_end)
+        return ops.conv2d(u0, wl("conv5.weight"), [self.w[p + "conv5.bias"] for p in ps], seg_end=seg_end, out=out, out2=out2)
+
     def corr_net(self, x: Tensor, level: int) -> Tensor:
         """itermvs.py:352-381 on [M,8,h,w] -> [M,1,h,w]."""
+        if self.backend == "hip":
+            return self.corr_nets(x, [level])
         w, p = self.w, f"iter_mvs.evaluation.corr_conv1.{level - 1}."
         c0 = F.relu_(F.conv2d(x, w[p + "conv0.conv.weight"], padding=1))
         c1 = F.relu_(F.conv2d(c0, w[p + "conv1.conv.weight"], stride=2, padding=1))
@@ -112,12 +172,19 @@ class InferenceEngine:
 
     def depth_head(self, hidden: Tensor) -> Tensor:
         w, p = self.w, "iter_mvs.update.depth_head."
+        if self.backend == "hip":
+            x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu")
+            x = self._conv(x, p + "2.", ksize=1, pad=0, act="relu")
+            return self._conv(x, p + "4.", bias=True, ksize=1, pad=0)
         x = F.relu_(F.conv2d(hidden, w[p + "0.weight"], padding=2, dilation=2))
         x = F.relu_(F.conv2d(x, w[p + "2.weight"]))
         return F.conv2d(x, w[p + "4.weight"], w[p + "4.bias"])
 
     def confidence(self, hidden: Tensor) -> Tensor:
         w, p = self.w, "iter_mvs.update.confidence_head."
+        if self.backend == "hip":
+            x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu")
+            return self._conv(x, p + "2.", bias=True, ksize=1, pad=0, act="sigmoid")
         x = F.relu_(F.conv2d(hidden, w[p + "0.weight"], padding=2, dilation=2))
         return torch.sigmoid_(F.conv2d(x, w[p + "2.weight"], w[p + "2.bias"]))
 
@@ -132,9 +199,16 @@ class InferenceEngine:
                 "hx": torch.zeros((b, HIDDEN + nx, h, w), device=dev),     # [h | nd | scores]  (module.py:60)
                 "hx2": torch.zeros((b, HIDDEN + nx, h, w), device=dev),    # [r*h | nd | scores] (module.py:64)
                 "hidden": torch.empty((b, HIDDEN, h, w), device=dev),
-                "agg": [torch.empty((b, len(self.offsets[l]), 8, h, w), device=dev) for l in (1, 2, 3)],
+                "agg_all": torch.empty((b * (nx - 1), 8, h, w), device=dev),   # the three levels' CorrNet inputs, back to back
+                "zbuf": torch.empty((b, HIDDEN, h, w), device=dev),
                 "nan_flag": torch.zeros((1,), device=dev, dtype=torch.int32),
             }
+            o, views = 0, []
+            for l in (1, 2, 3):
+                n = b * len(self.offsets[l])
+                views.append(ws["agg_all"][o:o + n].view(b, len(self.offsets[l]), 8, h, w))
+                o += n
+            ws["agg"] = views
             self._ws[key] = ws
         return ws
 
@@ -165,21 +239,31 @@ class InferenceEngine:
         # (packed copy: a strided batch-1 view would send MIOpen to its naive non-packed kernel)
         ref2_nchw = feats[2][:1] if b == 1 else feats[2].view(b, v, *feats[2].shape[1:])[:, 0].contiguous()
         u = "iter_mvs.upsample."
-        up_logits = F.conv2d(F.relu_(F.conv2d(ref2_nchw, w[u + "0.weight"], padding=1)), w[u + "2.weight"])
+        if self.backend == "hip":
+            up_logits = self._conv(self._conv(ref2_nchw, u + "0.", act="relu"), u + "2.", ksize=1, pad=0)
+        else:
+            up_logits = F.conv2d(F.relu_(F.conv2d(ref2_nchw, w[u + "0.weight"], padding=1)), w[u + "2.weight"])
 
         ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
 
         # ---- initialisation (itermvs.py:270-276) ------------------------------------------
         corr_v = ops.corr_init(src[3], ref[3], proj[2], inv_min, inv_max, INIT_SAMPLES)       # [B,S,32,8,h3,w3]
         pv = "iter_mvs.evaluation.pixel_view_weight."
-        x = F.relu_(F.conv2d(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), w[pv + "conv.0.conv.weight"], padding=1))
-        x = F.conv2d(x, w[pv + "conv.1.weight"], w[pv + "conv.1.bias"])
+        if self.backend == "hip":
+            x = self._conv(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), pv + "conv.0.conv.", act="relu")
+            x = self._conv(x, pv + "conv.1.", bias=True, ksize=1, pad=0)
+        else:
+            x = F.relu_(F.conv2d(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), w[pv + "conv.0.conv.weight"], padding=1))
+            x = F.conv2d(x, w[pv + "conv.1.weight"], w[pv + "conv.1.bias"])
         vw = ops.softmax_max(x.view(b * s, INIT_SAMPLES, h3, w3))                               # [B*S,1,h3,w3]
         view_w = ops.bilinear_up(vw, 2).view(b, s, h, wd)                                       # itermvs.py:56-57,71
         agg0 = ops.view_aggregate(corr_v, vw.view(b, s, h3, w3))                                # [B,32,8,h3,w3]
         score0 = self.corr_net(agg0.view(b * INIT_SAMPLES, 8, h3, w3), 3).view(b, INIT_SAMPLES, h3, w3)
         hi = "iter_mvs.update.hidden_init_head."
-        x = F.conv2d(F.relu_(F.conv2d(score0, w[hi + "0.weight"], padding=1)), w[hi + "2.weight"], w[hi + "2.bias"])
+        if self.backend == "hip":
+            x = self._conv(self._conv(score0, hi + "0.", act="relu"), hi + "2.", bias=True, ksize=1, pad=0)
+        else:
+            x = F.conv2d(F.relu_(F.conv2d(score0, w[hi + "0.weight"], padding=1)), w[hi + "2.weight"], w[hi + "2.bias"])
         hidden0 = ops.bilinear_up(x, 2, act="tanh")                                             # itermvs.py:161-163
         hidden.copy_(hidden0)
         hx[:, :HIDDEN].copy_(hidden0)
@@ -196,13 +280,33 @@ class InferenceEngine:
         for it in range(self.iteration):
             aggs = ops.corr_iter(src, ref_q, proj, view_w, inv_min, inv_max,
                                  norm_depth=hx[:, HIDDEN:HIDDEN + 1], offsets=self.offsets, out=ws["agg"])
-            scores = [self.corr_net(a.view(-1, 8, h, wd), l).view(b, -1, h, wd) for l, a in zip((1, 2, 3), aggs)]
-            ops.pack_scores(scores, hx, hx2, HIDDEN + 1)
-            zr = F.conv2d(hx, self.w_zr, self.b_zr, padding=2, dilation=2)
-            ops.gru_rh(zr, hx, hx2, HIDDEN)
-            q = F.conv2d(hx2, w[g + "convq.weight"], w[g + "convq.bias"], padding=2, dilation=2)
             nd_in = hx[:, HIDDEN:HIDDEN + 1].clone() if trace is not None else None
-            ops.gru_out(zr, q, hx, hidden, HIDDEN)
+            if self.backend == "hip":
+                # three CorrNets: one launch per layer over all 10*B maps; for B = 1 the last layer writes
+                # the ten score planes straight into channels 33..42 of both GRU input buffers
+                n1, n2 = b * len(self.offsets[1]), b * (len(self.offsets[1]) + len(self.offsets[2]))
+                if b == 1:
+                    sc = self.corr_nets(ws["agg_all"], (1, 2, 3), (n1, n2), out=hx[0, HIDDEN + 1:].unsqueeze(1),
+                                        out2=hx2[0, HIDDEN + 1:].unsqueeze(1))
+                    scores = [sc.squeeze(1).unsqueeze(0)] if trace is not None else None
+                else:
+                    sc = self.corr_nets(ws["agg_all"], (1, 2, 3), (n1, n2))
+                    scores = [sc[:n1].view(b, -1, h, wd), sc[n1:n2].view(b, -1, h, wd), sc[n2:].view(b, -1, h, wd)]
+                    ops.pack_scores(scores, hx, hx2, HIDDEN + 1)
+                # ConvGRU (module.py:59-66): gate math fused into the conv epilogues
+                zbuf = ws["zbuf"]
+                self._conv(hx, g + "convz.", bias=True, pad=2, dilation=2, act="sigmoid", out=zbuf)
+                self._conv(hx, g + "convr.", bias=True, pad=2, dilation=2, act="gru_rh", aux1=hx[:, :HIDDEN],
+                           out=hx2[:, :HIDDEN])
+                self._conv(hx2, g + "convq.", bias=True, pad=2, dilation=2, act="gru_out", aux1=hx[:, :HIDDEN],
+                           aux2=zbuf, out=hx[:, :HIDDEN], out2=hidden)
+            else:
+                scores = [self.corr_net(a.view(-1, 8, h, wd), l).view(b, -1, h, wd) for l, a in zip((1, 2, 3), aggs)]
+                ops.pack_scores(scores, hx, hx2, HIDDEN + 1)
+                zr = F.conv2d(hx, self.w_zr, self.b_zr, padding=2, dilation=2)
+                ops.gru_rh(zr, hx, hx2, HIDDEN)
+                q = F.conv2d(hx2, w[g + "convq.weight"], w[g + "convq.bias"], padding=2, dilation=2)
+                ops.gru_out(zr, q, hx, hidden, HIDDEN)
             if it == self.iteration - 1:
                 conf = self.confidence(hidden)                                                  # itermvs.py:197-199
             logits = self.depth_head(hidden)

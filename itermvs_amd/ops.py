@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import MAX_HYP, MAX_SRC, CorrInitParams, CorrIterParams, FMap, LevelSrc, check
+from ._lib import MAX_HYP, MAX_SRC, ConvParams, CorrInitParams, CorrIterParams, FMap, LevelSrc, check
 
 Tensor = torch.Tensor
 
@@ -306,6 +306,72 @@ def bilinear_up(x: Tensor, scale: int, act: str = "none") -> Tensor:
     out = torch.empty((b, c, scale * h, scale * w), device=x.device, dtype=torch.float32)
     check(_lib.load().itermvs_bilinear_up(x.data_ptr(), b * c, h, w, scale, {"none": 0, "tanh": 1}[act], out.data_ptr(),
                                           _stream()), "itermvs_bilinear_up")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+ACT = {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "gru_rh": 4, "gru_out": 5}
+
+
+def pack_conv_weight(w: Tensor, transposed: bool = False) -> Tensor:
+    """[Cout,Cin,k,k] (Conv2d) or [Cin,Cout,k,k] (ConvTranspose2d) -> packed [Cin,k,k,Cout]."""
+    return (w.permute(0, 2, 3, 1) if transposed else w.permute(1, 2, 3, 0)).contiguous()
+
+
+def _planes(t: Tensor, name: str):
+    """[N,C,H,W] view whose channel planes are dense (a channel slice of a contiguous buffer is fine)."""
+    _dev(t, name)
+    n, c, h, w = t.shape
+    if t.stride(3) != 1 or t.stride(2) != w or (c > 1 and t.stride(1) != h * w):
+        raise RuntimeError(f"{name}: needs dense [C,H,W] planes (NCHW); got strides {t.stride()}")
+    return t.data_ptr(), (t.stride(0) if n > 1 else c * h * w)
+
+
+def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad: int = 1, dilation: int = 1,
+           act: str = "none", add: Optional[Tensor] = None, aux1: Optional[Tensor] = None,
+           aux2: Optional[Tensor] = None, out: Optional[Tensor] = None, out2: Optional[Tensor] = None,
+           transposed: bool = False, seg_end: Sequence[int] = ()) -> Tensor:
+    """itermvs_conv2d.  ``weight`` / ``bias``: packed tensor(s) (see pack_conv_weight); pass lists of up to
+    three for per-segment weight sets with ``seg_end`` = batch boundaries.  Returns ``out``."""
+    weights = list(weight) if isinstance(weight, (list, tuple)) else [weight]
+    biases = list(bias) if isinstance(bias, (list, tuple)) else [bias] * len(weights)
+    n, cin, hin, win = x.shape
+    cout = weights[0].shape[3]
+    if transposed:
+        hout, wout = 2 * hin, 2 * win
+    else:
+        span = (ksize - 1) * dilation + 1
+        hout, wout = (hin + 2 * pad - span) // stride + 1, (win + 2 * pad - span) // stride + 1
+    if out is None:
+        out = torch.empty((n, cout, hout, wout), device=x.device, dtype=torch.float32)
+    p = ConvParams()
+    p.inp, p.in_sn = _planes(x, "conv input")
+    p.out, p.out_sn = _planes(out, "conv output")
+    if out.shape != (n, cout, hout, wout):
+        raise RuntimeError(f"conv2d: out has shape {tuple(out.shape)}, expected {(n, cout, hout, wout)}")
+    if out2 is not None:
+        assert out2.is_contiguous() and out2.shape == out.shape
+        p.out2 = out2.data_ptr()
+    for name, t in (("add", add), ("aux1", aux1), ("aux2", aux2)):
+        if t is not None:
+            ptr, sn = _planes(t, name)
+            if t.shape != out.shape:
+                raise RuntimeError(f"conv2d: {name} has shape {tuple(t.shape)}, expected {tuple(out.shape)}")
+            setattr(p, name, ptr)
+            setattr(p, name + "_sn", sn)
+    p.n_seg = len(weights)
+    for i, (wt, bs) in enumerate(zip(weights, biases)):
+        _dev(wt, "weight")
+        if not wt.is_contiguous() or wt.shape != (cin, ksize, ksize, cout):
+            raise RuntimeError(f"conv2d: packed weight must be contiguous [{cin},{ksize},{ksize},{cout}], got {tuple(wt.shape)}")
+        p.weight[i] = wt.data_ptr()
+        p.bias[i] = None if bs is None else _dev(bs, "bias").data_ptr()
+    for i, e in enumerate(seg_end):
+        p.seg_end[i] = e
+    p.N, p.Cin, p.Hin, p.Win, p.Cout = n, cin, hin, win, cout
+    p.ksize, p.stride, p.pad, p.dilation = ksize, stride, pad, dilation
+    p.transposed, p.act = int(transposed), ACT[act]
+    check(_lib.load().itermvs_conv2d(C.byref(p), _stream()), "itermvs_conv2d")
     return out
 
 

@@ -1,0 +1,118 @@
+"""itermvs_conv2d (hand-written direct convolutions with fused epilogues) vs torch.nn.functional
+on the same GPU, for every layer shape of the path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def ops():
+    from itermvs_amd import ops as _ops
+    return _ops
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-6))
+
+
+CASES = [
+    # cin, cout, k, stride, pad, dil, h, w, n
+    (3, 8, 3, 1, 1, 1, 32, 40, 5),      # FeatureNet conv1
+    (8, 16, 3, 2, 1, 1, 32, 40, 5),     # layer1.0 stride 2
+    (16, 16, 3, 1, 1, 1, 16, 20, 5),
+    (32, 48, 3, 2, 1, 1, 16, 24, 2),
+    (48, 48, 3, 1, 1, 1, 9, 11, 2),     # odd sizes
+    (48, 16, 3, 1, 1, 1, 16, 20, 2),    # output1
+    (16, 48, 1, 1, 0, 1, 16, 20, 2),    # inner1 (1x1)
+    (8, 8, 3, 1, 1, 1, 16, 20, 10),     # CorrNet conv0
+    (16, 32, 3, 2, 1, 1, 8, 10, 10),    # CorrNet conv2
+    (8, 1, 3, 1, 1, 1, 16, 20, 10),     # CorrNet conv5 (Cout = 1)
+    (43, 32, 3, 1, 2, 2, 16, 20, 1),    # ConvGRU gate, dilation 2
+    (32, 64, 1, 1, 0, 1, 16, 20, 1),    # depth head 1x1
+    (64, 256, 1, 1, 0, 1, 16, 20, 1),
+    (64, 144, 1, 1, 0, 1, 16, 20, 1),   # up-sampling logits
+    (16, 1, 1, 1, 0, 1, 8, 10, 64),     # PixelViewWeight 1x1
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("act", ["none", "relu"])
+def test_conv_matches_torch(case, act):
+    cin, cout, k, stride, pad, dil, h, w, n = case
+    gen = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn((n, cin, h, w), generator=gen).to(DEV)
+    wt = (torch.randn((cout, cin, k, k), generator=gen) / (cin * k * k) ** 0.5).to(DEV)
+    b = torch.randn((cout,), generator=gen).to(DEV)
+    want = F.conv2d(x, wt, b, stride=stride, padding=pad, dilation=dil)
+    add = torch.randn(want.shape, generator=gen).to(DEV)
+    want = want + add
+    if act == "relu":
+        want = F.relu(want)
+    got = ops().conv2d(x, ops().pack_conv_weight(wt), b, ksize=k, stride=stride, pad=pad, dilation=dil, act=act, add=add)
+    assert got.shape == want.shape
+    assert rel_err(got, want) <= 2e-6
+
+
+def test_transposed_conv_with_skip_and_segments():
+    """CorrNet conv3/conv4 (itermvs.py:359-363) incl. the per-level weight sets of one launch."""
+    gen = torch.Generator().manual_seed(5)
+    for cin, cout, h, w in ((32, 16, 8, 10), (16, 8, 7, 9)):
+        n = 10
+        x = torch.randn((n, cin, h, w), generator=gen).to(DEV)
+        ws = [(torch.randn((cin, cout, 3, 3), generator=gen) / (cin * 9) ** 0.5).to(DEV) for _ in range(3)]
+        skip = torch.randn((n, cout, 2 * h, 2 * w), generator=gen).to(DEV)
+        segs = [(0, 4), (4, 8), (8, 10)]
+        want = torch.cat([F.conv_transpose2d(x[a:b], ws[i], stride=2, padding=1, output_padding=1) + skip[a:b]
+                          for i, (a, b) in enumerate(segs)])
+        got = ops().conv2d(x, [ops().pack_conv_weight(wi, transposed=True) for wi in ws], None, transposed=True,
+                           stride=2, pad=1, add=skip, seg_end=[4, 8])
+        assert rel_err(got, want) <= 2e-6
+
+
+def test_segmented_conv_and_channel_slices():
+    gen = torch.Generator().manual_seed(6)
+    n, h, w = 10, 12, 16
+    x = torch.randn((n, 8, h, w), generator=gen).to(DEV)
+    ws = [(torch.randn((1, 8, 3, 3), generator=gen) / 8).to(DEV) for _ in range(3)]
+    bs = [torch.randn((1,), generator=gen).to(DEV) for _ in range(3)]
+    want = torch.cat([F.conv2d(x[a:b], ws[i], bs[i], padding=1) for i, (a, b) in enumerate(((0, 4), (4, 8), (8, 10)))])
+    # write the ten score planes straight into channels 33..42 of two [1,43,H,W] buffers
+    hx = torch.zeros((1, 43, h, w), device=DEV)
+    hx2 = torch.zeros((1, 43, h, w), device=DEV)
+    out = hx[0, 33:43].unsqueeze(1)
+    ops().conv2d(x, [ops().pack_conv_weight(wi) for wi in ws], bs, seg_end=[4, 8], out=out, out2=hx2[0, 33:43].unsqueeze(1))
+    assert rel_err(hx[0, 33:43], want[:, 0]) <= 2e-6 and rel_err(hx2[0, 33:43], want[:, 0]) <= 2e-6
+    assert float(hx[:, :33].abs().max()) == 0.0
+    # input given as a channel slice with a wider batch stride
+    wide = torch.randn((2, 43, h, w), generator=gen).to(DEV)
+    wt = (torch.randn((16, 32, 3, 3), generator=gen) / 17).to(DEV)
+    want = F.conv2d(wide[:, :32], wt, padding=2, dilation=2)
+    got = ops().conv2d(wide[:, :32], ops().pack_conv_weight(wt), None, pad=2, dilation=2)
+    assert rel_err(got, want) <= 2e-6
+
+
+def test_gru_fused_epilogues():
+    """module.py:59-66 with the gate math inside the conv epilogues."""
+    gen = torch.Generator().manual_seed(7)
+    b, hh, ww = 2, 16, 20
+    h = torch.tanh(torch.randn((b, 32, hh, ww), generator=gen)).to(DEV)
+    x = torch.randn((b, 11, hh, ww), generator=gen).to(DEV)
+    wz, wr, wq = [(torch.randn((32, 43, 3, 3), generator=gen) / 20).to(DEV) for _ in range(3)]
+    bz, br, bq = [torch.randn((32,), generator=gen).to(DEV) * 0.1 for _ in range(3)]
+    hx = torch.cat([h, x], 1).contiguous()
+    z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=2, dilation=2))
+    r = torch.sigmoid(F.conv2d(hx, wr, br, padding=2, dilation=2))
+    q = torch.tanh(F.conv2d(torch.cat([r * h, x], 1), wq, bq, padding=2, dilation=2))
+    want = (1 - z) * h + z * q
+    o = ops()
+    hx2 = hx.clone()
+    zbuf = o.conv2d(hx, o.pack_conv_weight(wz), bz, pad=2, dilation=2, act="sigmoid")
+    o.conv2d(hx, o.pack_conv_weight(wr), br, pad=2, dilation=2, act="gru_rh", aux1=hx[:, :32], out=hx2[:, :32])
+    assert rel_err(hx2[:, :32], r * h) <= 5e-6
+    hidden = torch.empty((b, 32, hh, ww), device=DEV)
+    o.conv2d(hx2, o.pack_conv_weight(wq), bq, pad=2, dilation=2, act="gru_out", aux1=hx[:, :32], aux2=zbuf,
+             out=hx[:, :32], out2=hidden)
+    assert rel_err(hidden, want) <= 5e-6 and rel_err(hx[:, :32], want) <= 5e-6
+    assert torch.equal(hx[:, 32:], x)
