@@ -222,8 +222,11 @@ int itermvs_bilinear_up(const float* x, int32_t M, int32_t H, int32_t W, int32_t
  *   nn.ConvTranspose2d(3, stride 2, pad 1, out_pad 1)  models/itermvs.py:359-363 (CorrNet)
  *   ConvGRU gates                                      models/module.py:59-66
  * fp32, contiguous [C,H,W] planes; `in_sn` / `out_sn` / ... are BATCH strides in elements, so
- * inputs and outputs may be channel slices of wider buffers.  `weight` is PACKED [Cin][k][k][Cout]
- * (conv weight.permute(1,2,3,0); transposed-conv weight.permute(0,2,3,1)).  Up to three weight sets
+ * inputs and outputs may be channel slices of wider buffers.  `weight` is PACKED:
+ *   weight_format 0: [Cin][k][k][Cout] (conv weight.permute(1,2,3,0); transposed-conv
+ *     weight.permute(0,2,3,1)) -- VALU kernels, required for `transposed`;
+ *   weight_format 1: [k*k][Cin_pad4][Cout_pad16], zero padded -- matrix-core (MFMA f32 16x16x4)
+ *     implicit-GEMM kernel, the fast path for every regular convolution.  Up to three weight sets
  * per launch: batch items [0,seg_end[0]) use set 0, [seg_end[0],seg_end[1]) set 1, the rest set 2
  * (the three CorrNets of one iteration in one launch).
  * Epilogue `act`: 0 v+add | 1 relu(v+add) | 2 sigmoid | 3 tanh | 4 sigmoid(v)*aux1 (r*h) |
@@ -246,7 +249,7 @@ typedef struct itermvs_conv_params {
     int32_t ksize, stride, pad, dilation;      /* ksize 1 or 3 */
     int32_t transposed;                        /* 1: ConvTranspose2d(3, stride 2, pad 1, output_padding 1) */
     int32_t act;
-    int32_t _pad;
+    int32_t weight_format;
 } itermvs_conv_params;
 
 int itermvs_conv2d(const itermvs_conv_params* p, void* stream);

@@ -180,6 +180,8 @@ static int launch_direct(const ConvArgs& a, int ct, hipStream_t stream) {
 
 using namespace itermvs;
 
+int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);  // conv_mfma.hip
+
 extern "C" int itermvs_conv2d(const itermvs_conv_params* p, void* stream) {
     ITERMVS_RETURN_IF(!p, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(!p->in || !p->out || !p->weight[0], ITERMVS_ERR_NULL);
@@ -200,7 +202,7 @@ extern "C" int itermvs_conv2d(const itermvs_conv_params* p, void* stream) {
     }
     a.N = p->N; a.Cin = p->Cin; a.Hin = p->Hin; a.Win = p->Win; a.Cout = p->Cout;
     a.stride = p->stride; a.pad = p->pad; a.dil = p->dilation; a.act = p->act;
-    // largest channel tile that divides Cout
+    // largest channel tile that divides Cout ...
     int ct = 1;
     for (int c : {32, 16, 8, 4})
         if (p->Cout % c == 0) { ct = c; break; }
@@ -208,6 +210,7 @@ extern "C" int itermvs_conv2d(const itermvs_conv_params* p, void* stream) {
         ITERMVS_RETURN_IF(p->ksize != 3 || p->stride != 2 || p->pad != 1 || p->act > 1, ITERMVS_ERR_DIMS);
         a.Hout = 2 * p->Hin; a.Wout = 2 * p->Win;
         if (ct > 16) ct = 16;       // 4 output pixels x CT accumulators per thread
+        while (ct > 1 && (int64_t)((p->Hin * p->Win + 255) / 256) * (p->Cout / ct) * p->N < 1024) ct /= 2;
         const dim3 grid((p->Hin * p->Win + 255) / 256, p->Cout / ct, p->N);
         switch (ct) {
             case 16: hipLaunchKernelGGL((deconv_s2_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
@@ -222,5 +225,8 @@ extern "C" int itermvs_conv2d(const itermvs_conv_params* p, void* stream) {
     a.Hout = (p->Hin + 2 * p->pad - span) / p->stride + 1;
     a.Wout = (p->Win + 2 * p->pad - span) / p->stride + 1;
     ITERMVS_RETURN_IF(a.Hout < 1 || a.Wout < 1, ITERMVS_ERR_DIMS);
+    if (p->weight_format == 1) return itermvs_conv2d_mfma(p, a.Hout, a.Wout, (hipStream_t)stream);
+    // ... that still leaves >= 1024 workgroups (the VALU kernel keeps all CT channels in one thread)
+    while (ct > 4 && (int64_t)((a.Hout * a.Wout + 255) / 256) * (p->Cout / ct) * p->N < 1024) ct /= 2;
     return p->ksize == 3 ? launch_direct<3>(a, ct, (hipStream_t)stream) : launch_direct<1>(a, ct, (hipStream_t)stream);
 }

@@ -87,15 +87,19 @@ class InferenceEngine:
             self._pack_weights()
 
     def _pack_weights(self) -> None:
-        """[Cout,Cin,k,k] -> packed [Cin,k,k,Cout] once, BatchNorm already folded."""
+        """Re-lay every conv weight once (BatchNorm already folded): regular convolutions in the
+        matrix-core format [k*k, Cin_pad4, Cout_pad16], CorrNet's two transposed convolutions in the
+        VALU format [Cin,k,k,Cout]."""
         w, pk = self.w, self.pk
         for n, (wt, _) in self.cbr.items():
-            pk["feature_net." + n] = ops.pack_conv_weight(wt)
+            pk["feature_net." + n] = ops.MfmaWeight(wt)
         for k, v in w.items():
             if not k.endswith("weight") or v.dim() != 4 or ".bn." in k or k.startswith("feature_net.") and ".conv." in k:
                 continue
-            transposed = k.endswith("conv3.weight") or k.endswith("conv4.weight")
-            pk[k] = ops.pack_conv_weight(v, transposed=transposed)
+            if k.endswith("conv3.weight") or k.endswith("conv4.weight"):      # ConvTranspose2d (itermvs.py:359-363)
+                pk[k] = ops.pack_conv_weight(v, transposed=True)
+            else:
+                pk[k] = ops.MfmaWeight(v)
 
     def _conv(self, x: Tensor, name: str, bias: bool = False, **kw) -> Tensor:
         """one layer by state-dict name (``name`` + "weight"/"bias")"""
@@ -220,7 +224,7 @@ class InferenceEngine:
         b, v, _, hh, ww = imgs.shape
         s = v - 1
         w = self.w
-        feats = self.feature_net(imgs.reshape(b * v, 3, hh, ww))
+        feats = self.feature_net(imgs.reshape(b * v, 3, hh, ww).contiguous())
         cl = {l: ops.channels_last(f) for l, f in feats.items()}
         per_view = {l: cl[l].view(b, v, *cl[l].shape[1:]) for l in (1, 2, 3)}
         src = {l: [per_view[l][:, i] for i in range(1, v)] for l in (1, 2, 3)}

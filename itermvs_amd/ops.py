@@ -314,8 +314,19 @@ ACT = {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "gru_rh": 4, "gru_out": 5}
 
 
 def pack_conv_weight(w: Tensor, transposed: bool = False) -> Tensor:
-    """[Cout,Cin,k,k] (Conv2d) or [Cin,Cout,k,k] (ConvTranspose2d) -> packed [Cin,k,k,Cout]."""
+    """VALU-kernel format: [Cout,Cin,k,k] (Conv2d) or [Cin,Cout,k,k] (ConvTranspose2d) -> [Cin,k,k,Cout]."""
     return (w.permute(0, 2, 3, 1) if transposed else w.permute(1, 2, 3, 0)).contiguous()
+
+
+class MfmaWeight:
+    """Matrix-core format of a Conv2d weight [Cout,Cin,k,k]: [k*k, Cin_pad4, Cout_pad16], zero padded."""
+
+    def __init__(self, w: Tensor):
+        cout, cin, k, _ = w.shape
+        cin_p, cout_p = (cin + 3) // 4 * 4, (cout + 15) // 16 * 16
+        packed = torch.zeros((k * k, cin_p, cout_p), device=w.device, dtype=torch.float32)
+        packed[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
+        self.data, self.cin, self.cout, self.ksize = packed.contiguous(), cin, cout, k
 
 
 def _planes(t: Tensor, name: str):
@@ -336,7 +347,16 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     weights = list(weight) if isinstance(weight, (list, tuple)) else [weight]
     biases = list(bias) if isinstance(bias, (list, tuple)) else [bias] * len(weights)
     n, cin, hin, win = x.shape
-    cout = weights[0].shape[3]
+    mfma = isinstance(weights[0], MfmaWeight)
+    if mfma:
+        if transposed:
+            raise RuntimeError("conv2d: transposed convolutions use the VALU weight format")
+        if any(wt.cin != cin or wt.ksize != ksize for wt in weights):
+            raise RuntimeError("conv2d: MfmaWeight does not match the input channels / kernel size")
+        cout = weights[0].cout
+        weights = [wt.data for wt in weights]
+    else:
+        cout = weights[0].shape[3]
     if transposed:
         hout, wout = 2 * hin, 2 * win
     else:
@@ -362,7 +382,7 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     p.n_seg = len(weights)
     for i, (wt, bs) in enumerate(zip(weights, biases)):
         _dev(wt, "weight")
-        if not wt.is_contiguous() or wt.shape != (cin, ksize, ksize, cout):
+        if not mfma and (not wt.is_contiguous() or wt.shape != (cin, ksize, ksize, cout)):
             raise RuntimeError(f"conv2d: packed weight must be contiguous [{cin},{ksize},{ksize},{cout}], got {tuple(wt.shape)}")
         p.weight[i] = wt.data_ptr()
         p.bias[i] = None if bs is None else _dev(bs, "bias").data_ptr()
@@ -371,6 +391,7 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     p.N, p.Cin, p.Hin, p.Win, p.Cout = n, cin, hin, win, cout
     p.ksize, p.stride, p.pad, p.dilation = ksize, stride, pad, dilation
     p.transposed, p.act = int(transposed), ACT[act]
+    p.weight_format = 1 if mfma else 0
     check(_lib.load().itermvs_conv2d(C.byref(p), _stream()), "itermvs_conv2d")
     return out
 

@@ -37,9 +37,14 @@ CASES = [
 ]
 
 
+def packed(wt, fmt):
+    return ops().MfmaWeight(wt) if fmt == "mfma" else ops().pack_conv_weight(wt)
+
+
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("act", ["none", "relu"])
-def test_conv_matches_torch(case, act):
+@pytest.mark.parametrize("fmt", ["mfma", "valu"])
+def test_conv_matches_torch(case, act, fmt):
     cin, cout, k, stride, pad, dil, h, w, n = case
     gen = torch.Generator().manual_seed(cin * 100 + cout)
     x = torch.randn((n, cin, h, w), generator=gen).to(DEV)
@@ -50,7 +55,7 @@ def test_conv_matches_torch(case, act):
     want = want + add
     if act == "relu":
         want = F.relu(want)
-    got = ops().conv2d(x, ops().pack_conv_weight(wt), b, ksize=k, stride=stride, pad=pad, dilation=dil, act=act, add=add)
+    got = ops().conv2d(x, packed(wt, fmt), b, ksize=k, stride=stride, pad=pad, dilation=dil, act=act, add=add)
     assert got.shape == want.shape
     assert rel_err(got, want) <= 2e-6
 
@@ -71,7 +76,8 @@ def test_transposed_conv_with_skip_and_segments():
         assert rel_err(got, want) <= 2e-6
 
 
-def test_segmented_conv_and_channel_slices():
+@pytest.mark.parametrize("fmt", ["mfma", "valu"])
+def test_segmented_conv_and_channel_slices(fmt):
     gen = torch.Generator().manual_seed(6)
     n, h, w = 10, 12, 16
     x = torch.randn((n, 8, h, w), generator=gen).to(DEV)
@@ -82,18 +88,19 @@ def test_segmented_conv_and_channel_slices():
     hx = torch.zeros((1, 43, h, w), device=DEV)
     hx2 = torch.zeros((1, 43, h, w), device=DEV)
     out = hx[0, 33:43].unsqueeze(1)
-    ops().conv2d(x, [ops().pack_conv_weight(wi) for wi in ws], bs, seg_end=[4, 8], out=out, out2=hx2[0, 33:43].unsqueeze(1))
+    ops().conv2d(x, [packed(wi, fmt) for wi in ws], bs, seg_end=[4, 8], out=out, out2=hx2[0, 33:43].unsqueeze(1))
     assert rel_err(hx[0, 33:43], want[:, 0]) <= 2e-6 and rel_err(hx2[0, 33:43], want[:, 0]) <= 2e-6
     assert float(hx[:, :33].abs().max()) == 0.0
     # input given as a channel slice with a wider batch stride
     wide = torch.randn((2, 43, h, w), generator=gen).to(DEV)
     wt = (torch.randn((16, 32, 3, 3), generator=gen) / 17).to(DEV)
     want = F.conv2d(wide[:, :32], wt, padding=2, dilation=2)
-    got = ops().conv2d(wide[:, :32], ops().pack_conv_weight(wt), None, pad=2, dilation=2)
+    got = ops().conv2d(wide[:, :32], packed(wt, fmt), None, pad=2, dilation=2)
     assert rel_err(got, want) <= 2e-6
 
 
-def test_gru_fused_epilogues():
+@pytest.mark.parametrize("fmt", ["mfma", "valu"])
+def test_gru_fused_epilogues(fmt):
     """module.py:59-66 with the gate math inside the conv epilogues."""
     gen = torch.Generator().manual_seed(7)
     b, hh, ww = 2, 16, 20
@@ -108,11 +115,11 @@ def test_gru_fused_epilogues():
     want = (1 - z) * h + z * q
     o = ops()
     hx2 = hx.clone()
-    zbuf = o.conv2d(hx, o.pack_conv_weight(wz), bz, pad=2, dilation=2, act="sigmoid")
-    o.conv2d(hx, o.pack_conv_weight(wr), br, pad=2, dilation=2, act="gru_rh", aux1=hx[:, :32], out=hx2[:, :32])
+    zbuf = o.conv2d(hx, packed(wz, fmt), bz, pad=2, dilation=2, act="sigmoid")
+    o.conv2d(hx, packed(wr, fmt), br, pad=2, dilation=2, act="gru_rh", aux1=hx[:, :32], out=hx2[:, :32])
     assert rel_err(hx2[:, :32], r * h) <= 5e-6
     hidden = torch.empty((b, 32, hh, ww), device=DEV)
-    o.conv2d(hx2, o.pack_conv_weight(wq), bq, pad=2, dilation=2, act="gru_out", aux1=hx[:, :32], aux2=zbuf,
+    o.conv2d(hx2, packed(wq, fmt), bq, pad=2, dilation=2, act="gru_out", aux1=hx[:, :32], aux2=zbuf,
              out=hx[:, :32], out2=hidden)
     assert rel_err(hidden, want) <= 5e-6 and rel_err(hx[:, :32], want) <= 5e-6
     assert torch.equal(hx[:, 32:], x)
