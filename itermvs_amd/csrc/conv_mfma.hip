@@ -49,7 +49,34 @@ __device__ __forceinline__ float mfma_epilogue(float v, int act, float add, floa
     }
 }
 
-template <int MB, int NB>
+// U consecutive k-steps of one tap: all loads first, then the MFMAs
+template <int MB, int NB, int U>
+__device__ __forceinline__ void k_group(f32x4 (&acc)[MB][NB], const float* __restrict__ wt, int wstep,
+                                        const float* __restrict__ inb, int plane, int ci0, int cmax,
+                                        const int (&off)[NB], const bool (&ok)[NB]) {
+    float av[U][MB], bv[U][NB];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int ci = min(ci0 + 4 * u, cmax);             // padded channels: weight is zero
+        const float* __restrict__ ip = inb + (int64_t)ci * plane;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[u][mb] = wt[u * wstep + mb * 16];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float x = ip[off[nb]];
+            bv[u][nb] = ok[nb] ? x : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mb], bv[u][nb], acc[mb][nb], 0, 0, 0);
+}
+
+template <int MB, int NB, int KS>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(const MfmaArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kslot = lane >> 4, l16 = lane & 15;
@@ -79,9 +106,11 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const MfmaArgs a) {
     const int plane = a.Hin * a.Win;
     const float* __restrict__ inb = a.in + (int64_t)n * a.in_sn;
     const float* __restrict__ wb = a.weight[seg] + (size_t)kslot * a.CoutPad + m0 + l16;
-    const int taps = a.ksize * a.ksize;
-    for (int tap = 0; tap < taps; ++tap) {
-        const int ky = tap / a.ksize, kx = tap - ky * a.ksize;
+    const int wstep = 4 * a.CoutPad;                   // one k-step in the packed weights
+    const int cmax = a.Cin - 1;
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap) {
+        const int ky = tap / KS, kx = tap - ky * KS;
         int off[NB];
         bool ok[NB];
 #pragma unroll
@@ -92,22 +121,18 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const MfmaArgs a) {
             off[nb] = ok[nb] ? iy * a.Win + ix : 0;
         }
         const float* __restrict__ wt = wb + (size_t)tap * a.CinPad * a.CoutPad;
-        for (int c0 = 0; c0 < a.CinPad; c0 += 4) {
-            const int ci = min(c0 + kslot, a.Cin - 1);       // padded channels: weight is zero
-            const float* __restrict__ ip = inb + (int64_t)ci * plane;
-            float av[MB], bv[NB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) av[mb] = wt[(size_t)c0 * a.CoutPad + mb * 16];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const float x = ip[off[nb]];
-                bv[nb] = ok[nb] ? x : 0.0f;
-            }
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+        // software pipelining: k-steps are issued in groups of U = 4 -- the 4*(MB+NB) wave loads of a
+        // group are all in flight before its first MFMA needs them (with 2-3 waves per SIMD on the
+        // small layers a step-by-step loop is pure load latency); the tail runs step by step
+        const int steps = a.CinPad >> 2;
+        int st = 0;
+        for (; st + 4 <= steps; st += 4) {
+            k_group<MB, NB, 4>(acc, wt, wstep, inb, plane, st * 4 + kslot, cmax, off, ok);
+            wt += 4 * wstep;
+        }
+        for (; st < steps; ++st) {
+            k_group<MB, NB, 1>(acc, wt, wstep, inb, plane, st * 4 + kslot, cmax, off, ok);
+            wt += wstep;
         }
     }
     // D: col (pixel) = lane & 15, row (cout) = (lane >> 4) * 4 + r
@@ -154,20 +179,27 @@ int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStr
     a.ksize = p->ksize; a.stride = p->stride; a.pad = p->pad; a.dil = p->dilation; a.act = p->act;
     const int P = hout * wout;
     const int mt = a.CoutPad / 16;
-    // largest register blocking that still yields >= 4096 waves (fills 256 CUs x 4 SIMDs x 4 waves)
+    // largest register blocking (MB x NB tiles of 16 channels x 16 pixels per wave) that still yields
+    // >= 2048 waves (2 per SIMD): bigger tiles need fewer loads per MFMA, more waves hide latency
     struct Cfg { int mb, nb; };
-    const Cfg cfgs[] = {{2, 4}, {2, 2}, {1, 2}, {1, 1}};
-    Cfg pick = cfgs[3];
+    const Cfg cfgs[] = {{3, 4}, {2, 4}, {3, 2}, {2, 2}, {1, 4}, {1, 2}, {3, 1}, {2, 1}, {1, 1}};
+    Cfg pick = {1, 1};
+    int64_t best_waves = -1;
     for (const Cfg& c : cfgs) {
-        if (c.mb > mt || (mt % c.mb) != 0) continue;
+        if (mt % c.mb != 0) continue;
         const int64_t waves = (int64_t)p->N * ((P + 16 * c.nb - 1) / (16 * c.nb)) * (mt / c.mb);
-        if (waves >= 4096) { pick = c; break; }
+        if (waves >= 2048) { pick = c; best_waves = waves; break; }
+        if (waves > best_waves) { pick = c; best_waves = waves; }   // otherwise: the most waves available
     }
     const int px_per_block = 4 * 16 * pick.nb;
     const dim3 grid((P + px_per_block - 1) / px_per_block, mt / pick.mb, p->N);
-    if (pick.mb == 2 && pick.nb == 4) hipLaunchKernelGGL((conv_mfma_kernel<2, 4>), grid, dim3(256), 0, stream, a);
-    else if (pick.mb == 2 && pick.nb == 2) hipLaunchKernelGGL((conv_mfma_kernel<2, 2>), grid, dim3(256), 0, stream, a);
-    else if (pick.mb == 1 && pick.nb == 2) hipLaunchKernelGGL((conv_mfma_kernel<1, 2>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((conv_mfma_kernel<1, 1>), grid, dim3(256), 0, stream, a);
+#define ITERMVS_LAUNCH(MB_, NB_)                                                                              \
+    if (pick.mb == MB_ && pick.nb == NB_) {                                                                    \
+        if (p->ksize == 3) hipLaunchKernelGGL((conv_mfma_kernel<MB_, NB_, 3>), grid, dim3(256), 0, stream, a); \
+        else hipLaunchKernelGGL((conv_mfma_kernel<MB_, NB_, 1>), grid, dim3(256), 0, stream, a);               \
+    }
+    ITERMVS_LAUNCH(3, 4) ITERMVS_LAUNCH(2, 4) ITERMVS_LAUNCH(3, 2) ITERMVS_LAUNCH(2, 2) ITERMVS_LAUNCH(1, 4)
+    ITERMVS_LAUNCH(1, 2) ITERMVS_LAUNCH(3, 1) ITERMVS_LAUNCH(2, 1) ITERMVS_LAUNCH(1, 1)
+#undef ITERMVS_LAUNCH
     return itermvs_launch_status();
 }
