@@ -19,6 +19,8 @@
 //     items [0,4), [4,8), [8,10)) run as ONE launch per layer instead of three.
 // Numerics: plain fp32 fma chains in (ci, ky, kx) order -- same class of rounding as any other
 // convolution back-end; parity is checked against F.conv2d in tests/test_conv_gpu.py.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace itermvs {
@@ -180,7 +182,8 @@ static int launch_direct(const ConvArgs& a, int ct, hipStream_t stream) {
 
 using namespace itermvs;
 
-int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);  // conv_mfma.hip
+int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);      // conv_mfma.hip
+int itermvs_conv2d_mfma_lds(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);  // conv_mfma_lds.hip
 
 extern "C" int itermvs_conv2d(const itermvs_conv_params* p, void* stream) {
     ITERMVS_RETURN_IF(!p, ITERMVS_ERR_NULL);
@@ -225,7 +228,15 @@ extern "C" int itermvs_conv2d(const itermvs_conv_params* p, void* stream) {
     a.Hout = (p->Hin + 2 * p->pad - span) / p->stride + 1;
     a.Wout = (p->Win + 2 * p->pad - span) / p->stride + 1;
     ITERMVS_RETURN_IF(a.Hout < 1 || a.Wout < 1, ITERMVS_ERR_DIMS);
-    if (p->weight_format == 1) return itermvs_conv2d_mfma(p, a.Hout, a.Wout, (hipStream_t)stream);
+    if (p->weight_format == 1) {
+        // direct-gather MFMA kernel by default; ITERMVS_CONV_MFMA=lds tries the LDS-staged variant first
+        static const bool lds = [] { const char* e = getenv("ITERMVS_CONV_MFMA"); return e && e[0] == 'l'; }();
+        if (lds) {
+            const int rc = itermvs_conv2d_mfma_lds(p, a.Hout, a.Wout, (hipStream_t)stream);
+            if (rc <= 0) return rc;
+        }
+        return itermvs_conv2d_mfma(p, a.Hout, a.Wout, (hipStream_t)stream);
+    }
     // ... that still leaves >= 1024 workgroups (the VALU kernel keeps all CT channels in one thread)
     while (ct > 4 && (int64_t)((a.Hout * a.Wout + 255) / 256) * (p->Cout / ct) * p->N < 1024) ct /= 2;
     return p->ksize == 3 ? launch_direct<3>(a, ct, (hipStream_t)stream) : launch_direct<1>(a, ct, (hipStream_t)stream);
