@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Depth inference driver -- counterpart of the reference's ``eval.py`` ``save_depth()`` (eval.py:104-151)
+for the MI355X engine.  Same flags, checkpoint format and output layout
+(``<outdir>/<scan>/depth_est/<view:08d>.pfm`` and ``.../confidence/...``), one process per GPU:
+
+    python eval.py --dataset synthetic --n_views 5 --img_wh 640 512 --outdir ./outputs [--loadckpt model.ckpt]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 eval.py ...
+
+Each rank takes the reference views ``rank, rank + world, ...`` (no collective on the data path).
+``--dataset module:Class`` accepts any dataset yielding the reference's sample dict
+(datasets/dtu_yao_eval.py:154-158); the reference's own loaders (cv2 / PIL based) are outside this
+repository's scope.  The filter/fusion stage of the reference's eval.py is the next row of the build.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from itermvs_amd import shard, synthetic  # noqa: E402
+from itermvs_amd.data_io import save_pfm  # noqa: E402
+from itermvs_amd.net import Pipeline  # noqa: E402
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Predict depth maps (MI355X engine)")
+    p.add_argument("--model", default="IterMVS")
+    p.add_argument("--dataset", default="synthetic", help="'synthetic' or module:Class of an MVSDataset")
+    p.add_argument("--testpath")
+    p.add_argument("--testlist")
+    p.add_argument("--split", default="intermediate")
+    p.add_argument("--batch_size", type=int, default=1)
+    p.add_argument("--n_views", type=int, default=5)
+    p.add_argument("--img_wh", nargs="+", type=int, default=[640, 512], help="width height")
+    p.add_argument("--loadckpt", default=None)
+    p.add_argument("--outdir", default="./outputs")
+    p.add_argument("--display", action="store_true")
+    p.add_argument("--iteration", type=int, default=4)
+    p.add_argument("--geo_pixel_thres", type=float, default=1)
+    p.add_argument("--geo_depth_thres", type=float, default=0.01)
+    p.add_argument("--photo_thres", type=float, default=0.3)
+    p.add_argument("--num_samples", type=int, default=8, help="synthetic dataset: number of reference views")
+    return p
+
+
+class SyntheticMVSDataset(torch.utils.data.Dataset):
+    """Photo-consistent synthetic scenes in the reference's sample-dict schema."""
+
+    def __init__(self, n_views: int, img_wh, count: int):
+        self.n_views, self.w, self.h, self.count = n_views, img_wh[0], img_wh[1], count
+
+    def __len__(self):
+        return self.count
+
+    def __getitem__(self, idx):
+        s = synthetic.make_scene_sample(num_views=self.n_views, height=self.h, width=self.w, seed=idx)
+        return {"imgs": {k: v[0] for k, v in s["imgs"].items()},
+                "proj_matrices": {k: v[0] for k, v in s["proj_matrices"].items()},
+                "depth_min": s["depth_min"][0], "depth_max": s["depth_max"][0],
+                "filename": "scan_synthetic/{}/" + "{:0>8}".format(idx) + "{}"}
+
+
+def make_dataset(args):
+    if args.dataset == "synthetic":
+        return SyntheticMVSDataset(args.n_views, args.img_wh, args.num_samples)
+    mod, cls = args.dataset.split(":")
+    return getattr(importlib.import_module(mod), cls)(args.testpath, args.testlist, args.n_views, tuple(args.img_wh))
+
+
+def collate(samples):
+    out = {"imgs": {}, "proj_matrices": {}}
+    for key in ("imgs", "proj_matrices"):
+        for lvl in samples[0][key]:
+            out[key][lvl] = torch.stack([torch.as_tensor(s[key][lvl]) for s in samples])
+    out["depth_min"] = torch.stack([torch.as_tensor(s["depth_min"], dtype=torch.float32) for s in samples])
+    out["depth_max"] = torch.stack([torch.as_tensor(s["depth_max"], dtype=torch.float32) for s in samples])
+    out["filename"] = [s["filename"] for s in samples]
+    return out
+
+
+def tocuda(x, dev):
+    """utils.py:60-67"""
+    if isinstance(x, torch.Tensor):
+        return x.to(dev, non_blocking=True)
+    if isinstance(x, dict):
+        return {k: tocuda(v, dev) for k, v in x.items()}
+    return x
+
+
+def load_model(args, dev) -> Pipeline:
+    model = Pipeline(iteration=args.iteration, test=True)
+    if args.loadckpt:
+        print("loading model {}".format(args.loadckpt))
+        state = torch.load(args.loadckpt, map_location="cpu", weights_only=False)
+        model.load_checkpoint_state(state["model"])            # eval.py:124-125 ('module.' prefixed keys)
+    else:
+        model.load_state_dict(synthetic.random_state_dict(0))
+    return model.to(dev).eval()
+
+
+def save_depth(args) -> int:
+    rank, local_rank, world = shard.init_distributed()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dataset = make_dataset(args)
+    mine = shard.shard_indices(len(dataset), rank, world)
+    model = load_model(args, dev)
+    done = 0
+    with torch.no_grad():
+        for i in range(0, len(mine), args.batch_size):
+            t0 = time.time()
+            sample = collate([dataset[j] for j in mine[i:i + args.batch_size]])
+            cu = tocuda(sample, dev)
+            out = model(cu["imgs"], cu["proj_matrices"], cu["depth_min"], cu["depth_max"])
+            depth = out["depths_upsampled"].cpu().numpy()      # D2H + sync, like tensor2numpy (eval.py:135)
+            conf = out["confidence_upsampled"].cpu().numpy()
+            print("Iter {}/{}, time = {:.3f}".format(i // args.batch_size, (len(mine) + args.batch_size - 1) // args.batch_size,
+                                                      time.time() - t0))
+            for name, d, c in zip(sample["filename"], depth, conf):
+                save_pfm(os.path.join(args.outdir, name.format("depth_est", ".pfm")), np.squeeze(d, 0))
+                save_pfm(os.path.join(args.outdir, name.format("confidence", ".pfm")), np.squeeze(c, 0))
+                done += 1
+    shard.barrier()
+    return done
+
+
+if __name__ == "__main__":
+    a = build_parser().parse_args()
+    print("argv:", sys.argv[1:])
+    save_depth(a)

@@ -71,3 +71,33 @@ def weights_seed0():
 @pytest.fixture(scope="session")
 def weights_dtu():
     return load_weights("dtu")
+
+
+def run_ranks(worker, world, *args, attempts=3, timeout=180):
+    """Spawn ``world`` CPU processes running ``worker(rank, world, port, *args, queue)`` and return their
+    queue items sorted by rank; retried with a fresh rendezvous port if a rank fails to come up."""
+    import socket
+    import torch.multiprocessing as mp
+    last = None
+    for _ in range(attempts):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=worker, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            res = [q.get(timeout=timeout) for _ in range(world)]
+            for p in procs:
+                p.join(timeout=60)
+            if all(p.exitcode == 0 for p in procs):
+                return sorted(res, key=lambda t: t[0])
+            last = RuntimeError(f"exit codes {[p.exitcode for p in procs]}")
+        except Exception as e:  # noqa: BLE001
+            last = e
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    raise last

@@ -268,7 +268,24 @@ def main():
     golden_cfg1(wd, "dtu")
     golden_cfg1(wd, "dtu", scene=True)
     golden_train(w0)
+    golden_pfm()
 
 
 if __name__ == "__main__":
     main()
+
+
+# ----------------------------------------------------------------------------
+# 7. PFM bytes as written by the reference's datasets/data_io.py (run separately: this part needs only numpy)
+# ----------------------------------------------------------------------------
+def golden_pfm():
+    import tempfile
+    from datasets.data_io import read_pfm, save_pfm
+    rng = np.random.RandomState(3)
+    img = (rng.rand(5, 7) * 900).astype(np.float32)
+    fd, path = tempfile.mkstemp(suffix=".pfm")
+    os.close(fd)
+    save_pfm(path, img)
+    raw = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+    back, scale = read_pfm(path)
+    save("pfm.npz", image=img, file_bytes=raw, readback=np.ascontiguousarray(back), scale=np.float64(scale))

@@ -1,0 +1,86 @@
+"""CPU checks of the formats and drivers either side of the hot path: PFM bytes identical to the
+reference writer's, checkpoint naming / format, learning-rate recipe, the flat gradient all-reduce on
+two gloo ranks, and the eval driver's flag surface."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from conftest import ROOT, golden
+
+sys.path.insert(0, ROOT)
+
+
+def test_pfm_bytes_equal_reference_writer(tmp_path):
+    from itermvs_amd.data_io import read_pfm, save_pfm
+    g = golden("pfm.npz")
+    img = g.np("image")
+    path = str(tmp_path / "sub" / "x.pfm")
+    save_pfm(path, img)
+    assert open(path, "rb").read() == g.np("file_bytes").tobytes()          # byte-identical file
+    back, scale = read_pfm(path)
+    assert scale == float(g.np("scale")) and np.array_equal(back, g.np("readback"))
+    assert np.array_equal(back[..., 0], img)
+    rgb = np.random.RandomState(0).rand(4, 6, 3).astype(np.float32)
+    save_pfm(path, rgb)
+    assert np.array_equal(read_pfm(path)[0], rgb)
+
+
+def test_train_recipe_and_checkpoint_format(tmp_path):
+    import train as T
+    assert T.parse_lrepochs("4,8,12:2") == ([4, 8, 12], 0.5) and T.GRAD_CLIP == 2.0
+    from itermvs_amd.net import Pipeline
+    m = Pipeline(iteration=1, test=False)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    for e in (0, 3, 11):
+        T.save_checkpoint(str(tmp_path / "model_{:0>6}.ckpt".format(e)), e, m, opt)
+    last = T.latest_checkpoint(str(tmp_path))
+    assert last.endswith("model_000011.ckpt")
+    state = torch.load(last, map_location="cpu", weights_only=False)
+    assert set(state) == {"epoch", "model", "optimizer"} and state["epoch"] == 11
+    assert all(k.startswith("module.") for k in state["model"]) and len(state["model"]) == 150   # eval.py:124-125
+    m2 = Pipeline(iteration=1, test=True)
+    m2.load_checkpoint_state(state["model"])
+    args = T.build_parser().parse_args(["--regress", "--lr", "0.002", "--resume"])
+    assert args.regress and args.resume and args.lr == 0.002 and args.epochs == 16
+
+
+def test_eval_flags_and_synthetic_dataset_schema():
+    import eval as E
+    args = E.build_parser().parse_args(["--n_views", "3", "--img_wh", "96", "64", "--iteration", "2", "--num_samples", "3"])
+    ds = E.make_dataset(args)
+    assert len(ds) == 3
+    s = E.collate([ds[0], ds[1]])
+    assert s["imgs"]["level_0"].shape == (2, 3, 3, 64, 96) and s["proj_matrices"]["level_2"].shape == (2, 3, 4, 4)
+    assert s["filename"][1].format("depth_est", ".pfm") == "scan_synthetic/depth_est/00000001.pfm"   # eval.py:141-151
+    assert s["depth_min"].shape == (2,)
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from itermvs_amd import ddp, shard
+    shard.init_distributed(backend="gloo")
+    torch.manual_seed(rank)
+    lin = torch.nn.Linear(5, 3)
+    unused = torch.nn.Parameter(torch.zeros(4))                 # like feature_net.inner3: never gets a gradient
+    params = list(lin.parameters()) + [unused]
+    ddp.broadcast_parameters(lin)
+    w0 = lin.weight.detach().clone()
+    x = torch.full((2, 5), float(rank + 1))
+    lin(x).sum().backward()
+    local = [p.grad.clone() for p in lin.parameters()]
+    n = ddp.flat_allreduce_gradients(params)
+    q.put((rank, w0, local, [p.grad.clone() for p in lin.parameters()], n, unused.grad))
+    torch.distributed.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_two_ranks():
+    from conftest import run_ranks
+    res = run_ranks(_ddp_worker, 2)
+    assert torch.equal(res[0][1], res[1][1])                                     # same start weights on both ranks
+    for i in range(2):                                                           # weight and bias
+        mean = (res[0][2][i] + res[1][2][i]) / 2
+        assert torch.allclose(res[0][3][i], mean) and torch.allclose(res[1][3][i], mean)
+    assert res[0][4] == res[1][4] == 5 * 3 + 3 and res[0][5] is None             # one bucket, unused parameter skipped

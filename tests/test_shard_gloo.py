@@ -1,19 +1,11 @@
 """The N>1 path on CPU: two ``gloo`` processes exercise the reference-view sharding, the
 barrier-bracketed timing with max-over-ranks and the throughput aggregation bench.py uses."""
 import os
-import socket
 import time
 
 import torch
-import torch.multiprocessing as mp
 
 from itermvs_amd import shard
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 def _worker(rank, world, port, n_items, q):
@@ -34,17 +26,9 @@ def _worker(rank, world, port, n_items, q):
 
 
 def test_two_rank_sharding_and_timing():
+    from conftest import run_ranks
     world, n_items = 2, 11
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = run_ranks(_worker, world, n_items)
     owned = sorted(i for _, mine, *_ in res for i in mine)
     assert owned == list(range(n_items))                         # disjoint cover of the reference views
     assert res[0][1] == [0, 2, 4, 6, 8, 10] and res[1][1] == [1, 3, 5, 7, 9]

