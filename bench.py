@@ -93,6 +93,11 @@ def main() -> None:
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--batch", type=int, default=1, help="reference views per step and GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent reference views in flight per GPU (one HIP stream + engine workspace each)")
+    ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying hipGraph segments")
+    ap.add_argument("--pipeline-streams", type=int, default=4,
+                    help="extra measurement: throughput with this many reference views in flight (0/1 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -105,9 +110,14 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    model = Pipeline(iteration=args.iters, test=True)
-    model.load_state_dict(synthetic.random_state_dict(0))
-    model = model.to(dev).eval()
+    models, streams = [], []
+    for _ in range(args.streams):
+        m = Pipeline(iteration=args.iters, test=True)
+        m.load_state_dict(synthetic.random_state_dict(0))
+        m.use_graphs = not args.eager
+        models.append(m.to(dev).eval())
+        streams.append(torch.cuda.Stream(device=dev) if args.streams > 1 else torch.cuda.current_stream(dev))
+    model = models[0]
 
     # this rank's shard of the synthetic reference views, resident in HBM before timing starts
     n_resident = 4
@@ -123,15 +133,22 @@ def main() -> None:
 
     def step(i: int) -> None:
         imgs, projs, dmin, dmax = samples[i % n_resident]
-        out = model(imgs, projs, dmin, dmax)
+        k = i % args.streams
+        with torch.cuda.stream(streams[k]):
+            out = models[k](imgs, projs, dmin, dmax)      # graph mode: replays on this stream
         sink[:] = [out["depths_upsampled"], out["confidence_upsampled"]]
+
+    for k in range(args.streams):                      # set-up, not a step: capture every runner's hipGraph segments
+        with torch.cuda.stream(streams[k]):
+            models[k](*samples[0])
+    torch.cuda.synchronize()
 
     # HIP-event pairs around the fused kernels' launches (on their launch stream); the samples of
     # the warm-up steps are dropped so the figures cover exactly the timed region
-    per_step = args.iters + 1
-    ops.profile_enable((args.steps + args.warmup) * per_step + 8)
+    per_step = args.iters + (1 if args.eager else 0)   # graph mode: corr_init is inside a captured segment
+    ops.profile_enable((args.steps + args.warmup) * per_step + 8 * per_step)
     elapsed = shard.timed_steps(step, args.steps, args.warmup)
-    prof = ops.profile_collect(max_samples=(args.steps + args.warmup) * per_step + 8)[args.warmup * per_step:]
+    prof = ops.profile_collect(max_samples=(args.steps + args.warmup) * per_step + 8 * per_step)[-args.steps * per_step:]
     ops.profile_enable(0)
     maps = world * args.steps * args.batch
     value = maps / elapsed
@@ -148,10 +165,75 @@ def main() -> None:
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": b_iter, "avg_launch_ms": avg_ms, "launches_timed": len(t_iter),
                     "timing": "hipEvent pairs on the launch stream inside the timed region"}
+        pmc_file = os.path.join(ROOT, "profiles", "r01_corr_iter_pmc.json")
+        if os.path.exists(pmc_file):      # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
+            pmc = json.load(open(pmc_file))
+            if pmc.get("workload") == [args.views, args.height, args.width, args.batch]:
+                roofline["traffic"] = pmc["traffic_bytes_per_launch"]
+                roofline["traffic_source"] = pmc["source"]
         if t_init:
             init_ms = sum(t_init) / len(t_init)
             roofline["corr_init"] = {"avg_launch_ms": init_ms, "algorithmic_bytes_per_launch": b_init,
                                      "achieved": b_init / (init_ms * 1e-3) / 1e9}
+
+    # extra: independent reference views pipelined on several HIP streams of the same GPU (each stream replays
+    # its own hipGraph segments).  Reported separately: with concurrent streams the HIP-event bracket of a
+    # single kernel also measures queueing behind the other streams, so the contract's `value` / `roofline`
+    # above stay single-stream and verifiable against rocprofv3.
+    pipelined = None
+    if args.streams == 1 and not args.eager and args.pipeline_streams > 1:
+        ns = args.pipeline_streams
+        pm, pstreams = [], []
+        for _ in range(ns):
+            m = Pipeline(iteration=args.iters, test=True)
+            m.load_state_dict(synthetic.random_state_dict(0))
+            m.use_graphs = True
+            pm.append(m.to(dev).eval())
+            pstreams.append(torch.cuda.Stream(device=dev))
+        for k in range(ns):
+            with torch.cuda.stream(pstreams[k]):
+                pm[k](*samples[0])
+        torch.cuda.synchronize()
+
+        def pstep(i: int) -> None:
+            with torch.cuda.stream(pstreams[i % ns]):
+                pm[i % ns](*samples[i % n_resident])
+
+        psteps = max(args.steps, 4 * ns)
+        pel = shard.timed_steps(pstep, psteps, 2 * ns)
+        pipelined = {"streams": ns, "value": world * psteps * args.batch / pel, "unit": "depth-maps/s",
+                     "steps": psteps, "ms_per_step": pel / psteps * 1e3}
+        del pm
+
+    # second roofline: the matrix-core convolutions (FeatureNet, CorrNet, ConvGRU, heads) -- timed with
+    # HIP-event pairs around every itermvs_conv2d launch in a short EXTRA pass after the timed region
+    # (event pairs around ~100 launches per step would perturb the throughput measurement)
+    conv_roofline = None
+    if rank == 0:
+        n_extra = 3
+        ops.profile_enable(n_extra * 160 + 8, mask=0x4)
+        ops.CONV_FLOP_COUNTER.update(enabled=True, flops=0.0, launches=0)
+        eager_model = Pipeline(iteration=args.iters, test=True)
+        eager_model.load_state_dict(synthetic.random_state_dict(0))
+        eager_model = eager_model.to(dev).eval()
+        eager_model(*samples[0])                       # warm-up (not timed: profiling collects below)
+        torch.cuda.synchronize()
+        ops.profile_collect(max_samples=4096)
+        ops.CONV_FLOP_COUNTER.update(flops=0.0, launches=0)
+        for i in range(n_extra):
+            eager_model(*samples[i % n_resident])
+        torch.cuda.synchronize()
+        ops.CONV_FLOP_COUNTER["enabled"] = False
+        conv_ms = [ms for kind, ms in ops.profile_collect(max_samples=n_extra * 160 + 8) if kind == 3]
+        ops.profile_enable(0)
+        if conv_ms and len(conv_ms) == ops.CONV_FLOP_COUNTER["launches"]:
+            tf = ops.CONV_FLOP_COUNTER["flops"] / (sum(conv_ms) * 1e-3) / 1e12
+            conv_roofline = {"bound": "mfma", "kernel": "itermvs_conv2d (conv_mfma_kernel / deconv_s2_kernel)",
+                             "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                             "launches_per_step": len(conv_ms) // n_extra, "ms_per_step": sum(conv_ms) / n_extra,
+                             "gflop_per_step": ops.CONV_FLOP_COUNTER["flops"] / n_extra / 1e9,
+                             "timing": "hipEvent pairs around every launch, 3 extra steps after the timed region",
+                             "peak_note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) = vector fp32 peak"}
 
     if rank == 0:
         result = {
@@ -163,9 +245,13 @@ def main() -> None:
                                    f"{args.width}x{args.height}, {args.iters} GRU iterations, test mode, "
                                    f"random-init weights, {args.batch} ref view(s) per step and GPU",
                        "views": args.views, "height": args.height, "width": args.width, "iterations": args.iters,
-                       "batch_per_gpu": args.batch, "parallelism": f"ref-view sharding x{world}, no collective",
+                       "batch_per_gpu": args.batch, "streams_per_gpu": args.streams,
+                       "launch": "eager" if args.eager else "hipGraph segments + eager corr_iter",
+                       "parallelism": f"ref-view sharding x{world}, no collective",
                        "algorithmic_MB_per_depth_map": b_map / 1e6},
             "roofline": roofline,
+            "roofline_conv": conv_roofline,
+            "pipelined": pipelined,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)

@@ -262,6 +262,9 @@ int itermvs_conv2d(const itermvs_conv_params* p, void* stream);
  * kind[i] (1 = corr_iter, 2 = corr_init) and ms[i].
  * ------------------------------------------------------------------------------------------ */
 int itermvs_profile_enable(int32_t capacity);
+/* which launches are timed: bit 0 = corr_iter (kind 1), bit 1 = corr_init (kind 2), bit 2 = itermvs_conv2d
+ * (kind 3).  Default 0x3. */
+int itermvs_profile_set_mask(int32_t mask);
 int itermvs_profile_collect(int32_t* kind, float* ms, int32_t max_samples);
 
 #ifdef __cplusplus

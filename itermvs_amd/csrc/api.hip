@@ -33,10 +33,16 @@ std::mutex g_mu;
 std::vector<Sample> g_pool;
 int g_used = 0;
 bool g_enabled = false;
+int g_mask = 0x3;   // kinds 1 (corr_iter) and 2 (corr_init) by default; bit 2 = itermvs_conv2d launches
 }  // namespace
 
+static bool capturing(hipStream_t stream) {   // launches recorded into a hipGraph are not timed
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
 void itermvs_profile_begin(int kind, hipStream_t stream) {
-    if (!g_enabled) return;
+    if (!g_enabled || !((g_mask >> (kind - 1)) & 1) || capturing(stream)) return;
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_used >= (int)g_pool.size()) return;
     g_pool[g_used].kind = kind;
@@ -46,11 +52,17 @@ void itermvs_profile_begin(int kind, hipStream_t stream) {
 void itermvs_profile_cancel() {}  // a begun sample without an end is simply overwritten by the next begin
 
 void itermvs_profile_end(int kind, hipStream_t stream) {
-    if (!g_enabled) return;
+    if (!g_enabled || !((g_mask >> (kind - 1)) & 1) || capturing(stream)) return;
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_used >= (int)g_pool.size() || g_pool[g_used].kind != kind) return;
     (void)hipEventRecord(g_pool[g_used].t1, stream);
     ++g_used;
+}
+
+extern "C" int itermvs_profile_set_mask(int32_t mask) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_mask = mask;
+    return ITERMVS_OK;
 }
 
 extern "C" int itermvs_profile_enable(int32_t capacity) {

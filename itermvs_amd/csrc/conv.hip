@@ -185,7 +185,16 @@ using namespace itermvs;
 int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);      // conv_mfma.hip
 int itermvs_conv2d_mfma_lds(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);  // conv_mfma_lds.hip
 
+static int conv2d_impl(const itermvs_conv_params* p, void* stream);
+
 extern "C" int itermvs_conv2d(const itermvs_conv_params* p, void* stream) {
+    itermvs_profile_begin(3, (hipStream_t)stream);
+    const int rc = conv2d_impl(p, stream);
+    itermvs_profile_end(3, (hipStream_t)stream);
+    return rc;
+}
+
+static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     ITERMVS_RETURN_IF(!p, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(!p->in || !p->out || !p->weight[0], ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->N < 1 || p->Cin < 1 || p->Cout < 1 || p->Hin < 1 || p->Win < 1, ITERMVS_ERR_DIMS);

@@ -74,12 +74,15 @@ class Pipeline(nn.Module):
             is_buffer = "running_" in name or name.endswith("num_batches_tracked")
             _attach(self, name, _default_init(name, shape), is_buffer)
         self._engine = None
+        self._runners = {}
+        self.use_graphs = False        # test mode: replay hipGraph segments instead of launching kernel by kernel
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     # -- weights ----------------------------------------------------------------------------
     def invalidate(self) -> None:
         """Drop the folded / re-laid-out inference weights (after any parameter change)."""
         self._engine = None
+        self._runners = {}
 
     def load_checkpoint_state(self, state: Mapping[str, torch.Tensor], strict: bool = True):
         """Load a reference checkpoint's ``state_dict['model']`` (keys may carry ``module.``)."""
@@ -113,7 +116,15 @@ class Pipeline(nn.Module):
             if self._engine is None:
                 self._engine = InferenceEngine(self.weights(), self.iteration)
             with torch.no_grad():
-                depth_up, conf_up = self._engine.run(x.float(), projs, depth_min, depth_max)
+                if self.use_graphs:
+                    from .engine import GraphedRunner
+                    key = (tuple(x.shape), x.device.index)
+                    runner = self._runners.get(key)
+                    if runner is None:
+                        runner = self._runners[key] = GraphedRunner(self._engine, x.float(), projs, depth_min, depth_max)
+                    depth_up, conf_up = runner(x.float(), projs, depth_min, depth_max)
+                else:
+                    depth_up, conf_up = self._engine.run(x.float(), projs, depth_min, depth_max)
             return {"depths_upsampled": depth_up, "confidence_upsampled": conf_up}
         from .train_graph import train_forward
         return train_forward(self.weights(), x.float(), projs, depth_min, depth_max, self.iteration,

@@ -392,12 +392,20 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     p.ksize, p.stride, p.pad, p.dilation = ksize, stride, pad, dilation
     p.transposed, p.act = int(transposed), ACT[act]
     p.weight_format = 1 if mfma else 0
+    if CONV_FLOP_COUNTER["enabled"]:
+        CONV_FLOP_COUNTER["flops"] += 2.0 * n * hout * wout * cout * cin * ksize * ksize / (4.0 if transposed else 1.0)
+        CONV_FLOP_COUNTER["launches"] += 1
     check(_lib.load().itermvs_conv2d(C.byref(p), _stream()), "itermvs_conv2d")
     return out
 
 
 # ------------------------------------------------------------------------------------------
-def profile_enable(capacity: int) -> None:
+CONV_FLOP_COUNTER = {"enabled": False, "flops": 0.0, "launches": 0}
+
+
+def profile_enable(capacity: int, mask: int = 0x3) -> None:
+    """mask: bit 0 corr_iter, bit 1 corr_init, bit 2 every itermvs_conv2d launch"""
+    check(_lib.load().itermvs_profile_set_mask(mask), "itermvs_profile_set_mask")
     check(_lib.load().itermvs_profile_enable(capacity), "itermvs_profile_enable")
 
 
