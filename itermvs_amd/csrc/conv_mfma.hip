@@ -16,6 +16,8 @@
 // K is ordered (tap, ci) with Cin padded to a multiple of 4 (zero weights), so the four k-slots of a
 // step share one tap: the spatial offset is computed once per tap and the inner loop is
 // `load A, load B, mfma` with two pointer bumps.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace itermvs {
@@ -159,6 +161,92 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const MfmaArgs a) {
         }
 }
 
+// Split-K variant for layers with too few output tiles to fill the chip (ConvGRU gates, heads, the
+// coarse CorrNet layers: a few hundred 16x16 tiles, each a serial chain of up to 100 dependent k-steps).
+// The four waves of a block share ONE 16-pixel x 16*MB-channel tile and each takes every fourth k-step;
+// partial accumulators are summed through LDS in a fixed order (deterministic) and wave 0 runs the
+// epilogue.  4x the waves, 4x shorter dependency chains.
+template <int MB, int KS>
+__global__ void __launch_bounds__(256) conv_mfma_splitk_kernel(const MfmaArgs a) {
+    __shared__ float red[3][MB][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kslot = lane >> 4, l16 = lane & 15;
+    const int n = blockIdx.z;
+    const int seg = (n >= a.seg_end[0]) + (n >= a.seg_end[1]);
+    const int P = a.Hout * a.Wout;
+    const int m0 = blockIdx.y * (MB * 16);
+    const int pbase = blockIdx.x * 16;
+    const int p = pbase + l16;
+    const bool pv = p < P;
+    const int pc = pv ? p : 0;
+    const int oy = pc / a.Wout, ox = pc - oy * a.Wout;
+    f32x4 acc[MB][1];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int plane = a.Hin * a.Win;
+    const float* __restrict__ inb = a.in + (int64_t)n * a.in_sn;
+    const float* __restrict__ wb = a.weight[seg] + (size_t)kslot * a.CoutPad + m0 + l16;
+    const int wstep = 4 * a.CoutPad;
+    const int cmax = a.Cin - 1;
+    const int steps = a.CinPad >> 2;
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap) {
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int iy = oy * a.stride - a.pad + ky * a.dil;
+        const int ix = ox * a.stride - a.pad + kx * a.dil;
+        bool ok[1];
+        int off[1];
+        ok[0] = pv && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        off[0] = ok[0] ? iy * a.Win + ix : 0;
+        const float* __restrict__ wt = wb + (size_t)tap * a.CinPad * a.CoutPad;
+        // this wave's k-steps of the tap: (tap * steps + st) % 4 == wave keeps the four waves balanced
+        int st = (wave - tap * steps) & 3;
+        for (; st + 4 < steps; st += 8) {        // two of this wave's steps per trip: 2*(MB+1) loads in flight
+            f32x4 (&ac)[MB][1] = acc;
+            float av0[MB], av1[MB];
+            const int c0 = min(st * 4 + kslot, cmax), c1 = min((st + 4) * 4 + kslot, cmax);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                av0[mb] = wt[(size_t)st * wstep + mb * 16];
+                av1[mb] = wt[(size_t)(st + 4) * wstep + mb * 16];
+            }
+            const float x0 = inb[(int64_t)c0 * plane + off[0]], x1 = inb[(int64_t)c1 * plane + off[0]];
+            const float b0 = ok[0] ? x0 : 0.0f, b1 = ok[0] ? x1 : 0.0f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                ac[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[mb], b0, ac[mb][0], 0, 0, 0);
+                ac[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[mb], b1, ac[mb][0], 0, 0, 0);
+            }
+        }
+        for (; st < steps; st += 4)
+            k_group<MB, 1, 1>(acc, wt + (size_t)st * wstep, wstep, inb, plane, st * 4 + kslot, cmax, off, ok);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave - 1][mb][r][lane] = acc[mb][0][r];
+    }
+    __syncthreads();
+    if (wave != 0 || !pv) return;
+    const float* __restrict__ bias = a.bias[seg];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = m0 + mb * 16 + kslot * 4 + r;
+            if (co >= a.Cout) continue;
+            const float sum = ((acc[mb][0][r] + red[0][mb][r][lane]) + red[1][mb][r][lane]) + red[2][mb][r][lane];
+            const int64_t ch = (int64_t)co * P + p;
+            const float ad = a.add ? a.add[(int64_t)n * a.add_sn + ch] : 0.0f;
+            const float a1 = a.aux1 ? a.aux1[(int64_t)n * a.aux1_sn + ch] : 0.0f;
+            const float a2 = a.aux2 ? a.aux2[(int64_t)n * a.aux2_sn + ch] : 0.0f;
+            const float v = mfma_epilogue(sum + (bias ? bias[co] : 0.0f), a.act, ad, a1, a2);
+            a.out[(int64_t)n * a.out_sn + ch] = v;
+            if (a.out2) a.out2[((int64_t)n * a.Cout) * P + ch] = v;
+        }
+}
+
 }  // namespace itermvs
 
 using namespace itermvs;
@@ -190,6 +278,22 @@ int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStr
         const int64_t waves = (int64_t)p->N * ((P + 16 * c.nb - 1) / (16 * c.nb)) * (mt / c.mb);
         if (waves >= 2048) { pick = c; best_waves = waves; break; }
         if (waves > best_waves) { pick = c; best_waves = waves; }   // otherwise: the most waves available
+    }
+    // too few tiles even at 16x16 and a k-loop long enough to split: four waves per tile (split-K)
+    static const bool no_splitk = [] { const char* e = getenv("ITERMVS_CONV_SPLITK"); return e && e[0] == '0'; }();
+    const int ksteps = p->ksize * p->ksize * (a.CinPad / 4);
+    const int64_t tiles16 = (int64_t)p->N * ((P + 15) / 16) * mt;       // waves of the <1,1> configuration
+    if (!no_splitk && tiles16 < 8192 && ksteps >= 16) {
+        const int mb = (mt % 2 == 0 && tiles16 / 2 >= 2048) ? 2 : 1;
+        const dim3 grid((P + 15) / 16, mt / mb, p->N);
+        if (mb == 2) {
+            if (p->ksize == 3) hipLaunchKernelGGL((conv_mfma_splitk_kernel<2, 3>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((conv_mfma_splitk_kernel<2, 1>), grid, dim3(256), 0, stream, a);
+        } else {
+            if (p->ksize == 3) hipLaunchKernelGGL((conv_mfma_splitk_kernel<1, 3>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((conv_mfma_splitk_kernel<1, 1>), grid, dim3(256), 0, stream, a);
+        }
+        return itermvs_launch_status();
     }
     const int px_per_block = 4 * 16 * pick.nb;
     const dim3 grid((P + px_per_block - 1) / px_per_block, mt / pick.mb, p->N);
