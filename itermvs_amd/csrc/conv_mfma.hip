@@ -51,23 +51,30 @@ __device__ __forceinline__ float mfma_epilogue(float v, int act, float add, floa
     }
 }
 
+// Operand fetch: every load is a BUFFER load through a wave-uniform 128-bit descriptor --
+//   address = descriptor base (SGPRs) + per-lane 32-bit byte offset (VGPR, constant per tap) + SGPR offset
+//   (advances with the k-step) -- so the k-loop carries NO vector address arithmetic, and the hardware
+//   bounds check returns 0 for (a) taps outside the image (their lane offset is set out of range) and
+//   (b) the zero-padded channels beyond Cin.  (PMC on the flat-pointer version: 11-21 VALU instructions
+//   per MFMA -- 64-bit address math, clamps and selects -- made the kernels VALU-issue bound.)
+constexpr uint32_t kOob = 0x7fffffffu;   // lane offset that is out of range for every descriptor used here
+
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 // U consecutive k-steps of one tap: all loads first, then the MFMAs
 template <int MB, int NB, int U>
-__device__ __forceinline__ void k_group(f32x4 (&acc)[MB][NB], const float* __restrict__ wt, int wstep,
-                                        const float* __restrict__ inb, int plane, int ci0, int cmax,
-                                        const int (&off)[NB], const bool (&ok)[NB]) {
+__device__ __forceinline__ void k_group(f32x4 (&acc)[MB][NB], __amdgpu_buffer_rsrc_t wr, uint32_t wv, uint32_t ws,
+                                        uint32_t wstep_b, __amdgpu_buffer_rsrc_t ir, const uint32_t (&iv)[NB],
+                                        uint32_t is, uint32_t istep_b) {
     float av[U][MB], bv[U][NB];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int ci = min(ci0 + 4 * u, cmax);             // padded channels: weight is zero
-        const float* __restrict__ ip = inb + (int64_t)ci * plane;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) av[u][mb] = wt[u * wstep + mb * 16];
+        for (int mb = 0; mb < MB; ++mb) av[u][mb] = bload(wr, wv + mb * 64, ws + u * wstep_b);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const float x = ip[off[nb]];
-            bv[u][nb] = ok[nb] ? x : 0.0f;
-        }
+        for (int nb = 0; nb < NB; ++nb) bv[u][nb] = bload(ir, iv[nb], is + u * istep_b);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -105,36 +112,40 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const MfmaArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    const int plane = a.Hin * a.Win;
-    const float* __restrict__ inb = a.in + (int64_t)n * a.in_sn;
-    const float* __restrict__ wb = a.weight[seg] + (size_t)kslot * a.CoutPad + m0 + l16;
-    const int wstep = 4 * a.CoutPad;                   // one k-step in the packed weights
-    const int cmax = a.Cin - 1;
+    const uint32_t plane = (uint32_t)(a.Hin * a.Win);
+    // descriptors from wave-uniform values only (kernel arguments, blockIdx)
+    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.in + (int64_t)n * a.in_sn), 0, (int)(a.Cin * plane * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.weight[seg] + m0), 0, (int)((uint32_t)(KS * KS) * a.CinPad * a.CoutPad * 4u), 0x00020000);
+    const uint32_t wv = (uint32_t)(kslot * a.CoutPad + l16) * 4u;
+    const uint32_t wstep_b = 16u * a.CoutPad;          // bytes per k-step in the packed weights
+    const uint32_t istep_b = 16u * plane;              // bytes per k-step in the input planes (4 channels)
+    const uint32_t kplane_b = (uint32_t)kslot * plane * 4u;
+    const int steps = a.CinPad >> 2;
 #pragma unroll
     for (int tap = 0; tap < KS * KS; ++tap) {
         const int ky = tap / KS, kx = tap - ky * KS;
-        int off[NB];
-        bool ok[NB];
+        uint32_t iv[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int iy = oy[nb] * a.stride - a.pad + ky * a.dil;
             const int ix = ox[nb] * a.stride - a.pad + kx * a.dil;
-            ok[nb] = pv[nb] && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            off[nb] = ok[nb] ? iy * a.Win + ix : 0;
+            const bool ok = pv[nb] && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            iv[nb] = ok ? kplane_b + (uint32_t)(iy * a.Win + ix) * 4u : kOob;
         }
-        const float* __restrict__ wt = wb + (size_t)tap * a.CinPad * a.CoutPad;
-        // software pipelining: k-steps are issued in groups of U = 4 -- the 4*(MB+NB) wave loads of a
-        // group are all in flight before its first MFMA needs them (with 2-3 waves per SIMD on the
-        // small layers a step-by-step loop is pure load latency); the tail runs step by step
-        const int steps = a.CinPad >> 2;
+        uint32_t ws = (uint32_t)tap * a.CinPad * a.CoutPad * 4u, is = 0;
+        // k-steps in groups of 4: the 4*(MB+NB) loads of a group are in flight before its first MFMA
         int st = 0;
         for (; st + 4 <= steps; st += 4) {
-            k_group<MB, NB, 4>(acc, wt, wstep, inb, plane, st * 4 + kslot, cmax, off, ok);
-            wt += 4 * wstep;
+            k_group<MB, NB, 4>(acc, wr, wv, ws, wstep_b, ir, iv, is, istep_b);
+            ws += 4 * wstep_b;
+            is += 4 * istep_b;
         }
         for (; st < steps; ++st) {
-            k_group<MB, NB, 1>(acc, wt, wstep, inb, plane, st * 4 + kslot, cmax, off, ok);
-            wt += wstep;
+            k_group<MB, NB, 1>(acc, wr, wv, ws, wstep_b, ir, iv, is, istep_b);
+            ws += wstep_b;
+            is += istep_b;
         }
     }
     // D: col (pixel) = lane & 15, row (cout) = (lane >> 4) * 4 + r
@@ -183,43 +194,43 @@ __global__ void __launch_bounds__(256) conv_mfma_splitk_kernel(const MfmaArgs a)
     f32x4 acc[MB][1];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const int plane = a.Hin * a.Win;
-    const float* __restrict__ inb = a.in + (int64_t)n * a.in_sn;
-    const float* __restrict__ wb = a.weight[seg] + (size_t)kslot * a.CoutPad + m0 + l16;
-    const int wstep = 4 * a.CoutPad;
-    const int cmax = a.Cin - 1;
+    const uint32_t plane = (uint32_t)(a.Hin * a.Win);
+    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.in + (int64_t)n * a.in_sn), 0, (int)(a.Cin * plane * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.weight[seg] + m0), 0, (int)((uint32_t)(KS * KS) * a.CinPad * a.CoutPad * 4u), 0x00020000);
+    const uint32_t wv = (uint32_t)(kslot * a.CoutPad + l16) * 4u;
+    const uint32_t wstep_b = 16u * a.CoutPad, istep_b = 16u * plane;
+    const uint32_t kplane_b = (uint32_t)kslot * plane * 4u;
     const int steps = a.CinPad >> 2;
+    // the wave id selects this wave's k-steps; made provably uniform for the scalar offset math
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
     for (int tap = 0; tap < KS * KS; ++tap) {
         const int ky = tap / KS, kx = tap - ky * KS;
         const int iy = oy * a.stride - a.pad + ky * a.dil;
         const int ix = ox * a.stride - a.pad + kx * a.dil;
-        bool ok[1];
-        int off[1];
-        ok[0] = pv && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        off[0] = ok[0] ? iy * a.Win + ix : 0;
-        const float* __restrict__ wt = wb + (size_t)tap * a.CinPad * a.CoutPad;
+        const bool ok = pv && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        uint32_t iv[1];
+        iv[0] = ok ? kplane_b + (uint32_t)(iy * a.Win + ix) * 4u : kOob;
+        const uint32_t wt = (uint32_t)tap * a.CinPad * a.CoutPad * 4u;
         // this wave's k-steps of the tap: (tap * steps + st) % 4 == wave keeps the four waves balanced
-        int st = (wave - tap * steps) & 3;
-        for (; st + 4 < steps; st += 8) {        // two of this wave's steps per trip: 2*(MB+1) loads in flight
-            f32x4 (&ac)[MB][1] = acc;
+        int st = (wu - tap * steps) & 3;
+        for (; st + 4 < steps; st += 8) {        // two of this wave's steps per trip
             float av0[MB], av1[MB];
-            const int c0 = min(st * 4 + kslot, cmax), c1 = min((st + 4) * 4 + kslot, cmax);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                av0[mb] = wt[(size_t)st * wstep + mb * 16];
-                av1[mb] = wt[(size_t)(st + 4) * wstep + mb * 16];
+                av0[mb] = bload(wr, wv + mb * 64, wt + st * wstep_b);
+                av1[mb] = bload(wr, wv + mb * 64, wt + (st + 4) * wstep_b);
             }
-            const float x0 = inb[(int64_t)c0 * plane + off[0]], x1 = inb[(int64_t)c1 * plane + off[0]];
-            const float b0 = ok[0] ? x0 : 0.0f, b1 = ok[0] ? x1 : 0.0f;
+            const float b0 = bload(ir, iv[0], st * istep_b), b1 = bload(ir, iv[0], (st + 4) * istep_b);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                ac[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[mb], b0, ac[mb][0], 0, 0, 0);
-                ac[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[mb], b1, ac[mb][0], 0, 0, 0);
+                acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[mb], b0, acc[mb][0], 0, 0, 0);
+                acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[mb], b1, acc[mb][0], 0, 0, 0);
             }
         }
-        for (; st < steps; st += 4)
-            k_group<MB, 1, 1>(acc, wt + (size_t)st * wstep, wstep, inb, plane, st * 4 + kslot, cmax, off, ok);
+        for (; st < steps; st += 4) k_group<MB, 1, 1>(acc, wr, wv, wt + st * wstep_b, wstep_b, ir, iv, st * istep_b, istep_b);
     }
     if (wave > 0) {
 #pragma unroll
