@@ -183,7 +183,7 @@ static int launch_direct(const ConvArgs& a, int ct, hipStream_t stream) {
 using namespace itermvs;
 
 int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);      // conv_mfma.hip
-int itermvs_conv2d_mfma_lds(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);  // conv_mfma_lds.hip
+int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);      // conv_tile.hip
 
 static int conv2d_impl(const itermvs_conv_params* p, void* stream);
 
@@ -202,6 +202,7 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     ITERMVS_RETURN_IF(p->n_seg < 1 || p->n_seg > 3 || p->act < 0 || p->act > 5, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF((p->act == 4 || p->act == 5) && !p->aux1, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->act == 5 && !p->aux2, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(p->act >= 2 && p->add, ITERMVS_ERR_DIMS);   // residual add only with none / relu
     ConvArgs a;
     a.in = p->in; a.out = p->out; a.out2 = p->out2; a.add = p->add; a.aux1 = p->aux1; a.aux2 = p->aux2;
     a.in_sn = p->in_sn; a.out_sn = p->out_sn; a.add_sn = p->add_sn; a.aux1_sn = p->aux1_sn; a.aux2_sn = p->aux2_sn;
@@ -237,15 +238,11 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     a.Hout = (p->Hin + 2 * p->pad - span) / p->stride + 1;
     a.Wout = (p->Win + 2 * p->pad - span) / p->stride + 1;
     ITERMVS_RETURN_IF(a.Hout < 1 || a.Wout < 1, ITERMVS_ERR_DIMS);
-    if (p->weight_format == 1) {
-        // direct-gather MFMA kernel by default; ITERMVS_CONV_MFMA=lds tries the LDS-staged variant first
-        static const bool lds = [] { const char* e = getenv("ITERMVS_CONV_MFMA"); return e && e[0] == 'l'; }();
-        if (lds) {
-            const int rc = itermvs_conv2d_mfma_lds(p, a.Hout, a.Wout, (hipStream_t)stream);
-            if (rc <= 0) return rc;
-        }
-        return itermvs_conv2d_mfma(p, a.Hout, a.Wout, (hipStream_t)stream);
+    if (p->weight_format == 2) {   // LDS-tiled 3x3 kernels; the packed layout fits no other kernel
+        const int rc = itermvs_conv2d_tile(p, a.Hout, a.Wout, (hipStream_t)stream);
+        return rc == 1 ? ITERMVS_ERR_DIMS : rc;
     }
+    if (p->weight_format == 1) return itermvs_conv2d_mfma(p, a.Hout, a.Wout, (hipStream_t)stream);
     // ... that still leaves >= 1024 workgroups (the VALU kernel keeps all CT channels in one thread)
     while (ct > 4 && (int64_t)((a.Hout * a.Wout + 255) / 256) * (p->Cout / ct) * p->N < 1024) ct /= 2;
     return p->ksize == 3 ? launch_direct<3>(a, ct, (hipStream_t)stream) : launch_direct<1>(a, ct, (hipStream_t)stream);

@@ -1,0 +1,157 @@
+// Shared epilogue of the matrix-core convolution kernels (conv_mfma.hip, conv_tile.hip).
+//
+// A wave holds MB x NB accumulator tiles of v_mfma_f32_16x16x4_f32: lane l owns output channels
+// m0 + mb*16 + (l >> 4)*4 + r (r = 0..3) of pixel slot nb.  Bias / residual / activation / ConvGRU gate
+// math are applied on the accumulators and written to the NCHW planes (16 lanes = one 64-byte run).
+//
+// gfx9 retires loads AND stores in order through one counter (vmcnt): an epilogue that loads an optional
+// operand per element forces `s_waitcnt vmcnt(0)` between consecutive stores -- one L2 round trip per
+// element (measured: 590 cycles per store, 9.4k of the 20k cycles a workgroup spent per tile).  Here every
+// access goes through a buffer descriptor (invalid pixels / padded channels get an out-of-range offset and
+// are dropped by the hardware bounds check: no divergent branches), optional operands are fetched for a
+// whole pixel slot before its first store, and a slot without optional operands issues its stores back to
+// back with no wait at all.
+#pragma once
+
+#include "common.hpp"
+
+namespace itermvs {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr uint32_t kEpiOob = 0x7fffffffu;
+
+template <int ACT>
+__device__ __forceinline__ float conv_activation(float v, float a1, float a2) {
+    if constexpr (ACT == 1) return fmaxf(v, 0.0f);
+    else if constexpr (ACT == 2) return sigmoidf_(v);
+    else if constexpr (ACT == 3) return tanhf(v);
+    else if constexpr (ACT == 4) return sigmoidf_(v) * a1;                  // r * h            (module.py:63-64)
+    else if constexpr (ACT == 5) return (1.0f - a2) * a1 + a2 * tanhf(v);   // (1-z) h + z q    (module.py:64-65)
+    else return v;
+}
+
+struct EpilogueArgs {
+    float* out;          // + n * out_sn applied by the caller
+    float* out2;         // dense [Cout][P] copy or nullptr
+    const float* add;    // optional, same indexing as out (already offset to batch item n)
+    const float* aux1;
+    const float* aux2;
+    int Cout, P, act;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float epi_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff = 0) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void epi_store(float v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0);
+}
+
+// The bias is NOT added here: the kernels start their accumulators from it (conv_bias_init), which saves
+// one VALU instruction per output -- on gfx950 fp32 MFMAs and ordinary VALU instructions of other waves do
+// not overlap (tools/ubench/mfma_valu_overlap.hip: the times add), so every VALU instruction in these
+// kernels is paid for in matrix-core time.
+template <int MB, int NB>
+__device__ __forceinline__ void conv_bias_init(f32x4 (&acc)[MB][NB], const float* bias, int Cout, int m0, int q) {
+    float bs[MB][4];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[mb][r] = 0.0f;
+    if (bias) {
+        const __amdgpu_buffer_rsrc_t rb = epi_rsrc(bias, (uint32_t)Cout * 4u);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bs[mb][r] = epi_load(rb, (uint32_t)(m0 + mb * 16 + q * 4 + r) * 4u);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{bs[mb][0], bs[mb][1], bs[mb][2], bs[mb][3]};
+}
+
+// pix_off[nb]: byte offset of this lane's pixel of slot nb inside a channel plane, or kEpiOob.
+// Element (mb, r) of a lane is channel m0 + mb*16 + q*4 + r: the lane part (q*4 planes + pixel) is ONE
+// vector offset per slot, the (m0 + mb*16 + r) planes go into the instruction's scalar offset -- no vector
+// address arithmetic per element, and padded channels (>= Cout) land beyond the descriptor by themselves.
+// The activation is a template parameter (one uniform switch in conv_epilogue below): inside the element
+// loops the code is straight-line.
+template <int ACT, bool ADD, int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_act(const EpilogueArgs& e, const f32x4 (&acc)[MB][NB], int m0, int q,
+                                                  const uint32_t (&pix_off)[NB]) {
+    const uint32_t plane_b = (uint32_t)e.P * 4u;
+    const uint32_t bytes = (uint32_t)e.Cout * plane_b;
+    const __amdgpu_buffer_rsrc_t ro = epi_rsrc(e.out, bytes);
+    const uint32_t lane_ch = (uint32_t)(q * 4) * plane_b;
+    const uint32_t s0 = (uint32_t)m0 * plane_b;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const uint32_t voff = pix_off[nb] == kEpiOob ? kEpiOob : pix_off[nb] + lane_ch;
+        float ad[MB][4], a1[MB][4], a2[MB][4], v[MB][4];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ad[mb][r] = a1[mb][r] = a2[mb][r] = 0.0f;
+        if constexpr (ADD) {
+            const __amdgpu_buffer_rsrc_t rr = epi_rsrc(e.add, bytes);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ad[mb][r] = epi_load(rr, voff, s0 + (uint32_t)(mb * 16 + r) * plane_b);
+        }
+        if constexpr (ACT == 4 || ACT == 5) {
+            const __amdgpu_buffer_rsrc_t rr = epi_rsrc(e.aux1, bytes);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a1[mb][r] = epi_load(rr, voff, s0 + (uint32_t)(mb * 16 + r) * plane_b);
+        }
+        if constexpr (ACT == 5) {
+            const __amdgpu_buffer_rsrc_t rr = epi_rsrc(e.aux2, bytes);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a2[mb][r] = epi_load(rr, voff, s0 + (uint32_t)(mb * 16 + r) * plane_b);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = ADD ? acc[mb][nb][r] + ad[mb][r] : acc[mb][nb][r];
+                v[mb][r] = conv_activation<ACT>(x, a1[mb][r], a2[mb][r]);
+                epi_store(v[mb][r], ro, voff, s0 + (uint32_t)(mb * 16 + r) * plane_b);
+            }
+        if (e.out2) {
+            const __amdgpu_buffer_rsrc_t r2 = epi_rsrc(e.out2, bytes);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) epi_store(v[mb][r], r2, voff, s0 + (uint32_t)(mb * 16 + r) * plane_b);
+        }
+    }
+}
+
+// The optional residual operand is a template parameter as well: a run-time `if (add)` around its loads
+// makes the compiler wait for vmcnt(0) in front of EVERY pixel slot -- i.e. for the previous slot's stores.
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue(const EpilogueArgs& e, const f32x4 (&acc)[MB][NB], int m0, int q,
+                                              const uint32_t (&pix_off)[NB]) {
+    const int key = e.act * 2 + (e.add ? 1 : 0);
+    switch (key) {
+        case 0: conv_epilogue_act<0, false, MB, NB>(e, acc, m0, q, pix_off); break;
+        case 1: conv_epilogue_act<0, true, MB, NB>(e, acc, m0, q, pix_off); break;
+        case 2: conv_epilogue_act<1, false, MB, NB>(e, acc, m0, q, pix_off); break;
+        case 3: conv_epilogue_act<1, true, MB, NB>(e, acc, m0, q, pix_off); break;
+        case 4: conv_epilogue_act<2, false, MB, NB>(e, acc, m0, q, pix_off); break;
+        case 6: conv_epilogue_act<3, false, MB, NB>(e, acc, m0, q, pix_off); break;
+        case 8: conv_epilogue_act<4, false, MB, NB>(e, acc, m0, q, pix_off); break;
+        case 10: conv_epilogue_act<5, false, MB, NB>(e, acc, m0, q, pix_off); break;
+        default: break;   // add with a gate activation: rejected on the host (itermvs_conv2d)
+    }
+}
+
+}  // namespace itermvs

@@ -19,10 +19,9 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "conv_epilogue.hpp"
 
 namespace itermvs {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct MfmaArgs {
     const float* in;
@@ -39,16 +38,15 @@ struct MfmaArgs {
     int ksize, stride, pad, dil, act;
 };
 
-__device__ __forceinline__ float mfma_epilogue(float v, int act, float add, float a1, float a2) {
-    v += add;
-    switch (act) {
-        case 1: return fmaxf(v, 0.0f);
-        case 2: return sigmoidf_(v);
-        case 3: return tanhf(v);
-        case 4: return sigmoidf_(v) * a1;                  // r * h            (module.py:63-64)
-        case 5: return (1.0f - a2) * a1 + a2 * tanhf(v);   // (1-z) h + z q    (module.py:64-65)
-        default: return v;
-    }
+__device__ __forceinline__ EpilogueArgs make_epilogue(const MfmaArgs& a, int n, int P) {
+    EpilogueArgs e;
+    e.out = a.out + (int64_t)n * a.out_sn;
+    e.out2 = a.out2 ? a.out2 + (int64_t)n * a.Cout * P : nullptr;
+    e.add = a.add ? a.add + (int64_t)n * a.add_sn : nullptr;
+    e.aux1 = a.aux1 ? a.aux1 + (int64_t)n * a.aux1_sn : nullptr;
+    e.aux2 = a.aux2 ? a.aux2 + (int64_t)n * a.aux2_sn : nullptr;
+    e.Cout = a.Cout; e.P = P; e.act = a.act;
+    return e;
 }
 
 // Operand fetch: every load is a BUFFER load through a wave-uniform 128-bit descriptor --
@@ -107,10 +105,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const MfmaArgs a) {
         ox[nb] = pc - oy[nb] * a.Wout;
     }
     f32x4 acc[MB][NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    conv_bias_init<MB, NB>(acc, a.bias[seg], a.Cout, m0, kslot);
 
     const uint32_t plane = (uint32_t)(a.Hin * a.Win);
     // descriptors from wave-uniform values only (kernel arguments, blockIdx)
@@ -149,27 +144,10 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const MfmaArgs a) {
         }
     }
     // D: col (pixel) = lane & 15, row (cout) = (lane >> 4) * 4 + r
-    const float* __restrict__ bias = a.bias[seg];
+    uint32_t pix_off[NB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = m0 + mb * 16 + kslot * 4 + r;
-            if (co >= a.Cout) continue;
-            const float bs = bias ? bias[co] : 0.0f;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                if (!pv[nb]) continue;
-                const int p = pbase + nb * 16 + l16;
-                const int64_t ch = (int64_t)co * P + p;
-                const float ad = a.add ? a.add[(int64_t)n * a.add_sn + ch] : 0.0f;
-                const float a1 = a.aux1 ? a.aux1[(int64_t)n * a.aux1_sn + ch] : 0.0f;
-                const float a2 = a.aux2 ? a.aux2[(int64_t)n * a.aux2_sn + ch] : 0.0f;
-                const float v = mfma_epilogue(acc[mb][nb][r] + bs, a.act, ad, a1, a2);
-                a.out[(int64_t)n * a.out_sn + ch] = v;
-                if (a.out2) a.out2[((int64_t)n * a.Cout) * P + ch] = v;
-            }
-        }
+    for (int nb = 0; nb < NB; ++nb) pix_off[nb] = pv[nb] ? (uint32_t)(pbase + nb * 16 + l16) * 4u : kEpiOob;
+    conv_epilogue<MB, NB>(make_epilogue(a, n, P), acc, m0, kslot, pix_off);
 }
 
 // Split-K variant for layers with too few output tiles to fill the chip (ConvGRU gates, heads, the
@@ -192,8 +170,7 @@ __global__ void __launch_bounds__(256) conv_mfma_splitk_kernel(const MfmaArgs a)
     const int pc = pv ? p : 0;
     const int oy = pc / a.Wout, ox = pc - oy * a.Wout;
     f32x4 acc[MB][1];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[mb][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    conv_bias_init<MB, 1>(acc, wave == 0 ? a.bias[seg] : nullptr, a.Cout, m0, kslot);   // the bias enters the sum once
     const uint32_t plane = (uint32_t)(a.Hin * a.Win);
     const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.in + (int64_t)n * a.in_sn), 0, (int)(a.Cin * plane * 4u), 0x00020000);
@@ -239,23 +216,14 @@ __global__ void __launch_bounds__(256) conv_mfma_splitk_kernel(const MfmaArgs a)
             for (int r = 0; r < 4; ++r) red[wave - 1][mb][r][lane] = acc[mb][0][r];
     }
     __syncthreads();
-    if (wave != 0 || !pv) return;
-    const float* __restrict__ bias = a.bias[seg];
+    if (wave != 0) return;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = m0 + mb * 16 + kslot * 4 + r;
-            if (co >= a.Cout) continue;
-            const float sum = ((acc[mb][0][r] + red[0][mb][r][lane]) + red[1][mb][r][lane]) + red[2][mb][r][lane];
-            const int64_t ch = (int64_t)co * P + p;
-            const float ad = a.add ? a.add[(int64_t)n * a.add_sn + ch] : 0.0f;
-            const float a1 = a.aux1 ? a.aux1[(int64_t)n * a.aux1_sn + ch] : 0.0f;
-            const float a2 = a.aux2 ? a.aux2[(int64_t)n * a.aux2_sn + ch] : 0.0f;
-            const float v = mfma_epilogue(sum + (bias ? bias[co] : 0.0f), a.act, ad, a1, a2);
-            a.out[(int64_t)n * a.out_sn + ch] = v;
-            if (a.out2) a.out2[((int64_t)n * a.Cout) * P + ch] = v;
-        }
+        for (int r = 0; r < 4; ++r)
+            acc[mb][0][r] = ((acc[mb][0][r] + red[0][mb][r][lane]) + red[1][mb][r][lane]) + red[2][mb][r][lane];
+    const uint32_t pix_off[1] = {pv ? (uint32_t)p * 4u : kEpiOob};
+    conv_epilogue<MB, 1>(make_epilogue(a, n, P), acc, m0, kslot, pix_off);
 }
 
 }  // namespace itermvs

@@ -7,6 +7,7 @@ CPU path: a CPU tensor raises ``RuntimeError``.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -318,8 +319,16 @@ def pack_conv_weight(w: Tensor, transposed: bool = False) -> Tensor:
     return (w.permute(0, 2, 3, 1) if transposed else w.permute(1, 2, 3, 0)).contiguous()
 
 
+def tile_k_split(cin: int) -> int:
+    """S of the LDS-tiled kernel (conv_tile.hip): consecutive channels held by one k-slot of a chunk."""
+    return 1 if cin <= 4 else 2 if cin <= 8 else 4
+
+
 class MfmaWeight:
-    """Matrix-core format of a Conv2d weight [Cout,Cin,k,k]: [k*k, Cin_pad4, Cout_pad16], zero padded."""
+    """Matrix-core formats of a Conv2d weight [Cout,Cin,k,k], zero padded:
+    ``data`` (weight_format 1, conv_mfma.hip): [k*k, Cin_pad4, Cout_pad16];
+    ``tile`` (weight_format 2, conv_tile.hip, 3x3 only): [9, chunks, S, 4, Cout_pad16] whose element
+    (tap, ch, s, q, co) is the weight of input channel ch*4*S + q*S + s."""
 
     def __init__(self, w: Tensor):
         cout, cin, k, _ = w.shape
@@ -327,6 +336,22 @@ class MfmaWeight:
         packed = torch.zeros((k * k, cin_p, cout_p), device=w.device, dtype=torch.float32)
         packed[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
         self.data, self.cin, self.cout, self.ksize = packed.contiguous(), cin, cout, k
+        self.tile = None
+        if k == 3:
+            s = tile_k_split(cin)
+            nch = (cin + 4 * s - 1) // (4 * s)
+            t = torch.zeros((9, nch * 4 * s, cout_p), device=w.device, dtype=torch.float32)
+            t[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(9, cin, cout)
+            self.tile = t.reshape(9, nch, 4, s, cout_p).permute(0, 1, 3, 2, 4).contiguous()
+
+
+_TILE_SHAPES = {(1, 1), (2, 1), (1, 2)}   # (stride, dilation) instantiated in conv_tile.hip
+
+
+def _use_tile(wt: "MfmaWeight", stride: int, dilation: int) -> bool:
+    if wt.tile is None or os.environ.get("ITERMVS_CONV_TILE", "1") == "0":
+        return False
+    return (stride, dilation) in _TILE_SHAPES and (wt.cin > 4 or (stride, dilation) == (1, 1))
 
 
 def _planes(t: Tensor, name: str):
@@ -347,14 +372,15 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     weights = list(weight) if isinstance(weight, (list, tuple)) else [weight]
     biases = list(bias) if isinstance(bias, (list, tuple)) else [bias] * len(weights)
     n, cin, hin, win = x.shape
-    mfma = isinstance(weights[0], MfmaWeight)
+    mfma, tiled = isinstance(weights[0], MfmaWeight), False
     if mfma:
         if transposed:
             raise RuntimeError("conv2d: transposed convolutions use the VALU weight format")
         if any(wt.cin != cin or wt.ksize != ksize for wt in weights):
             raise RuntimeError("conv2d: MfmaWeight does not match the input channels / kernel size")
         cout = weights[0].cout
-        weights = [wt.data for wt in weights]
+        tiled = all(_use_tile(wt, stride, dilation) for wt in weights)
+        weights = [wt.tile if tiled else wt.data for wt in weights]
     else:
         cout = weights[0].shape[3]
     if transposed:
@@ -391,7 +417,7 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     p.N, p.Cin, p.Hin, p.Win, p.Cout = n, cin, hin, win, cout
     p.ksize, p.stride, p.pad, p.dilation = ksize, stride, pad, dilation
     p.transposed, p.act = int(transposed), ACT[act]
-    p.weight_format = 1 if mfma else 0
+    p.weight_format = (2 if tiled else 1) if mfma else 0
     if CONV_FLOP_COUNTER["enabled"]:
         CONV_FLOP_COUNTER["flops"] += 2.0 * n * hout * wout * cout * cin * ksize * ksize / (4.0 if transposed else 1.0)
         CONV_FLOP_COUNTER["launches"] += 1

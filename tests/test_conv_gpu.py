@@ -34,11 +34,32 @@ CASES = [
     (64, 256, 1, 1, 0, 1, 16, 20, 1),
     (64, 144, 1, 1, 0, 1, 16, 20, 1),   # up-sampling logits
     (16, 1, 1, 1, 0, 1, 8, 10, 64),     # PixelViewWeight 1x1
+    # more tiles than resident workgroups: the persistent tile loop, interior fast path, weight reuse
+    (8, 16, 3, 1, 1, 1, 256, 320, 3),
+    (16, 32, 3, 2, 1, 1, 256, 320, 4),
+    (43, 32, 3, 1, 2, 2, 128, 160, 2),  # three channel chunks per tile
 ]
 
 
 def packed(wt, fmt):
     return ops().MfmaWeight(wt) if fmt == "mfma" else ops().pack_conv_weight(wt)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("act", ["none", "relu", "sigmoid", "tanh"])
+def test_conv_without_residual_or_bias(case, act):
+    """the epilogue variants without the optional operands (separate template instances in the kernels)"""
+    cin, cout, k, stride, pad, dil, h, w, n = case
+    gen = torch.Generator().manual_seed(cin * 100 + cout + 7)
+    x = torch.randn((n, cin, h, w), generator=gen).to(DEV)
+    wt = (torch.randn((cout, cin, k, k), generator=gen) / (cin * k * k) ** 0.5).to(DEV)
+    want = F.conv2d(x, wt, None, stride=stride, padding=pad, dilation=dil)
+    want = {"none": lambda t: t, "relu": F.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](want)
+    dense = torch.empty_like(want)
+    got = ops().conv2d(x, packed(wt, "mfma"), None, ksize=k, stride=stride, pad=pad, dilation=dil, act=act, out2=dense)
+    # sigmoid / tanh compress the value range the error is measured against
+    assert rel_err(got, want) <= (2e-6 if act in ("none", "relu") else 2e-5)
+    assert torch.equal(dense, got)
 
 
 @pytest.mark.parametrize("case", CASES)

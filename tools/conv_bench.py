@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer micro-benchmark of itermvs_conv2d on the layer shapes of a cfg-1 depth map (GPU box only).
-The kernel variant is chosen by the environment (ITERMVS_CONV_MFMA=lds|gather, ITERMVS_CONV_SPLITK=0|1)."""
+The kernel variant is chosen by the environment (ITERMVS_CONV_TILE=0|1, ITERMVS_CONV_SPLITK=0|1);
+an optional argument filters the layers by name (for rocprofv3 --pmc runs)."""
 import os
 import sys
 
@@ -39,9 +40,12 @@ def main():
     dev = torch.device("cuda")
     gen = torch.Generator().manual_seed(0)
     total = 0.0
-    print(f"variant: ITERMVS_CONV_MFMA={os.environ.get('ITERMVS_CONV_MFMA', 'gather')} "
+    print(f"variant: ITERMVS_CONV_TILE={os.environ.get('ITERMVS_CONV_TILE', '1')} "
           f"SPLITK={os.environ.get('ITERMVS_CONV_SPLITK', '1')}")
+    only = sys.argv[1] if len(sys.argv) > 1 else ""     # substring filter on the layer name
     for name, n, cin, cout, h, w, k, stride, dil, count in LAYERS:
+        if only not in name:
+            continue
         x = torch.randn((n, cin, h, w), generator=gen).to(dev)
         wt = ops.MfmaWeight((torch.randn((cout, cin, k, k), generator=gen) / (cin * k * k) ** 0.5).to(dev))
         pad = dil * (k // 2)
