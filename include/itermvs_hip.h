@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ITERMVS_ABI_VERSION 3
+#define ITERMVS_ABI_VERSION 4
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -226,11 +226,17 @@ int itermvs_bilinear_up(const float* x, int32_t M, int32_t H, int32_t W, int32_t
  *   weight_format 0: [Cin][k][k][Cout] (conv weight.permute(1,2,3,0); transposed-conv
  *     weight.permute(0,2,3,1)) -- VALU kernels, required for `transposed`;
  *   weight_format 1: [k*k][Cin_pad4][Cout_pad16], zero padded -- matrix-core (MFMA f32 16x16x4)
- *     implicit-GEMM kernel, the fast path for every regular convolution.  Up to three weight sets
+ *     implicit-GEMM kernel (any 1x1 / 3x3 shape);
+ *   weight_format 2: [9][chunks][4][Cout_pad16][S] with element (tap, ch, q, co, s) = weight of input
+ *     channel ch*4*S + q*S + s (S = 1 / 2 / 4 for Cin <= 4 / <= 8 / larger), zero padded -- the LDS-tiled
+ *     persistent matrix-core kernel for 3x3, stride 1|2, dilation 1|2.  Up to three weight sets
  * per launch: batch items [0,seg_end[0]) use set 0, [seg_end[0],seg_end[1]) set 1, the rest set 2
  * (the three CorrNets of one iteration in one launch).
  * Epilogue `act`: 0 v+add | 1 relu(v+add) | 2 sigmoid | 3 tanh | 4 sigmoid(v)*aux1 (r*h) |
  *                 5 (1-aux2)*aux1 + aux2*tanh(v)  (GRU state update; aux1 = h, aux2 = z).
+ * `add_mode` 0: `add` has the output's shape; 1: `add` is [N,Cout,Hout/2,Wout/2] and its x2 bilinear
+ *   up-sampling (F.interpolate(scale_factor=2, mode='bilinear'), models/net.py:46,49) is evaluated
+ *   in the epilogue (matrix-core formats only, Hout and Wout even).
  * `out2` (optional) receives a second, contiguous [N,Cout,H,W] copy of the result.
  * ------------------------------------------------------------------------------------------ */
 typedef struct itermvs_conv_params {
@@ -250,6 +256,7 @@ typedef struct itermvs_conv_params {
     int32_t transposed;                        /* 1: ConvTranspose2d(3, stride 2, pad 1, output_padding 1) */
     int32_t act;
     int32_t weight_format;
+    int32_t add_mode;
 } itermvs_conv_params;
 
 int itermvs_conv2d(const itermvs_conv_params* p, void* stream);

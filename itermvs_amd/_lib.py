@@ -13,7 +13,7 @@ from typing import Optional
 MAX_SRC = 16
 MAX_HYP = 8
 GROUPS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitermvs_hip.so")
@@ -63,7 +63,7 @@ class ConvParams(C.Structure):
                 ("weight", C.c_void_p * 3), ("bias", C.c_void_p * 3), ("seg_end", C.c_int32 * 3), ("n_seg", C.c_int32),
                 ("N", C.c_int32), ("Cin", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cout", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dilation", C.c_int32),
-                ("transposed", C.c_int32), ("act", C.c_int32), ("weight_format", C.c_int32)]
+                ("transposed", C.c_int32), ("act", C.c_int32), ("weight_format", C.c_int32), ("add_mode", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/itermvs_hip.h declares

@@ -203,6 +203,8 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     ITERMVS_RETURN_IF((p->act == 4 || p->act == 5) && !p->aux1, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->act == 5 && !p->aux2, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->act >= 2 && p->add, ITERMVS_ERR_DIMS);   // residual add only with none / relu
+    ITERMVS_RETURN_IF(p->add_mode < 0 || p->add_mode > 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(p->add_mode == 1 && (!p->add || p->weight_format == 0 || p->transposed || p->act != 0), ITERMVS_ERR_DIMS);
     ConvArgs a;
     a.in = p->in; a.out = p->out; a.out2 = p->out2; a.add = p->add; a.aux1 = p->aux1; a.aux2 = p->aux2;
     a.in_sn = p->in_sn; a.out_sn = p->out_sn; a.add_sn = p->add_sn; a.aux1_sn = p->aux1_sn; a.aux2_sn = p->aux2_sn;
@@ -238,6 +240,7 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     a.Hout = (p->Hin + 2 * p->pad - span) / p->stride + 1;
     a.Wout = (p->Win + 2 * p->pad - span) / p->stride + 1;
     ITERMVS_RETURN_IF(a.Hout < 1 || a.Wout < 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(p->add_mode == 1 && ((a.Hout | a.Wout) & 1), ITERMVS_ERR_DIMS);
     if (p->weight_format == 2) {   // LDS-tiled 3x3 kernels; the packed layout fits no other kernel
         const int rc = itermvs_conv2d_tile(p, a.Hout, a.Wout, (hipStream_t)stream);
         return rc == 1 ? ITERMVS_ERR_DIMS : rc;

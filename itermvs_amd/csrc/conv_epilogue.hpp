@@ -38,6 +38,7 @@ struct EpilogueArgs {
     const float* aux1;
     const float* aux2;
     int Cout, P, act;
+    int add_mode, Hout, Wout;   // add_mode 1: `add` is the half-resolution tensor, up-sampled x2 (bilinear) here
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* p, uint32_t bytes) {
@@ -80,9 +81,9 @@ __device__ __forceinline__ void conv_bias_init(f32x4 (&acc)[MB][NB], const float
 // address arithmetic per element, and padded channels (>= Cout) land beyond the descriptor by themselves.
 // The activation is a template parameter (one uniform switch in conv_epilogue below): inside the element
 // loops the code is straight-line.
-template <int ACT, bool ADD, int MB, int NB>
+template <int ACT, int ADD, int MB, int NB>
 __device__ __forceinline__ void conv_epilogue_act(const EpilogueArgs& e, const f32x4 (&acc)[MB][NB], int m0, int q,
-                                                  const uint32_t (&pix_off)[NB]) {
+                                                  const uint32_t (&pix_off)[NB], const int (&py)[NB], const int (&px)[NB]) {
     const uint32_t plane_b = (uint32_t)e.P * 4u;
     const uint32_t bytes = (uint32_t)e.Cout * plane_b;
     const __amdgpu_buffer_rsrc_t ro = epi_rsrc(e.out, bytes);
@@ -96,12 +97,43 @@ __device__ __forceinline__ void conv_epilogue_act(const EpilogueArgs& e, const f
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ad[mb][r] = a1[mb][r] = a2[mb][r] = 0.0f;
-        if constexpr (ADD) {
+        if constexpr (ADD == 1) {
             const __amdgpu_buffer_rsrc_t rr = epi_rsrc(e.add, bytes);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ad[mb][r] = epi_load(rr, voff, s0 + (uint32_t)(mb * 16 + r) * plane_b);
+        }
+        if constexpr (ADD == 2) {
+            // F.interpolate(scale_factor=2, 'bilinear', align_corners=False) of the half-resolution tensor:
+            // same arithmetic as bilinear_up_kernel (update.hip), models/net.py:46,49
+            const int Hc = e.Hout >> 1, Wc = e.Wout >> 1;
+            const uint32_t cplane_b = (uint32_t)(Hc * Wc) * 4u;
+            const __amdgpu_buffer_rsrc_t rr = epi_rsrc(e.add, (uint32_t)e.Cout * cplane_b);
+            float sy = ((float)py[nb] + 0.5f) * 0.5f - 0.5f, sx = ((float)px[nb] + 0.5f) * 0.5f - 0.5f;
+            sy = sy < 0.0f ? 0.0f : sy;
+            sx = sx < 0.0f ? 0.0f : sx;
+            int y0 = (int)sy, x0 = (int)sx;
+            y0 = y0 > Hc - 1 ? Hc - 1 : y0;
+            x0 = x0 > Wc - 1 ? Wc - 1 : x0;
+            const int y1 = y0 + (y0 < Hc - 1 ? 1 : 0), x1 = x0 + (x0 < Wc - 1 ? 1 : 0);
+            const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+            const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+            const uint32_t lane_c = (uint32_t)(q * 4) * cplane_b;
+            const uint32_t o00 = (uint32_t)(y0 * Wc + x0) * 4u + lane_c, o01 = (uint32_t)(y0 * Wc + x1) * 4u + lane_c;
+            const uint32_t o10 = (uint32_t)(y1 * Wc + x0) * 4u + lane_c, o11 = (uint32_t)(y1 * Wc + x1) * 4u + lane_c;
+            const uint32_t sc0 = (uint32_t)m0 * cplane_b;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t so = sc0 + (uint32_t)(mb * 16 + r) * cplane_b;
+                    const float v00 = epi_load(rr, o00, so), v01 = epi_load(rr, o01, so);
+                    const float v10 = epi_load(rr, o10, so), v11 = epi_load(rr, o11, so);
+                    const float top = v00 * lx0 + v01 * lx1;
+                    const float bot = v10 * lx0 + v11 * lx1;
+                    ad[mb][r] = top * ly0 + bot * ly1;
+                }
         }
         if constexpr (ACT == 4 || ACT == 5) {
             const __amdgpu_buffer_rsrc_t rr = epi_rsrc(e.aux1, bytes);
@@ -121,7 +153,7 @@ __device__ __forceinline__ void conv_epilogue_act(const EpilogueArgs& e, const f
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float x = ADD ? acc[mb][nb][r] + ad[mb][r] : acc[mb][nb][r];
+                const float x = ADD != 0 ? acc[mb][nb][r] + ad[mb][r] : acc[mb][nb][r];
                 v[mb][r] = conv_activation<ACT>(x, a1[mb][r], a2[mb][r]);
                 epi_store(v[mb][r], ro, voff, s0 + (uint32_t)(mb * 16 + r) * plane_b);
             }
@@ -137,20 +169,22 @@ __device__ __forceinline__ void conv_epilogue_act(const EpilogueArgs& e, const f
 
 // The optional residual operand is a template parameter as well: a run-time `if (add)` around its loads
 // makes the compiler wait for vmcnt(0) in front of EVERY pixel slot -- i.e. for the previous slot's stores.
+// py / px: output coordinates of this lane's pixel per slot (only read by the bilinear residual).
 template <int MB, int NB>
 __device__ __forceinline__ void conv_epilogue(const EpilogueArgs& e, const f32x4 (&acc)[MB][NB], int m0, int q,
-                                              const uint32_t (&pix_off)[NB]) {
-    const int key = e.act * 2 + (e.add ? 1 : 0);
+                                              const uint32_t (&pix_off)[NB], const int (&py)[NB], const int (&px)[NB]) {
+    const int key = e.act * 3 + (e.add ? 1 + e.add_mode : 0);
     switch (key) {
-        case 0: conv_epilogue_act<0, false, MB, NB>(e, acc, m0, q, pix_off); break;
-        case 1: conv_epilogue_act<0, true, MB, NB>(e, acc, m0, q, pix_off); break;
-        case 2: conv_epilogue_act<1, false, MB, NB>(e, acc, m0, q, pix_off); break;
-        case 3: conv_epilogue_act<1, true, MB, NB>(e, acc, m0, q, pix_off); break;
-        case 4: conv_epilogue_act<2, false, MB, NB>(e, acc, m0, q, pix_off); break;
-        case 6: conv_epilogue_act<3, false, MB, NB>(e, acc, m0, q, pix_off); break;
-        case 8: conv_epilogue_act<4, false, MB, NB>(e, acc, m0, q, pix_off); break;
-        case 10: conv_epilogue_act<5, false, MB, NB>(e, acc, m0, q, pix_off); break;
-        default: break;   // add with a gate activation: rejected on the host (itermvs_conv2d)
+        case 0: conv_epilogue_act<0, 0, MB, NB>(e, acc, m0, q, pix_off, py, px); break;
+        case 1: conv_epilogue_act<0, 1, MB, NB>(e, acc, m0, q, pix_off, py, px); break;
+        case 2: conv_epilogue_act<0, 2, MB, NB>(e, acc, m0, q, pix_off, py, px); break;
+        case 3: conv_epilogue_act<1, 0, MB, NB>(e, acc, m0, q, pix_off, py, px); break;
+        case 4: conv_epilogue_act<1, 1, MB, NB>(e, acc, m0, q, pix_off, py, px); break;
+        case 6: conv_epilogue_act<2, 0, MB, NB>(e, acc, m0, q, pix_off, py, px); break;
+        case 9: conv_epilogue_act<3, 0, MB, NB>(e, acc, m0, q, pix_off, py, px); break;
+        case 12: conv_epilogue_act<4, 0, MB, NB>(e, acc, m0, q, pix_off, py, px); break;
+        case 15: conv_epilogue_act<5, 0, MB, NB>(e, acc, m0, q, pix_off, py, px); break;
+        default: break;   // other combinations are rejected on the host (itermvs_conv2d)
     }
 }
 

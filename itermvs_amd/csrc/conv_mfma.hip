@@ -35,7 +35,7 @@ struct MfmaArgs {
     const float* bias[3];
     int seg_end[3];
     int N, Cin, CinPad, Hin, Win, Cout, CoutPad, Hout, Wout;
-    int ksize, stride, pad, dil, act;
+    int ksize, stride, pad, dil, act, add_mode;
 };
 
 __device__ __forceinline__ EpilogueArgs make_epilogue(const MfmaArgs& a, int n, int P) {
@@ -46,6 +46,7 @@ __device__ __forceinline__ EpilogueArgs make_epilogue(const MfmaArgs& a, int n, 
     e.aux1 = a.aux1 ? a.aux1 + (int64_t)n * a.aux1_sn : nullptr;
     e.aux2 = a.aux2 ? a.aux2 + (int64_t)n * a.aux2_sn : nullptr;
     e.Cout = a.Cout; e.P = P; e.act = a.act;
+    e.add_mode = a.add_mode; e.Hout = a.Hout; e.Wout = a.Wout;
     return e;
 }
 
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const MfmaArgs a) {
     uint32_t pix_off[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) pix_off[nb] = pv[nb] ? (uint32_t)(pbase + nb * 16 + l16) * 4u : kEpiOob;
-    conv_epilogue<MB, NB>(make_epilogue(a, n, P), acc, m0, kslot, pix_off);
+    conv_epilogue<MB, NB>(make_epilogue(a, n, P), acc, m0, kslot, pix_off, oy, ox);
 }
 
 // Split-K variant for layers with too few output tiles to fill the chip (ConvGRU gates, heads, the
@@ -223,7 +224,8 @@ __global__ void __launch_bounds__(256) conv_mfma_splitk_kernel(const MfmaArgs a)
         for (int r = 0; r < 4; ++r)
             acc[mb][0][r] = ((acc[mb][0][r] + red[0][mb][r][lane]) + red[1][mb][r][lane]) + red[2][mb][r][lane];
     const uint32_t pix_off[1] = {pv ? (uint32_t)p * 4u : kEpiOob};
-    conv_epilogue<MB, 1>(make_epilogue(a, n, P), acc, m0, kslot, pix_off);
+    const int py[1] = {oy}, px[1] = {ox};
+    conv_epilogue<MB, 1>(make_epilogue(a, n, P), acc, m0, kslot, pix_off, py, px);
 }
 
 }  // namespace itermvs
@@ -244,6 +246,7 @@ int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStr
     a.N = p->N; a.Cin = p->Cin; a.CinPad = (p->Cin + 3) / 4 * 4; a.Hin = p->Hin; a.Win = p->Win;
     a.Cout = p->Cout; a.CoutPad = (p->Cout + 15) / 16 * 16; a.Hout = hout; a.Wout = wout;
     a.ksize = p->ksize; a.stride = p->stride; a.pad = p->pad; a.dil = p->dilation; a.act = p->act;
+    a.add_mode = p->add_mode;
     const int P = hout * wout;
     const int mt = a.CoutPad / 16;
     // largest register blocking (MB x NB tiles of 16 channels x 16 pixels per wave) that still yields

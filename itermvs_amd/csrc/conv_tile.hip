@@ -10,13 +10,18 @@
 //
 // K ordering inside a chunk: k-slot q (= lane >> 4) of MFMA step s holds channel  c0 + q*S + s, so the
 // S values a lane needs across the S steps of a chunk are CONTIGUOUS:
-//   * LDS tile layout  [q][pixel][S]            -> one ds_read_b32/b64/b128 per (tap, 16-pixel segment);
-//   * weight layout    [tap][chunk][s][q][cout] -> S coalesced buffer_load_dword per (tap, 16 channels);
+//   * LDS tile layout    [q][pixel][S]          -> one ds_read_b32/b64/b128 per (tap, 16-pixel segment);
+//   * LDS weight layout  [chunk][tap][q][co][S] -> one ds_read per (tap, 16 output channels);
 // and every LDS address is `lane base + compile-time offset` (tile geometry, stride and dilation are
-// template parameters), every weight address `lane base + SGPR offset`: no vector address math in the
-// k-loop.  S = 1 / 2 / 4 for Cin <= 4 / <= 8 / larger (3, 8 and 16..64 input channels on the path).
-// The q-plane stride is padded so that a wave's read hits each bank once (MI355X_MICROARCH.md, LDS:
-// b128 -> 64 banks, 16-lane groups mixing two q's; b64 -> 64 banks / 32 lanes; b32 -> 32 banks / 32 lanes).
+// template parameters): no vector address math in the k-loop.  S = 1 / 2 / 4 for Cin <= 4 / <= 8 / larger
+// (3, 8 and 16..64 input channels on the path).  The q-plane stride is padded so that a wave's read hits
+// each bank once (MI355X_MICROARCH.md, LDS: b128 -> 64 banks, 16-lane groups mixing two q's; b64 -> 64
+// banks / 32 lanes; b32 -> 32 banks / 32 lanes).
+//
+// The weights of the workgroup's channel block (all chunks, all taps: Cin_pad * 576 * MB bytes) are copied
+// to LDS ONCE per workgroup and shared by its four waves.  (Held per wave in registers they cost
+// 36 * MB * chunks VGPRs and, worse, 27 KB of L1 -> register traffic per wave: on the ConvGRU gate conv the
+// 108 weight loads of a wave took 9.4k cycles to issue, twice its MFMA work.)
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -34,11 +39,11 @@ struct TileArgs {
     const float* aux1;
     const float* aux2;
     int64_t in_sn, out_sn, add_sn, aux1_sn, aux2_sn;
-    const float* weight[3];   // packed [9][nchunk][S][4][CoutPad]
+    const float* weight[3];   // packed [9][nchunk][4][CoutPad][S]
     const float* bias[3];
     int seg_end[3];
     int N, Cin, Hin, Win, Cout, CoutPad, Hout, Wout;
-    int pad, act, nchunk, tiles_x, tiles_y, ncb, total;
+    int pad, act, add_mode, nchunk, nstage, tiles_x, tiles_y, ncb, total;
     uint32_t rcp_tiles_x, rcp_tiles_y;   // floor(2^32 / d) + 1
 };
 
@@ -60,18 +65,6 @@ template <int S> struct Vec;
 template <> struct Vec<1> { float v[1]; };
 template <> struct Vec<2> { float v[2]; };
 template <> struct Vec<4> { float v[4]; };
-
-// weights of one (tap, chunk, 16 output channels): S dword loads, each a fully coalesced 256-byte row
-// [q][cout] (this compiler lowers the b64/b128 raw-buffer builtins to a single dword load, so the wide
-// forms are not used)
-template <int S>
-__device__ __forceinline__ Vec<S> wload(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, uint32_t sstep_b) {
-    Vec<S> o;
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-        o.v[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff + s * sstep_b, 0));
-    return o;
-}
 
 template <int S>
 __device__ __forceinline__ Vec<S> lds_read(const float* p) {
@@ -114,17 +107,48 @@ struct TileGeom {
     static_assert(NB % TWT == 0 || TWT % NB == 0, "a wave's segments must form whole rows or a row part");
 };
 
-template <int MB, int S, int STRIDE, int DIL, int TH, int TWT>
+template <int MB, int S, int STRIDE, int DIL, int TH, int TWT, int CPS>
 __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
     using G = TileGeom<S, STRIDE, DIL, TH, TWT>;
     constexpr int NB = G::NB;
-    __shared__ __attribute__((aligned(16))) float tile[4 * G::PL];
+    constexpr int CH_FLOATS = 4 * G::PL;             // one staged chunk (4*S input channels of the tile + halo)
+    constexpr int WROW = 16 * MB * S;                // floats of one weight row (tap, chunk, q): [16*MB co][S]
+    constexpr int WBLK = 4 * WROW;                   // floats per (chunk, tap)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* __restrict__ tile = smem;                                 // [CPS][4][PL]
+    float* __restrict__ wlds = smem + CPS * CH_FLOATS;               // [nchunk][9][4][16*MB][S]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l16 = lane & 15;
     const uint32_t plane = (uint32_t)(a.Hin * a.Win);
-    const int m0 = blockIdx.y * (MB * 16);          // the workgroup's channel block is fixed: weights and bias
-                                                    // are fetched once and stay in registers across its tiles
+    const int m0 = blockIdx.y * (MB * 16);          // the workgroup's channel block is fixed
+    // copy of the channel block's weights for weight set `seg`: global rows [tap][chunk][q] of CoutPad*S
+    // floats -> LDS rows [chunk][tap][q] of 16*MB*S floats (contiguous 16-byte pieces)
+    auto fill_weights = [&](int seg) {
+        constexpr int VPR = WROW / 4;                // float4 per row
+        const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.weight[seg] + m0 * S);
+        const int rows = a.nchunk * 36;
+        const int col = tid % VPR;
+        constexpr int RPP = 256 / VPR;               // rows per pass of the workgroup
+        // four passes of loads in flight before their LDS stores (one L2 round trip per four passes)
+        for (int r0 = tid / VPR; r0 < rows; r0 += 4 * RPP) {
+            f32x4 t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + i * RPP;
+                const int cidx = r / 36, rem = r - cidx * 36;
+                const int tap = rem >> 2, qq = rem & 3;
+                const int64_t g = (int64_t)((tap * a.nchunk + cidx) * 4 + qq) * (a.CoutPad * S / 4) + col;
+                if (r < rows) t[i] = src[g];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + i * RPP;
+                if (r < rows) reinterpret_cast<f32x4*>(wlds)[r * VPR + col] = t[i];
+            }
+        }
+    };
+
     // work item w -> (tile column, tile row, batch item)
     struct Work { int n, oy0, ox0; };
     auto decode = [&](int w) {
@@ -174,42 +198,40 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
             }
         }
     };
-    Vec<S> stage[G::ITEMS];
+    // A STAGE is CPS consecutive chunks (CPS*4*S input channels) of one tile: staged, synchronised and
+    // multiplied together.  CPS > 1 shortens the per-tile chain of barriers and weight fetches for the
+    // layers with few, deep tiles (ConvGRU: 43 channels = 3 chunks, 320 tiles of 64 pixels).
+    Vec<S> stage[CPS][G::ITEMS];
     const uint32_t chunk_b = 4u * S * plane * 4u;   // bytes between chunks in the input planes
-    // the ITEMS*S dword loads of one stage, split into nine parts: part t is issued inside tap t of the
-    // previous stage's MFMA loop.  (Issued in one burst the loads fill the CU's vector-memory queue and the
-    // wave sits in the issue of the 24 loads for 2-5k cycles -- as long as the whole MFMA phase -- before
-    // its first MFMA.)
-    constexpr int kLoads = G::ITEMS * S;
+    // the CPS*ITEMS*S dword loads of one stage, split into 9*CPS parts: part t is issued inside tap t of
+    // the previous stage's MFMA loop.  (Issued in one burst the loads fill the CU's vector-memory queue and
+    // the wave sits in the issue of its 24 loads for 2-5k cycles -- as long as the whole MFMA phase.)
+    constexpr int kLoads = CPS * G::ITEMS * S;
+    constexpr int kParts = 9 * CPS;
     auto fetch_part = [&](uint32_t soff, int part) {
 #pragma unroll
         for (int e = 0; e < kLoads; ++e)
-            if (e * 9 / kLoads == part) {
-                const int j = e / S, s2 = e % S;
-                stage[j].v[s2] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(ir, goff[j], soff + s2 * plane * 4u, 0));
+            if (e * kParts / kLoads == part) {
+                const int c = e / (G::ITEMS * S), j = (e / S) % G::ITEMS, s2 = e % S;
+                stage[c][j].v[s2] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(ir, goff[j], soff + c * chunk_b + s2 * plane * 4u, 0));
             }
     };
-    auto fetch = [&](int ch) {
+    auto fetch = [&](uint32_t soff) {
 #pragma unroll
-        for (int part = 0; part < 9; ++part) fetch_part(ch * chunk_b, part);
+        for (int part = 0; part < kParts; ++part) fetch_part(soff, part);
     };
 
     // this wave's segments: id = wave * NB + nb -> (row, column block) of the output tile
     const int seg0 = wave * NB;
     const int row0 = seg0 / TWT, col0 = seg0 - row0 * TWT;          // NB >= TWT: col0 == 0
     const float* __restrict__ bbase = tile + q * G::PL + ((row0 * STRIDE) * G::IN_W + (col0 * 16 + l16) * STRIDE) * S;
-    const uint32_t wv = (uint32_t)(q * a.CoutPad + l16) * 4u;
-    const uint32_t wstep_b = 4u * a.CoutPad * 4u;                  // bytes per MFMA step ([q][cout] row block)
-    const uint32_t wchunk_b = S * wstep_b;                          // bytes per (tap, chunk) of the packed weights
+    const float* __restrict__ abase = wlds + (q * 16 * MB + l16) * S;
     const int P = a.Hout * a.Wout;
 
     // Persistent workgroups: the grid is about two workgroups per CU and each walks the tile list with
-    // stride gridDim.x.  The next (tile, chunk) is fetched into registers while the matrix cores work on
-    // the current one.  vmcnt retires in order, so this chunk's weights are requested BEFORE the prefetch
-    // (the MFMAs then wait only for the older weight loads); with a single chunk (Cin <= 16) the weights
-    // are loaded once per workgroup.
-    Vec<S> av[9][MB];
+    // stride gridDim.x.  The next stage (chunks of this tile, or the first ones of the next tile) is fetched
+    // into registers while the matrix cores work on the current one.
     int w = blockIdx.x;
 #ifdef ITERMVS_TILE_TRACE
     int trace_tile = 0;
@@ -220,34 +242,31 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
     fetch(0);
     while (true) {
         const int seg = (cur.n >= a.seg_end[0]) + (cur.n >= a.seg_end[1]);
-        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.weight[seg] + m0), 0, (int)(9u * a.nchunk * S * wstep_b), 0x00020000);
         f32x4 acc[MB][NB];
         conv_bias_init<MB, NB>(acc, a.bias[seg], a.Cout, m0, q);
         const int wn = w + gridDim.x;
         Work nxt = cur;
-        for (int ch = 0; ch < a.nchunk; ++ch) {
+        for (int st = 0; st < a.nstage; ++st) {
             TILE_STAMP(0);
             __syncthreads();                        // the previous stage's LDS reads are done
-#pragma unroll
-            for (int j = 0; j < G::ITEMS; ++j)
-                if (j < G::ITEMS - 1 || tid + j * 256 < 4 * G::IN_PX) lds_write<S>(tile + loff[j], stage[j]);
-            __syncthreads();
-            TILE_STAMP(1);
-            if (a.nchunk > 1 || seg != wseg) {
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-                        av[tap][mb] = wload<S>(wr, wv + mb * 64, (uint32_t)(tap * a.nchunk + ch) * wchunk_b, wstep_b);
+            if (seg != wseg) {                      // first tile, or a batch item of another weight set
+                fill_weights(seg);
                 wseg = seg;
             }
+#pragma unroll
+            for (int c = 0; c < CPS; ++c)
+#pragma unroll
+                for (int j = 0; j < G::ITEMS; ++j)
+                    if (j < G::ITEMS - 1 || tid + j * 256 < 4 * G::IN_PX) lds_write<S>(tile + c * CH_FLOATS + loff[j], stage[c][j]);
+            __syncthreads();
+            TILE_STAMP(1);
+            const float* __restrict__ ast = abase + st * (CPS * 9 * WBLK);
             __builtin_amdgcn_sched_barrier(0);
-            // the next stage: the following chunk of this tile, or chunk 0 of the workgroup's next tile
+            // the next stage: the following chunks of this tile, or the first ones of the workgroup's next tile
             bool prefetch = true;
             uint32_t pf_soff = 0;
-            if (ch + 1 < a.nchunk) {
-                pf_soff = (uint32_t)(ch + 1) * chunk_b;
+            if (st + 1 < a.nstage) {
+                pf_soff = (uint32_t)((st + 1) * CPS) * chunk_b;
             } else if (wn < a.total) {
                 nxt = decode(wn);
                 setup(nxt);
@@ -255,23 +274,33 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
                 prefetch = false;
             }
             TILE_STAMP(2);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
+            // operands of step u+1 are read from LDS before the MFMAs of step u (two register sets): the
+            // LDS latency hides behind MB*NB*S MFMAs instead of stalling every tap
+            Vec<S> av[2][MB], bv[2][NB];
+            auto read_operands = [&](int u, int set) {
+                const int c = u / 9, tap = u % 9;
                 const int ky = tap / 3, kx = tap - ky * 3;
-                Vec<S> bv[NB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) av[set][mb] = lds_read<S>(ast + (c * 9 + tap) * WBLK + mb * 16 * S);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const int r = (nb / TWT), c = nb % TWT;     // relative to (row0, col0)
-                    bv[nb] = lds_read<S>(bbase + ((r * STRIDE + ky * DIL) * G::IN_W + c * 16 * STRIDE + kx * DIL) * S);
+                    const int r = (nb / TWT), cc = nb % TWT;     // relative to (row0, col0)
+                    bv[set][nb] = lds_read<S>(bbase + c * CH_FLOATS +
+                                              ((r * STRIDE + ky * DIL) * G::IN_W + cc * 16 * STRIDE + kx * DIL) * S);
                 }
-                if (prefetch) fetch_part(pf_soff, tap);
+            };
+            read_operands(0, 0);
 #pragma unroll
-                for (int s = 0; s < S; ++s)
+            for (int u = 0; u < kParts; ++u) {
+                if (u + 1 < kParts) read_operands(u + 1, (u + 1) & 1);
+                if (prefetch) fetch_part(pf_soff, u);
+#pragma unroll
+                for (int s2 = 0; s2 < S; ++s2)
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap][mb].v[s], bv[nb].v[s], acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u & 1][mb].v[s2], bv[u & 1][nb].v[s2], acc[mb][nb], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -279,10 +308,13 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
         TILE_STAMP(3);
         // D: col (pixel) = lane & 15, row (cout) = (lane >> 4) * 4 + r
         uint32_t pix_off[NB];
+        int py[NB], px[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int oy = cur.oy0 + row0 + nb / TWT, ox = cur.ox0 + (col0 + nb % TWT) * 16 + l16;
             pix_off[nb] = oy < a.Hout && ox < a.Wout ? (uint32_t)(oy * a.Wout + ox) * 4u : kEpiOob;
+            py[nb] = oy;
+            px[nb] = ox;
         }
         EpilogueArgs e;
         e.out = a.out + (int64_t)cur.n * a.out_sn;
@@ -291,7 +323,8 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
         e.aux1 = a.aux1 ? a.aux1 + (int64_t)cur.n * a.aux1_sn : nullptr;
         e.aux2 = a.aux2 ? a.aux2 + (int64_t)cur.n * a.aux2_sn : nullptr;
         e.Cout = a.Cout; e.P = P; e.act = a.act;
-        conv_epilogue<MB, NB>(e, acc, m0, q, pix_off);
+        e.add_mode = a.add_mode; e.Hout = a.Hout; e.Wout = a.Wout;
+        conv_epilogue<MB, NB>(e, acc, m0, q, pix_off, py, px);
         TILE_STAMP(4);
 #ifdef ITERMVS_TILE_TRACE
         ++trace_tile;
@@ -302,51 +335,69 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
     }
 }
 
-template <int MB, int S, int STRIDE, int DIL, int TH, int TWT>
-static void launch_tile(TileArgs& a, int mt, hipStream_t stream) {
+constexpr int kLdsBudget = 64 * 1024;    // per workgroup (default dynamic-LDS limit; two workgroups fit a CU)
+
+template <int MB, int S, int STRIDE, int DIL, int TH, int TWT, int CPS>
+static constexpr int tile_lds_bytes(int nchunk) {
+    return (CPS * 4 * TileGeom<S, STRIDE, DIL, TH, TWT>::PL + nchunk * 36 * 16 * MB * S) * 4;
+}
+
+template <int MB, int S, int STRIDE, int DIL, int TH, int TWT, int CPS>
+static int launch_tile(TileArgs& a, int mt, hipStream_t stream) {
     constexpr int TW = 16 * TWT;
+    const int lds = tile_lds_bytes<MB, S, STRIDE, DIL, TH, TWT, CPS>(a.nchunk);
+    if (lds > kLdsBudget) return 1;
     a.tiles_x = (a.Wout + TW - 1) / TW;
     a.tiles_y = (a.Hout + TH - 1) / TH;
     a.ncb = mt / MB;
+    a.nstage = (a.nchunk + CPS - 1) / CPS;
     a.total = a.N * a.tiles_y * a.tiles_x;
     a.rcp_tiles_x = (uint32_t)((1ull << 32) / (uint32_t)a.tiles_x + 1);   // (unused when the divisor is 1)
     a.rcp_tiles_y = (uint32_t)((1ull << 32) / (uint32_t)a.tiles_y + 1);
     // persistent grid: about ITERMVS_TILE_PERSIST (default 2) workgroups per CU in total, each walking the
-    // tile list of its channel block (one tile each when there are fewer tiles than that)
-    static const int per_cu = [] {
-        const char* e = getenv("ITERMVS_TILE_PERSIST");
-        int want = e ? atoi(e) : 2, fit = 1;
-        // never more workgroups than are resident at once: a persistent workgroup queued behind another
-        // one would serialise its whole tile list
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT>, 256, 0) != hipSuccess)
-            fit = 1;
-        if (want < 1) want = 2;
-        return want < fit ? want : (fit < 1 ? 1 : fit);
-    }();
-    int gx = 256 * per_cu / a.ncb;
+    // tile list of its channel block (one tile each when there are fewer tiles than that); never more than
+    // are resident at once -- a persistent workgroup queued behind another would serialise its tile list
+    static const int want = [] { const char* e = getenv("ITERMVS_TILE_PERSIST"); const int v = e ? atoi(e) : 2; return v < 1 ? 2 : v; }();
+    int fit = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS>, 256, lds) != hipSuccess || fit < 1)
+        fit = 1;
+    int gx = 256 * (want < fit ? want : fit) / a.ncb;
     if (gx > a.total) gx = a.total;
     if (gx < 1) gx = 1;
     const dim3 grid(gx, a.ncb);
-    hipLaunchKernelGGL((conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS>), grid, dim3(256), lds, stream, a);
+    return 0;
+}
+
+// chunks per stage: all chunks of a 2..4-chunk layer at once when input stages + weights fit the LDS budget
+template <int MB, int S, int STRIDE, int DIL, int TH, int TWT>
+static int launch_cps(TileArgs& a, int mt, hipStream_t stream) {
+    if constexpr (S == 4) {
+        if (a.nchunk == 3 && tile_lds_bytes<MB, S, STRIDE, DIL, TH, TWT, 3>(3) <= kLdsBudget)
+            return launch_tile<MB, S, STRIDE, DIL, TH, TWT, 3>(a, mt, stream);
+        if ((a.nchunk == 2 || a.nchunk == 4) && tile_lds_bytes<MB, S, STRIDE, DIL, TH, TWT, 2>(a.nchunk) <= kLdsBudget)
+            return launch_tile<MB, S, STRIDE, DIL, TH, TWT, 2>(a, mt, stream);
+    }
+    return launch_tile<MB, S, STRIDE, DIL, TH, TWT, 1>(a, mt, stream);
 }
 
 // tile shapes: big = 8 x 32 pixels (4 segments per wave), mid = 4 x 32 (2), small = 4 x 16 (1)
 template <int MB, int S, int STRIDE, int DIL>
-static void launch_shape(TileArgs& a, int mt, int shape, hipStream_t stream) {
+static int launch_shape(TileArgs& a, int mt, int shape, hipStream_t stream) {
     if (shape == 2) {
-        if constexpr (STRIDE == 1) launch_tile<MB, S, STRIDE, DIL, 8, 2>(a, mt, stream);
-        else launch_tile<MB, S, STRIDE, DIL, 4, 2>(a, mt, stream);     // stride 2: the 8x32 halo tile would not fit
+        if constexpr (STRIDE == 1) return launch_cps<MB, S, STRIDE, DIL, 8, 2>(a, mt, stream);
+        else return launch_cps<MB, S, STRIDE, DIL, 4, 2>(a, mt, stream);   // stride 2: the 8x32 halo tile is too big
     } else if (shape == 1) {
-        launch_tile<MB, S, STRIDE, DIL, 4, 2>(a, mt, stream);
-    } else {
-        launch_tile<MB, S, STRIDE, DIL, 4, 1>(a, mt, stream);
+        return launch_cps<MB, S, STRIDE, DIL, 4, 2>(a, mt, stream);
     }
+    return launch_cps<MB, S, STRIDE, DIL, 4, 1>(a, mt, stream);
 }
 
 template <int S, int STRIDE, int DIL>
-static void launch_mb(TileArgs& a, int mt, int mb, int shape, hipStream_t stream) {
-    if (mb == 2) launch_shape<2, S, STRIDE, DIL>(a, mt, shape, stream);
-    else launch_shape<1, S, STRIDE, DIL>(a, mt, shape, stream);
+static int launch_mb(TileArgs& a, int mt, int mb, int shape, hipStream_t stream) {
+    if (mb == 3) return launch_shape<3, S, STRIDE, DIL>(a, mt, shape, stream);
+    if (mb == 2) return launch_shape<2, S, STRIDE, DIL>(a, mt, shape, stream);
+    return launch_shape<1, S, STRIDE, DIL>(a, mt, shape, stream);
 }
 
 }  // namespace itermvs
@@ -371,7 +422,7 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
     }
     a.N = p->N; a.Cin = p->Cin; a.Hin = p->Hin; a.Win = p->Win;
     a.Cout = p->Cout; a.CoutPad = (p->Cout + 15) / 16 * 16; a.Hout = hout; a.Wout = wout;
-    a.pad = p->pad; a.act = p->act;
+    a.pad = p->pad; a.act = p->act; a.add_mode = p->add_mode;
     const int S = p->Cin <= 4 ? 1 : p->Cin <= 8 ? 2 : 4;
     a.nchunk = (p->Cin + 4 * S - 1) / (4 * S);
     const int mt = a.CoutPad / 16;
@@ -384,23 +435,29 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
     int64_t best = -1;
     bool found = false;
     for (int sh = 2; sh >= 0 && !found; --sh)
-        for (int m : {2, 1}) {   // MB 3 would need 108 weight registers per chunk
+        for (int m : {3, 2, 1}) {
             if (mt % m != 0) continue;
             const int64_t b = blocks(sh, m);
             if (b >= 512) { shape = sh; mb = m; found = true; break; }
             if (b > best) { best = b; shape = sh; mb = m; }
         }
-    if (S == 1) {
-        if (!s1d1) return 1;
-        launch_mb<1, 1, 1>(a, mt, mb, shape, stream);
-    } else if (S == 2) {
-        if (s1d1) launch_mb<2, 1, 1>(a, mt, mb, shape, stream);
-        else if (s2d1) launch_mb<2, 2, 1>(a, mt, mb, shape, stream);
-        else return 1;
-    } else {
-        if (s1d1) launch_mb<4, 1, 1>(a, mt, mb, shape, stream);
-        else if (s2d1) launch_mb<4, 2, 1>(a, mt, mb, shape, stream);
-        else launch_mb<4, 1, 2>(a, mt, mb, shape, stream);
+    // the weights of the channel block must fit LDS next to at least one input stage: narrow the block
+    int rc = 1;
+    for (; rc == 1 && mb >= 1; --mb) {
+        if (mt % mb != 0) continue;
+        if (S == 1) {
+            if (!s1d1) return 1;
+            rc = launch_mb<1, 1, 1>(a, mt, mb, shape, stream);
+        } else if (S == 2) {
+            if (s1d1) rc = launch_mb<2, 1, 1>(a, mt, mb, shape, stream);
+            else if (s2d1) rc = launch_mb<2, 2, 1>(a, mt, mb, shape, stream);
+            else return 1;
+        } else {
+            if (s1d1) rc = launch_mb<4, 1, 1>(a, mt, mb, shape, stream);
+            else if (s2d1) rc = launch_mb<4, 2, 1>(a, mt, mb, shape, stream);
+            else rc = launch_mb<4, 1, 2>(a, mt, mb, shape, stream);
+        }
     }
+    if (rc != 0) return 1;
     return itermvs_launch_status();
 }

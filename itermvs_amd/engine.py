@@ -134,9 +134,9 @@ class InferenceEngine:
             f2 = self._res_hip(self._res_hip(f1, "layer2.0.", 2), "layer2.1.", 1)
             f3 = self._res_hip(self._res_hip(f2, "layer3.0.", 2), "layer3.1.", 1)
             o3 = self._conv(f3, p + "output3.", bias=True)
-            mid = self._conv(f2, p + "inner2.", bias=True, ksize=1, pad=0, add=ops.bilinear_up(f3, 2))     # net.py:46
+            mid = self._conv(f2, p + "inner2.", bias=True, ksize=1, pad=0, add=f3, add_up2=True)   # net.py:46 (fused F.interpolate)
             o2 = self._conv(mid, p + "output2.", bias=True)
-            mid = self._conv(f1, p + "inner1.", bias=True, ksize=1, pad=0, add=ops.bilinear_up(mid, 2))    # net.py:49
+            mid = self._conv(f1, p + "inner1.", bias=True, ksize=1, pad=0, add=mid, add_up2=True)  # net.py:49
             o1 = self._conv(mid, p + "output1.", bias=True)
             return {1: o1, 2: o2, 3: o3}
         f0 = self._cbr(x, "conv1.", 1, True)

@@ -327,8 +327,8 @@ def tile_k_split(cin: int) -> int:
 class MfmaWeight:
     """Matrix-core formats of a Conv2d weight [Cout,Cin,k,k], zero padded:
     ``data`` (weight_format 1, conv_mfma.hip): [k*k, Cin_pad4, Cout_pad16];
-    ``tile`` (weight_format 2, conv_tile.hip, 3x3 only): [9, chunks, S, 4, Cout_pad16] whose element
-    (tap, ch, s, q, co) is the weight of input channel ch*4*S + q*S + s."""
+    ``tile`` (weight_format 2, conv_tile.hip, 3x3 only): [9, chunks, 4, Cout_pad16, S] whose element
+    (tap, ch, q, co, s) is the weight of input channel ch*4*S + q*S + s."""
 
     def __init__(self, w: Tensor):
         cout, cin, k, _ = w.shape
@@ -342,7 +342,7 @@ class MfmaWeight:
             nch = (cin + 4 * s - 1) // (4 * s)
             t = torch.zeros((9, nch * 4 * s, cout_p), device=w.device, dtype=torch.float32)
             t[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(9, cin, cout)
-            self.tile = t.reshape(9, nch, 4, s, cout_p).permute(0, 1, 3, 2, 4).contiguous()
+            self.tile = t.reshape(9, nch, 4, s, cout_p).permute(0, 1, 2, 4, 3).contiguous()
 
 
 _TILE_SHAPES = {(1, 1), (2, 1), (1, 2)}   # (stride, dilation) instantiated in conv_tile.hip
@@ -366,9 +366,10 @@ def _planes(t: Tensor, name: str):
 def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad: int = 1, dilation: int = 1,
            act: str = "none", add: Optional[Tensor] = None, aux1: Optional[Tensor] = None,
            aux2: Optional[Tensor] = None, out: Optional[Tensor] = None, out2: Optional[Tensor] = None,
-           transposed: bool = False, seg_end: Sequence[int] = ()) -> Tensor:
+           transposed: bool = False, seg_end: Sequence[int] = (), add_up2: bool = False) -> Tensor:
     """itermvs_conv2d.  ``weight`` / ``bias``: packed tensor(s) (see pack_conv_weight); pass lists of up to
-    three for per-segment weight sets with ``seg_end`` = batch boundaries.  Returns ``out``."""
+    three for per-segment weight sets with ``seg_end`` = batch boundaries.  ``add_up2``: ``add`` is the
+    half-resolution tensor whose x2 bilinear up-sampling is added (fused F.interpolate).  Returns ``out``."""
     weights = list(weight) if isinstance(weight, (list, tuple)) else [weight]
     biases = list(bias) if isinstance(bias, (list, tuple)) else [bias] * len(weights)
     n, cin, hin, win = x.shape
@@ -401,8 +402,9 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     for name, t in (("add", add), ("aux1", aux1), ("aux2", aux2)):
         if t is not None:
             ptr, sn = _planes(t, name)
-            if t.shape != out.shape:
-                raise RuntimeError(f"conv2d: {name} has shape {tuple(t.shape)}, expected {tuple(out.shape)}")
+            want = (n, cout, hout // 2, wout // 2) if (name == "add" and add_up2) else tuple(out.shape)
+            if tuple(t.shape) != want:
+                raise RuntimeError(f"conv2d: {name} has shape {tuple(t.shape)}, expected {want}")
             setattr(p, name, ptr)
             setattr(p, name + "_sn", sn)
     p.n_seg = len(weights)
@@ -418,6 +420,7 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     p.ksize, p.stride, p.pad, p.dilation = ksize, stride, pad, dilation
     p.transposed, p.act = int(transposed), ACT[act]
     p.weight_format = (2 if tiled else 1) if mfma else 0
+    p.add_mode = int(add_up2)
     if CONV_FLOP_COUNTER["enabled"]:
         CONV_FLOP_COUNTER["flops"] += 2.0 * n * hout * wout * cout * cin * ksize * ksize / (4.0 if transposed else 1.0)
         CONV_FLOP_COUNTER["launches"] += 1

@@ -45,6 +45,24 @@ def packed(wt, fmt):
     return ops().MfmaWeight(wt) if fmt == "mfma" else ops().pack_conv_weight(wt)
 
 
+@pytest.mark.parametrize("shape", [(16, 48, 1, 32, 40, 3), (32, 48, 1, 18, 22, 2), (16, 32, 3, 64, 96, 2)])
+def test_conv_fused_bilinear_residual(shape):
+    """FeatureNet's `F.interpolate(coarse, scale_factor=2, 'bilinear') + inner(x)` (models/net.py:46,49) with the
+    up-sampling evaluated in the conv epilogue: identical to bilinear_up + residual add"""
+    cin, cout, k, h, w, n = shape
+    gen = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn((n, cin, h, w), generator=gen).to(DEV)
+    wt = (torch.randn((cout, cin, k, k), generator=gen) / (cin * k * k) ** 0.5).to(DEV)
+    b = torch.randn((cout,), generator=gen).to(DEV)
+    coarse = torch.randn((n, cout, h // 2, w // 2), generator=gen).to(DEV)
+    want = F.interpolate(coarse, scale_factor=2, mode="bilinear") + F.conv2d(x, wt, b, padding=k // 2)
+    pk = ops().MfmaWeight(wt)
+    got = ops().conv2d(x, pk, b, ksize=k, pad=k // 2, add=coarse, add_up2=True)
+    assert rel_err(got, want) <= 2e-6
+    two_step = ops().conv2d(x, pk, b, ksize=k, pad=k // 2, add=ops().bilinear_up(coarse, 2))
+    assert torch.equal(got, two_step)
+
+
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("act", ["none", "relu", "sigmoid", "tanh"])
 def test_conv_without_residual_or_bias(case, act):
