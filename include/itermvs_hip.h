@@ -74,9 +74,12 @@ typedef struct itermvs_level_src {
  * holding rows of [rot | trans].  Inverse and product are evaluated in fp64 and rounded
  * once to fp32.  `nan_flag` (device int32, may be NULL) is OR-ed with 1 when a result is
  * NaN -- the deferred form of the reference's host-side asserts (module.py:83,87).
+ * When `inv_min` != NULL the same launch also writes the inverse depth range of the batch,
+ * inv_min[b] = 1 / depth_min[b], inv_max[b] = 1 / depth_max[b] (models/itermvs.py:240-241), b < B.
  * ------------------------------------------------------------------------------------------ */
 int itermvs_compose_proj(const float* mats, int32_t n_sets, int32_t V, float* out,
-                         int32_t* nan_flag, void* stream);
+                         int32_t* nan_flag, const float* depth_min, const float* depth_max,
+                         int32_t B, float* inv_min, float* inv_max, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * itermvs_warp -- models/module.py:68-125  differentiable_warping(src_fea, src_proj,
@@ -237,6 +240,9 @@ int itermvs_bilinear_up(const float* x, int32_t M, int32_t H, int32_t W, int32_t
  * `add_mode` 0: `add` has the output's shape; 1: `add` is [N,Cout,Hout/2,Wout/2] and its x2 bilinear
  *   up-sampling (F.interpolate(scale_factor=2, mode='bilinear'), models/net.py:46,49) is evaluated
  *   in the epilogue (matrix-core formats only, Hout and Wout even).
+ * `out_layout` 0: `out` is [Cout,H,W] planes per batch item (batch stride out_sn); 1: `out` is a dense
+ *   channels-last [N,H,W,Cout] tensor (the layout the correlation kernels read; act 0, no `add`,
+ *   Cout % 4 == 0, matrix-core formats only).
  * `out2` (optional) receives a second, contiguous [N,Cout,H,W] copy of the result.
  * ------------------------------------------------------------------------------------------ */
 typedef struct itermvs_conv_params {
@@ -257,6 +263,7 @@ typedef struct itermvs_conv_params {
     int32_t act;
     int32_t weight_format;
     int32_t add_mode;
+    int32_t out_layout;
 } itermvs_conv_params;
 
 int itermvs_conv2d(const itermvs_conv_params* p, void* stream);

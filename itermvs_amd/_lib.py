@@ -63,14 +63,15 @@ class ConvParams(C.Structure):
                 ("weight", C.c_void_p * 3), ("bias", C.c_void_p * 3), ("seg_end", C.c_int32 * 3), ("n_seg", C.c_int32),
                 ("N", C.c_int32), ("Cin", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cout", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dilation", C.c_int32),
-                ("transposed", C.c_int32), ("act", C.c_int32), ("weight_format", C.c_int32), ("add_mode", C.c_int32)]
+                ("transposed", C.c_int32), ("act", C.c_int32), ("weight_format", C.c_int32), ("add_mode", C.c_int32), ("out_layout", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/itermvs_hip.h declares
 PROTOTYPES = {
     "itermvs_version": (C.c_int, []),
     "itermvs_error_string": (C.c_char_p, [C.c_int]),
-    "itermvs_compose_proj": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "itermvs_compose_proj": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "itermvs_warp": (C.c_int, [C.POINTER(FMap), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "itermvs_warp_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p, C.c_void_p]),

@@ -204,6 +204,9 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     ITERMVS_RETURN_IF(p->act == 5 && !p->aux2, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->act >= 2 && p->add, ITERMVS_ERR_DIMS);   // residual add only with none / relu
     ITERMVS_RETURN_IF(p->add_mode < 0 || p->add_mode > 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(p->out_layout < 0 || p->out_layout > 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(p->out_layout == 1 && (p->weight_format == 0 || p->transposed || p->act != 0 || p->add || (p->Cout & 3)),
+                      ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(p->add_mode == 1 && (!p->add || p->weight_format == 0 || p->transposed || p->act != 0), ITERMVS_ERR_DIMS);
     ConvArgs a;
     a.in = p->in; a.out = p->out; a.out2 = p->out2; a.add = p->add; a.aux1 = p->aux1; a.aux2 = p->aux2;

@@ -38,6 +38,7 @@ struct EpilogueArgs {
     const float* aux1;
     const float* aux2;
     int Cout, P, act;
+    int out_nhwc;               // `out` is channels-last [P][Cout] (per batch item) instead of [Cout][P]
     int add_mode, Hout, Wout;   // add_mode 1: `add` is the half-resolution tensor, up-sampled x2 (bilinear) here
 };
 
@@ -167,12 +168,44 @@ __device__ __forceinline__ void conv_epilogue_act(const EpilogueArgs& e, const f
     }
 }
 
+// Channels-last output (the feature maps the correlation kernels gather from): a lane's four channels of one
+// pixel are 16 contiguous bytes -> one dwordx4 store per (mb, nb) instead of four dword stores into four
+// planes.  act 0, no residual (checked on the host); `out2` may still take the planar copy.
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_nhwc(const EpilogueArgs& e, const f32x4 (&acc)[MB][NB], int m0, int q,
+                                                   const uint32_t (&pix_off)[NB]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        if (pix_off[nb] == kEpiOob) continue;
+        float* __restrict__ row = e.out + (size_t)(pix_off[nb] >> 2) * (size_t)e.Cout;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int co = m0 + mb * 16 + q * 4;
+            if (co < e.Cout) *reinterpret_cast<f32x4*>(row + co) = acc[mb][nb];
+        }
+    }
+    if (e.out2) {
+        const uint32_t plane_b = (uint32_t)e.P * 4u;
+        const __amdgpu_buffer_rsrc_t r2 = epi_rsrc(e.out2, (uint32_t)e.Cout * plane_b);
+        const uint32_t lane_ch = (uint32_t)(q * 4) * plane_b, s0 = (uint32_t)m0 * plane_b;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const uint32_t voff = pix_off[nb] == kEpiOob ? kEpiOob : pix_off[nb] + lane_ch;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) epi_store(acc[mb][nb][r], r2, voff, s0 + (uint32_t)(mb * 16 + r) * plane_b);
+        }
+    }
+}
+
 // The optional residual operand is a template parameter as well: a run-time `if (add)` around its loads
 // makes the compiler wait for vmcnt(0) in front of EVERY pixel slot -- i.e. for the previous slot's stores.
 // py / px: output coordinates of this lane's pixel per slot (only read by the bilinear residual).
 template <int MB, int NB>
 __device__ __forceinline__ void conv_epilogue(const EpilogueArgs& e, const f32x4 (&acc)[MB][NB], int m0, int q,
                                               const uint32_t (&pix_off)[NB], const int (&py)[NB], const int (&px)[NB]) {
+    if (e.out_nhwc) return conv_epilogue_nhwc<MB, NB>(e, acc, m0, q, pix_off);
     const int key = e.act * 3 + (e.add ? 1 + e.add_mode : 0);
     switch (key) {
         case 0: conv_epilogue_act<0, 0, MB, NB>(e, acc, m0, q, pix_off, py, px); break;

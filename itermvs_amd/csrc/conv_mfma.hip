@@ -35,7 +35,7 @@ struct MfmaArgs {
     const float* bias[3];
     int seg_end[3];
     int N, Cin, CinPad, Hin, Win, Cout, CoutPad, Hout, Wout;
-    int ksize, stride, pad, dil, act, add_mode;
+    int ksize, stride, pad, dil, act, add_mode, out_nhwc;
 };
 
 __device__ __forceinline__ EpilogueArgs make_epilogue(const MfmaArgs& a, int n, int P) {
@@ -46,7 +46,7 @@ __device__ __forceinline__ EpilogueArgs make_epilogue(const MfmaArgs& a, int n, 
     e.aux1 = a.aux1 ? a.aux1 + (int64_t)n * a.aux1_sn : nullptr;
     e.aux2 = a.aux2 ? a.aux2 + (int64_t)n * a.aux2_sn : nullptr;
     e.Cout = a.Cout; e.P = P; e.act = a.act;
-    e.add_mode = a.add_mode; e.Hout = a.Hout; e.Wout = a.Wout;
+    e.add_mode = a.add_mode; e.Hout = a.Hout; e.Wout = a.Wout; e.out_nhwc = a.out_nhwc;
     return e;
 }
 
@@ -246,7 +246,7 @@ int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStr
     a.N = p->N; a.Cin = p->Cin; a.CinPad = (p->Cin + 3) / 4 * 4; a.Hin = p->Hin; a.Win = p->Win;
     a.Cout = p->Cout; a.CoutPad = (p->Cout + 15) / 16 * 16; a.Hout = hout; a.Wout = wout;
     a.ksize = p->ksize; a.stride = p->stride; a.pad = p->pad; a.dil = p->dilation; a.act = p->act;
-    a.add_mode = p->add_mode;
+    a.add_mode = p->add_mode; a.out_nhwc = p->out_layout;
     const int P = hout * wout;
     const int mt = a.CoutPad / 16;
     // largest register blocking (MB x NB tiles of 16 channels x 16 pixels per wave) that still yields

@@ -43,7 +43,7 @@ struct TileArgs {
     const float* bias[3];
     int seg_end[3];
     int N, Cin, Hin, Win, Cout, CoutPad, Hout, Wout;
-    int pad, act, add_mode, nchunk, nstage, tiles_x, tiles_y, ncb, total;
+    int pad, act, add_mode, out_nhwc, nchunk, nstage, tiles_x, tiles_y, ncb, total;
     uint32_t rcp_tiles_x, rcp_tiles_y;   // floor(2^32 / d) + 1
 };
 
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
         e.aux1 = a.aux1 ? a.aux1 + (int64_t)cur.n * a.aux1_sn : nullptr;
         e.aux2 = a.aux2 ? a.aux2 + (int64_t)cur.n * a.aux2_sn : nullptr;
         e.Cout = a.Cout; e.P = P; e.act = a.act;
-        e.add_mode = a.add_mode; e.Hout = a.Hout; e.Wout = a.Wout;
+        e.add_mode = a.add_mode; e.Hout = a.Hout; e.Wout = a.Wout; e.out_nhwc = a.out_nhwc;
         conv_epilogue<MB, NB>(e, acc, m0, q, pix_off, py, px);
         TILE_STAMP(4);
 #ifdef ITERMVS_TILE_TRACE
@@ -422,7 +422,7 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
     }
     a.N = p->N; a.Cin = p->Cin; a.Hin = p->Hin; a.Win = p->Win;
     a.Cout = p->Cout; a.CoutPad = (p->Cout + 15) / 16 * 16; a.Hout = hout; a.Wout = wout;
-    a.pad = p->pad; a.act = p->act; a.add_mode = p->add_mode;
+    a.pad = p->pad; a.act = p->act; a.add_mode = p->add_mode; a.out_nhwc = p->out_layout;
     const int S = p->Cin <= 4 ? 1 : p->Cin <= 8 ? 2 : 4;
     a.nchunk = (p->Cin + 4 * S - 1) / (4 * S);
     const int mt = a.CoutPad / 16;

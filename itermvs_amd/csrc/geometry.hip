@@ -8,9 +8,16 @@ namespace itermvs {
 // One thread per (set, source view); 4x4 Gauss-Jordan with partial pivoting in fp64.
 // ---------------------------------------------------------------------------------------------
 __global__ void compose_proj_kernel(const float* __restrict__ mats, int n_sets, int V, float* __restrict__ out,
-                                    int* __restrict__ nan_flag) {
+                                    int* __restrict__ nan_flag, const float* __restrict__ depth_min,
+                                    const float* __restrict__ depth_max, int B, float* __restrict__ inv_min,
+                                    float* __restrict__ inv_max) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int S = V - 1;
+    // inverse depth range of the batch (1 / depth_min, 1 / depth_max: itermvs.py:240-241), IEEE division
+    if (inv_min && t < B) {
+        inv_min[t] = 1.0f / depth_min[t];
+        inv_max[t] = 1.0f / depth_max[t];
+    }
     if (t >= n_sets * S) return;
     const int set = t / S, s = t - set * S + 1;
     const float* ref = mats + (size_t)set * V * 16;
@@ -180,13 +187,16 @@ __global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fma
 using namespace itermvs;
 
 extern "C" int itermvs_compose_proj(const float* mats, int32_t n_sets, int32_t V, float* out, int32_t* nan_flag,
-                                    void* stream) {
+                                    const float* depth_min, const float* depth_max, int32_t B, float* inv_min,
+                                    float* inv_max, void* stream) {
     ITERMVS_RETURN_IF(!mats || !out, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(inv_min && (!depth_min || !depth_max || !inv_max || B < 1), ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(n_sets < 1, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(V < 2 || V - 1 > ITERMVS_MAX_SRC, ITERMVS_ERR_VIEWS);
-    const int total = n_sets * (V - 1);
+    int total = n_sets * (V - 1);
+    if (inv_min && B > total) total = B;
     hipLaunchKernelGGL(compose_proj_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, mats, n_sets, V,
-                       out, nan_flag);
+                       out, nan_flag, depth_min, depth_max, B, inv_min, inv_max);
     return itermvs_launch_status();
 }
 

@@ -133,11 +133,14 @@ class InferenceEngine:
             f1 = self._res_hip(self._res_hip(f0, "layer1.0.", 2), "layer1.1.", 1)
             f2 = self._res_hip(self._res_hip(f1, "layer2.0.", 2), "layer2.1.", 1)
             f3 = self._res_hip(self._res_hip(f2, "layer3.0.", 2), "layer3.1.", 1)
-            o3 = self._conv(f3, p + "output3.", bias=True)
+            # the three outputs are written channels-last (the layout the correlation kernels gather from);
+            # level 2 also keeps a planar copy for the up-sampling head (itermvs.py:262)
+            o3 = self._conv(f3, p + "output3.", bias=True, channels_last_out=True)
             mid = self._conv(f2, p + "inner2.", bias=True, ksize=1, pad=0, add=f3, add_up2=True)   # net.py:46 (fused F.interpolate)
-            o2 = self._conv(mid, p + "output2.", bias=True)
+            self.o2_planar = torch.empty((mid.shape[0], self.w[p + "output2.bias"].shape[0], *mid.shape[2:]), device=mid.device)
+            o2 = self._conv(mid, p + "output2.", bias=True, channels_last_out=True, out2=self.o2_planar)
             mid = self._conv(f1, p + "inner1.", bias=True, ksize=1, pad=0, add=mid, add_up2=True)  # net.py:49
-            o1 = self._conv(mid, p + "output1.", bias=True)
+            o1 = self._conv(mid, p + "output1.", bias=True, channels_last_out=True)
             return {1: o1, 2: o2, 3: o3}
         f0 = self._cbr(x, "conv1.", 1, True)
         f1 = self._res(self._res(f0, "layer1.0.", 2), "layer1.1.", 1)
@@ -234,14 +237,18 @@ class InferenceEngine:
         ws = self._workspace(b, h, wd)
         hx, hx2, hidden = ws["hx"], ws["hx2"], ws["hidden"]
 
-        proj = ops.compose_proj(torch.stack([projs[1], projs[2], projs[3]]).reshape(3 * b, v, 4, 4),
-                                ws["nan_flag"]).view(3, b, s, 12)
-        inv_min = (1.0 / depth_min).contiguous()
-        inv_max = (1.0 / depth_max).contiguous()
+        # projs: {1,2,3: [B,V,4,4]} like the reference's sample dict, or the same stacked [3,B,V,4,4]
+        pstack = projs if torch.is_tensor(projs) else torch.stack([projs[1], projs[2], projs[3]])
+        proj, inv_min, inv_max = ops.compose_proj(pstack.reshape(3 * b, v, 4, 4), ws["nan_flag"], (depth_min, depth_max))
+        proj = proj.view(3, b, s, 12)
 
         # convex up-sampling logits from the reference level-2 feature (itermvs.py:262-263)
         # (packed copy: a strided batch-1 view would send MIOpen to its naive non-packed kernel)
-        ref2_nchw = feats[2][:1] if b == 1 else feats[2].view(b, v, *feats[2].shape[1:])[:, 0].contiguous()
+        if self.backend == "hip":
+            f2p = self.o2_planar
+            ref2_nchw = f2p[:1] if b == 1 else f2p.view(b, v, *f2p.shape[1:])[:, 0].contiguous()
+        else:
+            ref2_nchw = feats[2][:1] if b == 1 else feats[2].view(b, v, *feats[2].shape[1:])[:, 0].contiguous()
         u = "iter_mvs.upsample."
         if self.backend == "hip":
             up_logits = self._conv(self._conv(ref2_nchw, u + "0.", act="relu"), u + "2.", ksize=1, pad=0)
@@ -351,7 +358,8 @@ class GraphedRunner:
         self.engine = engine
         self.stream = stream or torch.cuda.Stream(device=imgs.device)
         self.imgs = imgs.clone()
-        self.projs = {l: p.clone() for l, p in projs.items()}
+        self.proj_stack = torch.stack([projs[1], projs[2], projs[3]]).contiguous()      # static [3,B,V,4,4]
+        self.projs = {l: self.proj_stack[l - 1] for l in (1, 2, 3)}
         self.depth_min, self.depth_max = depth_min.clone(), depth_max.clone()
         self.graphs: List["torch.cuda.CUDAGraph"] = []
         self.eager_calls = []
@@ -359,11 +367,11 @@ class GraphedRunner:
         self.stream.wait_stream(torch.cuda.current_stream(imgs.device))
         with torch.cuda.stream(self.stream):
             for _ in range(2):                                  # warm-up: allocates the workspaces, primes caches
-                engine.run(self.imgs, self.projs, self.depth_min, self.depth_max)
+                engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max)
             torch.cuda.synchronize(imgs.device)
             self._pool = torch.cuda.graph_pool_handle()          # one memory pool shared by all segments
             self._begin()
-            self.out = engine.run(self.imgs, self.projs, self.depth_min, self.depth_max, seg=self)
+            self.out = engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max, seg=self)
             self._end()
         torch.cuda.synchronize(imgs.device)
 
@@ -385,14 +393,24 @@ class GraphedRunner:
         return res
 
     # -- replay --------------------------------------------------------------------------------------------
+    @property
+    def static_inputs(self):
+        """(imgs, projs, depth_min, depth_max) buffers the graph reads: a producer (data loader, H2D copy)
+        may fill them in place and pass them back to ``__call__``, which then skips its staging copies."""
+        return self.imgs, self.projs, self.depth_min, self.depth_max
+
     def __call__(self, imgs: Tensor, projs: Dict[int, Tensor], depth_min: Tensor, depth_max: Tensor):
-        """copy the sample into the static inputs and replay ON THE CURRENT STREAM; returns the static
-        (depth, confidence) buffers, valid in stream order like any other torch op"""
-        self.imgs.copy_(imgs, non_blocking=True)
+        """copy the sample into the static inputs (unless it already IS them) and replay ON THE CURRENT
+        STREAM; returns the static (depth, confidence) buffers, valid in stream order like any other torch op"""
+        if imgs is not self.imgs:
+            self.imgs.copy_(imgs, non_blocking=True)
         for l in self.projs:
-            self.projs[l].copy_(projs[l], non_blocking=True)
-        self.depth_min.copy_(depth_min, non_blocking=True)
-        self.depth_max.copy_(depth_max, non_blocking=True)
+            if projs[l] is not self.projs[l]:
+                self.projs[l].copy_(projs[l], non_blocking=True)
+        if depth_min is not self.depth_min:
+            self.depth_min.copy_(depth_min, non_blocking=True)
+        if depth_max is not self.depth_max:
+            self.depth_max.copy_(depth_max, non_blocking=True)
         for i, g in enumerate(self.graphs):
             g.replay()
             if i < len(self.eager_calls):

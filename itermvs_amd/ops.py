@@ -65,14 +65,22 @@ def channels_last(t: Tensor) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------
-def compose_proj(mats: Tensor, nan_flag: Optional[Tensor] = None) -> Tensor:
-    """module.py:77-90.  mats [n,V,4,4] (view 0 = reference) -> [n,V-1,12] rows of [rot|trans]."""
+def compose_proj(mats: Tensor, nan_flag: Optional[Tensor] = None, depth_range=None):
+    """module.py:77-90.  mats [n,V,4,4] (view 0 = reference) -> [n,V-1,12] rows of [rot|trans].
+    ``depth_range`` = (depth_min [B], depth_max [B]): the same launch also returns (1/depth_min, 1/depth_max)
+    (itermvs.py:240-241); the result is then (proj, inv_min, inv_max)."""
     mats = _dev(mats, "mats").contiguous()
     n, v = mats.shape[0], mats.shape[1]
     out = torch.empty((n, v - 1, 12), device=mats.device, dtype=torch.float32)
-    check(_lib.load().itermvs_compose_proj(mats.data_ptr(), n, v, out.data_ptr(), _ptr(nan_flag), _stream()),
-          "itermvs_compose_proj")
-    return out
+    dmin = dmax = imin = imax = None
+    nb = 0
+    if depth_range is not None:
+        dmin, dmax = (_dev(t, "depth range").contiguous() for t in depth_range)
+        nb = dmin.numel()
+        imin, imax = torch.empty_like(dmin), torch.empty_like(dmax)
+    check(_lib.load().itermvs_compose_proj(mats.data_ptr(), n, v, out.data_ptr(), _ptr(nan_flag), _ptr(dmin), _ptr(dmax),
+                                           nb, _ptr(imin), _ptr(imax), _stream()), "itermvs_compose_proj")
+    return out if depth_range is None else (out, imin, imax)
 
 
 class _WarpFn(torch.autograd.Function):
@@ -366,10 +374,13 @@ def _planes(t: Tensor, name: str):
 def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad: int = 1, dilation: int = 1,
            act: str = "none", add: Optional[Tensor] = None, aux1: Optional[Tensor] = None,
            aux2: Optional[Tensor] = None, out: Optional[Tensor] = None, out2: Optional[Tensor] = None,
-           transposed: bool = False, seg_end: Sequence[int] = (), add_up2: bool = False) -> Tensor:
+           transposed: bool = False, seg_end: Sequence[int] = (), add_up2: bool = False,
+           channels_last_out: bool = False) -> Tensor:
     """itermvs_conv2d.  ``weight`` / ``bias``: packed tensor(s) (see pack_conv_weight); pass lists of up to
     three for per-segment weight sets with ``seg_end`` = batch boundaries.  ``add_up2``: ``add`` is the
-    half-resolution tensor whose x2 bilinear up-sampling is added (fused F.interpolate).  Returns ``out``."""
+    half-resolution tensor whose x2 bilinear up-sampling is added (fused F.interpolate).
+    ``channels_last_out``: ``out`` is written in channels-last memory format ([N,H,W,C] dense, what the
+    correlation kernels read); ``out2`` can still take the planar copy.  Returns ``out``."""
     weights = list(weight) if isinstance(weight, (list, tuple)) else [weight]
     biases = list(bias) if isinstance(bias, (list, tuple)) else [bias] * len(weights)
     n, cin, hin, win = x.shape
@@ -390,10 +401,16 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
         span = (ksize - 1) * dilation + 1
         hout, wout = (hin + 2 * pad - span) // stride + 1, (win + 2 * pad - span) // stride + 1
     if out is None:
-        out = torch.empty((n, cout, hout, wout), device=x.device, dtype=torch.float32)
+        out = torch.empty((n, cout, hout, wout), device=x.device, dtype=torch.float32,
+                          memory_format=torch.channels_last if channels_last_out else torch.contiguous_format)
     p = ConvParams()
     p.inp, p.in_sn = _planes(x, "conv input")
-    p.out, p.out_sn = _planes(out, "conv output")
+    if channels_last_out:
+        if not out.is_contiguous(memory_format=torch.channels_last):
+            raise RuntimeError("conv2d: channels_last_out needs a dense channels-last `out`")
+        p.out, p.out_sn, p.out_layout = _dev(out, "conv output").data_ptr(), cout * hout * wout, 1
+    else:
+        p.out, p.out_sn = _planes(out, "conv output")
     if out.shape != (n, cout, hout, wout):
         raise RuntimeError(f"conv2d: out has shape {tuple(out.shape)}, expected {(n, cout, hout, wout)}")
     if out2 is not None:

@@ -63,6 +63,23 @@ def test_conv_fused_bilinear_residual(shape):
     assert torch.equal(got, two_step)
 
 
+@pytest.mark.parametrize("shape", [(48, 16, 3, 32, 40, 3), (48, 48, 3, 9, 11, 2), (32, 48, 1, 16, 20, 2), (48, 32, 3, 64, 96, 5)])
+def test_conv_channels_last_output(shape):
+    """FeatureNet output layers write the channels-last layout the correlation kernels read (+ planar copy)"""
+    cin, cout, k, h, w, n = shape
+    gen = torch.Generator().manual_seed(cin * 3 + cout)
+    x = torch.randn((n, cin, h, w), generator=gen).to(DEV)
+    wt = (torch.randn((cout, cin, k, k), generator=gen) / (cin * k * k) ** 0.5).to(DEV)
+    b = torch.randn((cout,), generator=gen).to(DEV)
+    pk = ops().MfmaWeight(wt)
+    planar = ops().conv2d(x, pk, b, ksize=k, pad=k // 2)
+    copy = torch.empty_like(planar)
+    got = ops().conv2d(x, pk, b, ksize=k, pad=k // 2, channels_last_out=True, out2=copy)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, planar) and torch.equal(copy, planar)
+    assert rel_err(got, F.conv2d(x, wt, b, padding=k // 2)) <= 2e-6
+
+
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("act", ["none", "relu", "sigmoid", "tanh"])
 def test_conv_without_residual_or_bias(case, act):

@@ -39,7 +39,7 @@ def test_argument_validation_error_codes():
     from itermvs_amd import _lib
     lib = _lib.load()
     assert lib.itermvs_error_string(0) == b"ok"
-    assert lib.itermvs_compose_proj(None, 1, 2, None, None, None) == -1            # ERR_NULL
+    assert lib.itermvs_compose_proj(None, 1, 2, None, None, None, None, 0, None, None, None) == -1            # ERR_NULL
     assert lib.itermvs_corr_iter(None, None) == -1
     buf = (C.c_float * 64)()
     addr = C.addressof(buf)
