@@ -43,8 +43,8 @@ def test_argument_validation_error_codes():
     assert lib.itermvs_corr_iter(None, None) == -1
     buf = (C.c_float * 64)()
     addr = C.addressof(buf)
-    assert lib.itermvs_compose_proj(addr, 0, 2, addr, None, None) == -2            # ERR_DIMS
-    assert lib.itermvs_compose_proj(addr, 1, 40, addr, None, None) == -4           # ERR_VIEWS
+    assert lib.itermvs_compose_proj(addr, 0, 2, addr, None, None, None, 0, None, None, None) == -2            # ERR_DIMS
+    assert lib.itermvs_compose_proj(addr, 1, 40, addr, None, None, None, 0, None, None, None) == -4           # ERR_VIEWS
     assert lib.itermvs_softmax_max(addr, 0, 4, 4, addr, None) == -2
     p = _lib.CorrInitParams()
     p.B, p.S, p.H, p.W, p.N = 1, 1, 4, 4, 32
