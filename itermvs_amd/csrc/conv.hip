@@ -184,6 +184,7 @@ using namespace itermvs;
 
 int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);      // conv_mfma.hip
 int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);      // conv_tile.hip
+int itermvs_deconv2d_tile(const itermvs_conv_params* p, hipStream_t stream);                        // conv_tile.hip
 
 static int conv2d_impl(const itermvs_conv_params* p, void* stream);
 
@@ -224,7 +225,12 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     int ct = 1;
     for (int c : {32, 16, 8, 4})
         if (p->Cout % c == 0) { ct = c; break; }
+    if (p->transposed && p->weight_format == 2) {
+        const int rc = itermvs_deconv2d_tile(p, (hipStream_t)stream);
+        return rc == 1 ? ITERMVS_ERR_DIMS : rc;
+    }
     if (p->transposed) {
+        ITERMVS_RETURN_IF(p->weight_format != 0, ITERMVS_ERR_DIMS);
         ITERMVS_RETURN_IF(p->ksize != 3 || p->stride != 2 || p->pad != 1 || p->act > 1, ITERMVS_ERR_DIMS);
         a.Hout = 2 * p->Hin; a.Wout = 2 * p->Win;
         if (ct > 16) ct = 16;       // 4 output pixels x CT accumulators per thread

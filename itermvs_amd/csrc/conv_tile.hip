@@ -400,6 +400,135 @@ static int launch_mb(TileArgs& a, int mt, int mb, int shape, hipStream_t stream)
     return launch_shape<1, S, STRIDE, DIL>(a, mt, shape, stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// ConvTranspose2d(3, stride 2, pad 1, output_padding 1) on the matrix cores (CorrNet, itermvs.py:359-363).
+// out[2y+py][2x+px] only receives the taps of matching parity:
+//   py = 0: ky = 1 from in[y];   py = 1: ky = 0 from in[y+1], ky = 2 from in[y]      (same for px / kx)
+// so a wave takes 16 INPUT positions of one row, reads the four neighbours in[y+dy][x+dx] (dy, dx in {0,1})
+// from the LDS tile once per chunk and accumulates the four output parities separately: 9 weight reads,
+// 4 input reads and 9*S MFMAs per chunk -- the MFMA count of a 3x3 convolution on the input grid.  The
+// four parities are the four pixel slots of the shared epilogue (skip connection `add`, bias).
+// One tile (TH x 16 input positions, all chunks staged at once) per workgroup: these layers are a few
+// hundred tiles.
+// ---------------------------------------------------------------------------------------------
+template <int MB, int S, int TH, int NCH>
+__global__ void __launch_bounds__(256) deconv_tile_kernel(const TileArgs a) {
+    constexpr int IN_H = TH + 1, IN_W = 17, IN_PX = IN_H * IN_W;
+    constexpr int PL = (IN_PX * S + 63) / 64 * 64 + (S == 4 ? 0 : S == 2 ? 32 : 16);
+    constexpr int CH_FLOATS = 4 * PL;
+    constexpr int ITEMS = (4 * IN_PX + 255) / 256;
+    constexpr int WROW = 16 * MB * S, WBLK = 4 * WROW, VPR = WROW / 4;
+    static_assert(TH == 4, "one input row per wave");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* __restrict__ tile = smem;                        // [NCH][4][PL]
+    float* __restrict__ wlds = smem + NCH * CH_FLOATS;      // [NCH][9][4][16*MB][S]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l16 = lane & 15;
+    const uint32_t plane = (uint32_t)(a.Hin * a.Win);
+    const int m0 = blockIdx.y * (MB * 16);
+    const int t2 = blockIdx.x / a.tiles_x, tx = blockIdx.x - t2 * a.tiles_x;
+    const int n = t2 / a.tiles_y, ty = t2 - n * a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * 16;
+    const int seg = (n >= a.seg_end[0]) + (n >= a.seg_end[1]);
+
+    // input tile (rows y0 .. y0+TH, columns x0 .. x0+16; beyond the image -> 0), all chunks
+    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.in + (int64_t)n * a.in_sn), 0, (int)(a.Cin * plane * 4u), 0x00020000);
+    Vec<S> stage[NCH][ITEMS];
+    int loff[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int item = tid + j * 256;
+        const int iq = item / IN_PX, px = item - iq * IN_PX;
+        const int y = px / IN_W, x = px - y * IN_W;
+        const int gy = y0 + y, gx = x0 + x;
+        const bool ok = item < 4 * IN_PX && gy < a.Hin && gx < a.Win;
+        const uint32_t goff = ok ? ((uint32_t)(iq * S) * plane + (uint32_t)(gy * a.Win + gx)) * 4u : kTileOob;
+        loff[j] = iq * PL + px * S;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2)
+                stage[c][j].v[s2] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(ir, goff, (uint32_t)(c * 4 * S + s2) * plane * 4u, 0));
+    }
+    // weights of this channel block: global rows [tap][chunk][q] -> LDS rows [chunk][tap][q]
+    {
+        const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.weight[seg] + m0 * S);
+        const int col = tid % VPR;
+        for (int r = tid / VPR; r < NCH * 36; r += 256 / VPR) {
+            const int cidx = r / 36, rem = r - cidx * 36;
+            const int64_t g = (int64_t)(((rem >> 2) * NCH + cidx) * 4 + (rem & 3)) * (a.CoutPad * S / 4) + col;
+            reinterpret_cast<f32x4*>(wlds)[r * VPR + col] = src[g];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (j < ITEMS - 1 || tid + j * 256 < 4 * IN_PX) lds_write<S>(tile + c * CH_FLOATS + loff[j], stage[c][j]);
+    __syncthreads();
+
+    f32x4 acc[MB][4];     // [.][py * 2 + px]
+    conv_bias_init<MB, 4>(acc, a.bias[seg], a.Cout, m0, q);
+    const float* __restrict__ bbase = tile + q * PL + (wave * IN_W + l16) * S;
+    const float* __restrict__ abase = wlds + (q * 16 * MB + l16) * S;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        Vec<S> bv[2][2];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) bv[dy][dx] = lds_read<S>(bbase + c * CH_FLOATS + (dy * IN_W + dx) * S);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int py = ky == 1 ? 0 : 1, dy = ky == 0 ? 1 : 0;
+            const int px = kx == 1 ? 0 : 1, dx = kx == 0 ? 1 : 0;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const Vec<S> av = lds_read<S>(abase + (c * 9 + tap) * WBLK + mb * 16 * S);
+#pragma unroll
+                for (int s2 = 0; s2 < S; ++s2)
+                    acc[mb][py * 2 + px] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.v[s2], bv[dy][dx].v[s2], acc[mb][py * 2 + px], 0, 0, 0);
+            }
+        }
+    }
+
+    const int P = a.Hout * a.Wout;
+    const int iy = y0 + wave, ix = x0 + l16;
+    uint32_t pix_off[4];
+    int oyv[4], oxv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        oyv[k] = 2 * iy + (k >> 1);
+        oxv[k] = 2 * ix + (k & 1);
+        pix_off[k] = iy < a.Hin && ix < a.Win ? (uint32_t)(oyv[k] * a.Wout + oxv[k]) * 4u : kEpiOob;
+    }
+    EpilogueArgs e;
+    e.out = a.out + (int64_t)n * a.out_sn;
+    e.out2 = a.out2 ? a.out2 + (int64_t)n * a.Cout * P : nullptr;
+    e.add = a.add ? a.add + (int64_t)n * a.add_sn : nullptr;
+    e.aux1 = nullptr; e.aux2 = nullptr;
+    e.Cout = a.Cout; e.P = P; e.act = a.act;
+    e.add_mode = 0; e.Hout = a.Hout; e.Wout = a.Wout; e.out_nhwc = 0;
+    conv_epilogue<MB, 4>(e, acc, m0, q, pix_off, oyv, oxv);
+}
+
+template <int MB, int S, int NCH>
+static int launch_deconv(TileArgs& a, int mt, hipStream_t stream) {
+    constexpr int TH = 4, IN_PX = (TH + 1) * 17;
+    constexpr int PL = (IN_PX * S + 63) / 64 * 64 + (S == 4 ? 0 : S == 2 ? 32 : 16);
+    constexpr int lds = (NCH * 4 * PL + NCH * 36 * 16 * MB * S) * 4;
+    static_assert(lds <= kLdsBudget, "deconv tile does not fit LDS");
+    a.tiles_x = (a.Win + 15) / 16;
+    a.tiles_y = (a.Hin + TH - 1) / TH;
+    const dim3 grid(a.N * a.tiles_y * a.tiles_x, mt / MB);
+    hipLaunchKernelGGL((deconv_tile_kernel<MB, S, TH, NCH>), grid, dim3(256), lds, stream, a);
+    return 0;
+}
+
 }  // namespace itermvs
 
 using namespace itermvs;
@@ -458,6 +587,34 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
             else rc = launch_mb<4, 1, 2>(a, mt, mb, shape, stream);
         }
     }
+    if (rc != 0) return 1;
+    return itermvs_launch_status();
+}
+
+// transposed convolutions (weight_format 2 built from the ConvTranspose2d weight with in/out channels swapped);
+// returns 1 when the shape is not covered
+int itermvs_deconv2d_tile(const itermvs_conv_params* p, hipStream_t stream) {
+    if (p->ksize != 3 || p->stride != 2 || p->pad != 1 || p->act > 1 || p->Cin <= 4 || p->Cin > 32) return 1;
+    TileArgs a;
+    a.in = p->in; a.out = p->out; a.out2 = p->out2; a.add = p->add; a.aux1 = nullptr; a.aux2 = nullptr;
+    a.in_sn = p->in_sn; a.out_sn = p->out_sn; a.add_sn = p->add_sn; a.aux1_sn = 0; a.aux2_sn = 0;
+    for (int i = 0; i < 3; ++i) {
+        const int k = i < p->n_seg ? i : p->n_seg - 1;
+        a.weight[i] = p->weight[k];
+        a.bias[i] = p->bias[k];
+        a.seg_end[i] = i < p->n_seg - 1 ? p->seg_end[i] : p->N;
+    }
+    a.N = p->N; a.Cin = p->Cin; a.Hin = p->Hin; a.Win = p->Win;
+    a.Cout = p->Cout; a.CoutPad = (p->Cout + 15) / 16 * 16; a.Hout = 2 * p->Hin; a.Wout = 2 * p->Win;
+    a.pad = 1; a.act = p->act; a.add_mode = 0; a.out_nhwc = 0;
+    const int S = p->Cin <= 8 ? 2 : 4;
+    a.nchunk = (p->Cin + 4 * S - 1) / (4 * S);
+    const int mt = a.CoutPad / 16;
+    if (mt > 2) return 1;
+    int rc = 1;
+    if (S == 2) rc = mt == 2 ? launch_deconv<2, 2, 1>(a, mt, stream) : launch_deconv<1, 2, 1>(a, mt, stream);
+    else if (a.nchunk == 1) rc = mt == 2 ? launch_deconv<2, 4, 1>(a, mt, stream) : launch_deconv<1, 4, 1>(a, mt, stream);
+    else rc = mt == 2 ? launch_deconv<2, 4, 2>(a, mt, stream) : launch_deconv<1, 4, 2>(a, mt, stream);
     if (rc != 0) return 1;
     return itermvs_launch_status();
 }

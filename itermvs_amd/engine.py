@@ -97,7 +97,7 @@ class InferenceEngine:
             if not k.endswith("weight") or v.dim() != 4 or ".bn." in k or k.startswith("feature_net.") and ".conv." in k:
                 continue
             if k.endswith("conv3.weight") or k.endswith("conv4.weight"):      # ConvTranspose2d (itermvs.py:359-363)
-                pk[k] = ops.pack_conv_weight(v, transposed=True)
+                pk[k] = ops.MfmaWeight(v, transposed=True)
             else:
                 pk[k] = ops.MfmaWeight(v)
 

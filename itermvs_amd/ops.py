@@ -338,7 +338,11 @@ class MfmaWeight:
     ``tile`` (weight_format 2, conv_tile.hip, 3x3 only): [9, chunks, 4, Cout_pad16, S] whose element
     (tap, ch, q, co, s) is the weight of input channel ch*4*S + q*S + s."""
 
-    def __init__(self, w: Tensor):
+    def __init__(self, w: Tensor, transposed: bool = False):
+        """``transposed``: ``w`` is a ConvTranspose2d weight [Cin,Cout,k,k] (only the tile format is built)."""
+        self.transposed = transposed
+        if transposed:
+            w = w.permute(1, 0, 2, 3)
         cout, cin, k, _ = w.shape
         cin_p, cout_p = (cin + 3) // 4 * 4, (cout + 15) // 16 * 16
         packed = torch.zeros((k * k, cin_p, cout_p), device=w.device, dtype=torch.float32)
@@ -386,12 +390,12 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     n, cin, hin, win = x.shape
     mfma, tiled = isinstance(weights[0], MfmaWeight), False
     if mfma:
-        if transposed:
-            raise RuntimeError("conv2d: transposed convolutions use the VALU weight format")
+        if transposed != weights[0].transposed:
+            raise RuntimeError("conv2d: weight was packed for the other direction (MfmaWeight(transposed=...))")
         if any(wt.cin != cin or wt.ksize != ksize for wt in weights):
             raise RuntimeError("conv2d: MfmaWeight does not match the input channels / kernel size")
         cout = weights[0].cout
-        tiled = all(_use_tile(wt, stride, dilation) for wt in weights)
+        tiled = transposed or all(_use_tile(wt, stride, dilation) for wt in weights)
         weights = [wt.tile if tiled else wt.data for wt in weights]
     else:
         cout = weights[0].shape[3]

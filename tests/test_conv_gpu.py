@@ -116,10 +116,12 @@ def test_conv_matches_torch(case, act, fmt):
     assert rel_err(got, want) <= 2e-6
 
 
-def test_transposed_conv_with_skip_and_segments():
+@pytest.mark.parametrize("fmt", ["mfma", "valu"])
+def test_transposed_conv_with_skip_and_segments(fmt):
     """CorrNet conv3/conv4 (itermvs.py:359-363) incl. the per-level weight sets of one launch."""
     gen = torch.Generator().manual_seed(5)
-    for cin, cout, h, w in ((32, 16, 8, 10), (16, 8, 7, 9)):
+    pack = (lambda wi: ops().MfmaWeight(wi, transposed=True)) if fmt == "mfma" else (lambda wi: ops().pack_conv_weight(wi, transposed=True))
+    for cin, cout, h, w in ((32, 16, 8, 10), (16, 8, 7, 9), (32, 16, 32, 40), (16, 8, 64, 80), (8, 8, 5, 33)):
         n = 10
         x = torch.randn((n, cin, h, w), generator=gen).to(DEV)
         ws = [(torch.randn((cin, cout, 3, 3), generator=gen) / (cin * 9) ** 0.5).to(DEV) for _ in range(3)]
@@ -127,7 +129,7 @@ def test_transposed_conv_with_skip_and_segments():
         segs = [(0, 4), (4, 8), (8, 10)]
         want = torch.cat([F.conv_transpose2d(x[a:b], ws[i], stride=2, padding=1, output_padding=1) + skip[a:b]
                           for i, (a, b) in enumerate(segs)])
-        got = ops().conv2d(x, [ops().pack_conv_weight(wi, transposed=True) for wi in ws], None, transposed=True,
+        got = ops().conv2d(x, [pack(wi) for wi in ws], None, transposed=True,
                            stride=2, pad=1, add=skip, seg_end=[4, 8])
         assert rel_err(got, want) <= 2e-6
 
