@@ -180,6 +180,20 @@ int itermvs_prob_regress(const float* logits, int64_t sb, int64_t sc, int64_t sp
                          int64_t nd_sb1, float* prob, int64_t* best, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * itermvs_head_regress -- the two 1x1 layers of the depth head fused with itermvs_prob_regress
+ * (models/itermvs.py:121-126 depth_head[2:5], then :171-190 / :201-219):
+ *   y = relu(W1 x); logits = W2 y + b2; nd = window regression of softmax(logits)
+ * x [B,32,P] planes (batch stride x_sb) is the output of the head's first (3x3, dilated) layer.
+ * Packed weights (fp32):  w1_packed [4][2][4][16][4] with element (mb,u,q,i,s) = W1[mb*16+i][u*16+q*4+s],
+ *                         w2_packed [16][4][4][16][4] with element (mb,m,q,i,r) = W2[mb*16+i][m*16+q*4+r];
+ * bias2 [256].  Outputs as itermvs_prob_regress (nd_out0 / nd_out1 / best may be NULL); the 256-bin
+ * logits are never written to memory.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_head_regress(const float* x, int64_t x_sb, int32_t B, int32_t P, const float* w1_packed,
+                         const float* w2_packed, const float* bias2, float* nd_out0, int64_t nd_sb0,
+                         float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * ConvGRU gates -- models/module.py:59-66 (the three 3x3 dilated convolutions stay in MIOpen)
  * itermvs_gru_rh :  rh[b,c,p] = sigmoid(zr[b,32+c,p]) * h[b,c,p]           (r * h, :63-64)
  * itermvs_gru_out:  h[b,c,p]  = (1-z) * h + z * tanh(q),  z = sigmoid(zr[b,c,p])   (:62,64,65)

@@ -85,6 +85,8 @@ class InferenceEngine:
         self.pk: Dict[str, Tensor] = {}
         if self.backend == "hip":
             self._pack_weights()
+            dh = "iter_mvs.update.depth_head."
+            self.head_w1, self.head_w2 = ops.pack_head_weights(w[dh + "2.weight"], w[dh + "4.weight"])
 
     def _pack_weights(self) -> None:
         """Re-lay every conv weight once (BatchNorm already folded): regular convolutions in the
@@ -176,6 +178,19 @@ class InferenceEngine:
         u1 = F.conv_transpose2d(c2, w[p + "conv3.weight"], stride=2, padding=1, output_padding=1).add_(c1)
         u0 = F.conv_transpose2d(u1, w[p + "conv4.weight"], stride=2, padding=1, output_padding=1).add_(c0)
         return F.conv2d(u0, w[p + "conv5.weight"], w[p + "conv5.bias"], padding=1)
+
+    def depth_regress(self, hidden: Tensor, nd_out, trace_logits: bool):
+        """depth head + softmax regression (itermvs.py:121-126, 171-190): -> (logits | None, best | None).
+        Without a trace the two 1x1 layers and the regression are ONE launch (itermvs_head_regress) and the
+        256-bin logits never reach memory."""
+        if self.backend == "hip" and not trace_logits:
+            p = "iter_mvs.update.depth_head."
+            x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu")
+            ops.head_regress(x, self.head_w1, self.head_w2, self.w[p + "4.bias"], nd_out=nd_out)
+            return None, None
+        logits = self.depth_head(hidden)
+        _, _, best = ops.prob_regress(logits, nd_out=nd_out, want_best=trace_logits)
+        return logits, best
 
     def depth_head(self, hidden: Tensor) -> Tensor:
         w, p = self.w, "iter_mvs.update.depth_head."
@@ -278,8 +293,7 @@ class InferenceEngine:
         hidden0 = ops.bilinear_up(x, 2, act="tanh")                                             # itermvs.py:161-163
         hidden.copy_(hidden0)
         hx[:, :HIDDEN].copy_(hidden0)
-        logits = self.depth_head(hidden)
-        _, _, best = ops.prob_regress(logits, nd_out=[(hx, HIDDEN), (hx2, HIDDEN)], want_best=trace is not None)
+        logits, best = self.depth_regress(hidden, [(hx, HIDDEN), (hx2, HIDDEN)], trace is not None)
         if trace is not None:
             trace.update(feats=feats, proj=proj, ref_q=ref_q, corr_views=corr_v, view_weights=view_w, init_agg=agg0,
                          init_score=score0, hidden0=hidden0.clone(), logits0=logits, nd0=hx[:, HIDDEN:HIDDEN + 1].clone(),
@@ -323,8 +337,7 @@ class InferenceEngine:
                 ops.gru_out(zr, q, hx, hidden, HIDDEN)
             if it == self.iteration - 1:
                 conf = self.confidence(hidden)                                                  # itermvs.py:197-199
-            logits = self.depth_head(hidden)
-            _, _, best = ops.prob_regress(logits, nd_out=[(hx, HIDDEN), (hx2, HIDDEN)], want_best=trace is not None)
+            logits, best = self.depth_regress(hidden, [(hx, HIDDEN), (hx2, HIDDEN)], trace is not None)
             if trace is not None:
                 trace["iters"].append(dict(nd_in=nd_in, aggs=[a.clone() for a in aggs], score=torch.cat(scores, 1),
                                            hidden=hidden.clone(), logits=logits, best=best,

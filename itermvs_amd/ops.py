@@ -225,6 +225,42 @@ def softmax_max(x: Tensor) -> Tensor:
     return out
 
 
+def pack_head_weights(w1: Tensor, w2: Tensor) -> Tuple[Tensor, Tensor]:
+    """depth_head[2].weight [64,32,1,1], depth_head[4].weight [256,64,1,1] -> the matrix-core operand
+    layouts of itermvs_head_regress (include/itermvs_hip.h)."""
+    a1 = w1.reshape(4, 16, 2, 4, 4).permute(0, 2, 3, 1, 4).contiguous()     # [mb,i,u,q,s] -> [mb,u,q,i,s]
+    a2 = w2.reshape(16, 16, 4, 4, 4).permute(0, 2, 3, 1, 4).contiguous()    # [mb,i,m,q,r] -> [mb,m,q,i,r]
+    return a1, a2
+
+
+def head_regress(x: Tensor, w1p: Tensor, w2p: Tensor, bias2: Tensor,
+                 nd_out: Optional[Sequence[Tuple[Tensor, int]]] = None, want_best: bool = False):
+    """itermvs_head_regress: x [B,32,H,W] (after depth_head[0:2]) -> normalised depth (and arg-max bin),
+    written like prob_regress's ``nd_out``.  Returns (nd | None, best | None)."""
+    _dev(x, "x")
+    b, c, h, w = x.shape
+    if c != 32:
+        raise RuntimeError("head_regress: expects the 32-channel depth-head feature")
+    ptr, sb = _planes(x, "head input")
+    p = h * w
+    nd, dests = None, []
+    if nd_out is None:
+        nd = torch.empty((b, 1, h, w), device=x.device, dtype=torch.float32)
+        dests.append((nd.data_ptr(), p))
+    else:
+        for buf, ch in nd_out:
+            _dev(buf, "nd_out")
+            assert buf.is_contiguous() and buf.shape[2:] == (h, w)
+            dests.append((buf.data_ptr() + 4 * ch * p, buf.shape[1] * p))
+    while len(dests) < 2:
+        dests.append((None, 0))
+    best = torch.empty((b, 1, h, w), device=x.device, dtype=torch.int64) if want_best else None
+    check(_lib.load().itermvs_head_regress(ptr, sb, b, p, _dev(w1p, "w1").data_ptr(), _dev(w2p, "w2").data_ptr(),
+                                           _dev(bias2, "bias2").data_ptr(), dests[0][0], dests[0][1], dests[1][0],
+                                           dests[1][1], _ptr(best), _stream()), "itermvs_head_regress")
+    return nd, best
+
+
 def prob_regress(logits: Tensor, nd_out: Optional[Sequence[Tuple[Tensor, int]]] = None, want_prob: bool = False,
                  want_best: bool = False):
     """itermvs.py:171-190 / 201-219.  logits [B,256,H,W] (NCHW or channels-last).

@@ -213,6 +213,67 @@ def test_prob_regress_edges():
     assert maxdiff(nd, nd_ref) <= 1e-6
 
 
+def _head_reference(x, w1, w2, b2):
+    """depth_head[2:5] + regression with torch ops (oracle restatement of itermvs.py:121-126,171-190)"""
+    import torch.nn.functional as F
+    logits = F.conv2d(F.relu(F.conv2d(x, w1)), w2, b2)
+    nd, best = O.window_regression(torch.softmax(logits, 1))
+    return logits, nd, best
+
+
+@pytest.mark.parametrize("tag", ["seed0", "dtu"])
+def test_head_regress_fused_matches_chain(tag):
+    """itermvs_head_regress (two 1x1 layers + softmax regression in one launch) against the oracle chain and
+    against the unfused kernels on the golden hidden states"""
+    g = golden(f"e2e_small_{tag}.npz")
+    w = load_weights(tag)
+    p = "iter_mvs.update.depth_head."
+    import torch.nn.functional as F
+    w0, w1, w2, b2 = (cu(w[p + k]) for k in ("0.weight", "2.weight", "4.weight", "4.bias"))
+    a1, a2 = ops().pack_head_weights(w1, w2)
+    for it in range(int(g.np("iteration"))):
+        hidden = cu(g[f"iter{it}.hidden"])
+        x = F.relu(F.conv2d(hidden, w0, padding=2, dilation=2))
+        logits, nd_ref, best_ref = _head_reference(x.cpu(), w1.cpu(), w2.cpu(), b2.cpu())
+        nd, best = ops().head_regress(x, a1, a2, b2, want_best=True)
+        # the arg-max may legitimately move between bins whose logits differ by rounding noise
+        top2 = logits.topk(2, dim=1).values
+        clear = ((top2[:, :1] - top2[:, 1:2]) > 1e-4)
+        assert torch.equal(best.cpu()[clear], best_ref[clear])
+        assert float((nd.cpu() - nd_ref)[clear].abs().max()) <= 2e-6
+        assert float(clear.float().mean()) > 0.9
+        # in-place destinations inside wider buffers, like the GRU input buffers
+        b, _, h, wd = x.shape
+        buf0, buf1 = torch.zeros((b, 5, h, wd), device=DEV), torch.zeros((b, 5, h, wd), device=DEV)
+        ops().head_regress(x, a1, a2, b2, nd_out=[(buf0, 3), (buf1, 1)])
+        assert torch.equal(buf0[:, 3:4], nd) and torch.equal(buf1[:, 1:2], nd)
+        assert float(buf0[:, :3].abs().max()) == 0.0 and float(buf1[:, 2:].abs().max()) == 0.0
+
+
+def test_head_regress_edges_and_ties():
+    """window clamps at both ends and exact ties (first max): weights that route x straight to chosen bins"""
+    h, wd = 2, 40
+    x = torch.zeros((1, 32, h, wd))
+    w1 = torch.zeros((64, 32, 1, 1))
+    w2 = torch.zeros((256, 64, 1, 1))
+    b2 = torch.full((256,), -5.0)
+    for c in range(32):
+        w1[c, c] = 1.0                     # y[c] = relu(x[c])
+    # channel c lights bin bins[c]
+    bins = [0, 1, 2, 3, 4, 7, 100, 128, 200, 250, 251, 252, 253, 254, 255, 35, 10, 77, 78, 33, 34, 36, 37, 60, 61, 62, 63, 64, 65, 66, 67, 68]
+    for c, k in enumerate(bins):
+        w2[k, c] = 8.0
+    for xx in range(wd):
+        x[0, xx % 32, 0, xx] = 1.0                          # one peak: incl. bins 0..4 and 250..255 (clamps)
+        x[0, 15, 1, xx] = 1.0                               # tie between bin 35 ...
+        x[0, 16 + (xx % 3), 1, xx] = 1.0                    # ... and bin 10 / 77 / 78: the lower index wins
+    logits, nd_ref, best_ref = _head_reference(x, w1, w2, b2)
+    a1, a2 = ops().pack_head_weights(cu(w1), cu(w2))
+    nd, best = ops().head_regress(cu(x), a1, a2, cu(b2), want_best=True)
+    assert torch.equal(best.cpu(), best_ref)
+    assert maxdiff(nd, nd_ref) <= 1e-6
+
+
 @pytest.mark.parametrize("tag", ["seed0", "dtu"])
 def test_gru_gates(tag):
     g = golden(f"e2e_small_{tag}.npz")

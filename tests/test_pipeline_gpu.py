@@ -105,8 +105,10 @@ def test_cfg1_against_reference_outputs(tag):
         o_cpu = O.pipeline_forward(w, s["imgs"], s["proj_matrices"], s["depth_min"], s["depth_max"], 4, trace=t_cpu)
         o_gpu = O.pipeline_forward({k: v.to(DEV) for k, v in w.items()}, imgs, pm, dmin, dmax, 4, trace=t_gpu)
         eng = InferenceEngine(model.weights(), 4)
-        d2, _ = eng.run(imgs["level_0"], {l: pm[f"level_{l}"] for l in (1, 2, 3)}, dmin, dmax, trace=t_eng)
-    assert maxdiff(d2, d) == 0.0                                                    # deterministic engine
+        pj = {l: pm[f"level_{l}"] for l in (1, 2, 3)}
+        d3, _ = eng.run(imgs["level_0"], pj, dmin, dmax)
+        d2, _ = eng.run(imgs["level_0"], pj, dmin, dmax, trace=t_eng)
+    assert maxdiff(d3, d) == 0.0                                                    # deterministic engine
 
     # (1) first arg-max, before any feedback
     flips0 = float((t_eng["best0"].cpu() != t_cpu["best0"]).float().mean())
@@ -129,6 +131,9 @@ def test_cfg1_against_reference_outputs(tag):
     assert med_cpu <= med_lim and med_gold <= med_lim
     assert bad_cpu <= 1.5 * max(floor, host_floor) + 0.005
     assert bad_gold <= 1.5 * max(floor, host_floor) + 0.005
+    # the traced run evaluates the depth head unfused (logits in memory, other summation order): same gate
+    bad_tr, med_tr, _ = _rates(d2, d)
+    assert med_tr <= med_lim and bad_tr <= 1.5 * max(floor, host_floor) + 0.005, (bad_tr, med_tr)
     cbad = float(((c.cpu() - o_cpu["confidence_upsampled"]).abs() > 1e-3).float().mean())
     assert cbad <= 1.5 * max(floor, host_floor) + 0.01
 
@@ -224,10 +229,13 @@ def test_full_size_configs_cross_backend(cfg):
     t_hip, t_mio = {}, {}
     with torch.no_grad():
         d1, c1 = hip.run(imgs["level_0"], projs, dmin, dmax, trace=t_hip)
-        d1b, _ = hip.run(imgs["level_0"], projs, dmin, dmax)
+        d1b, _ = hip.run(imgs["level_0"], projs, dmin, dmax)                    # fused depth head (no trace)
+        d1c = hip.run(imgs["level_0"], projs, dmin, dmax)[0].clone()
         d2, c2 = mio.run(imgs["level_0"], projs, dmin, dmax, trace=t_mio)
     assert d1.shape == (1, 1, h, w) and c1.shape == (1, 1, h, w)
-    assert torch.equal(d1, d1b)                                                  # deterministic
+    assert torch.equal(d1b, d1c)                                                 # deterministic
+    relf = (d1 - d1b).abs() / d1b                                                # traced (unfused head) vs fused
+    assert float(relf.median()) <= 1e-6 and float((relf > 1e-4).float().mean()) <= 0.03
     assert bool(torch.isfinite(d1).all()) and float(d1.min()) >= 424.9 and float(d1.max()) <= 935.1
     flips0 = float((t_hip["best0"] != t_mio["best0"]).float().mean())
     rel = (d1 - d2).abs() / d2
