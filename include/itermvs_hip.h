@@ -258,6 +258,10 @@ int itermvs_bilinear_up(const float* x, int32_t M, int32_t H, int32_t W, int32_t
  *   channels-last [N,H,W,Cout] tensor (the layout the correlation kernels read; act 0, no `add`,
  *   Cout % 4 == 0, matrix-core formats only).
  * `out2` (optional) receives a second, contiguous [N,Cout,H,W] copy of the result.
+ * `split_cout` > 0 (matrix-core formats, multiple of 16): output channels [split_cout, Cout) form a SECOND
+ *   result with its own activation `act_b` and destination `out_b` (planes, batch stride out_b_sn, channel
+ *   index rebased to 0); channels [0, split_cout) go to `out` with `act`.  One launch then evaluates two
+ *   convolutions of the same input -- the ConvGRU update and reset gates (models/module.py:61-63).
  * ------------------------------------------------------------------------------------------ */
 typedef struct itermvs_conv_params {
     const float* in;
@@ -278,6 +282,10 @@ typedef struct itermvs_conv_params {
     int32_t weight_format;
     int32_t add_mode;
     int32_t out_layout;
+    int32_t split_cout;
+    int32_t act_b;
+    float* out_b;
+    int64_t out_b_sn;
 } itermvs_conv_params;
 
 int itermvs_conv2d(const itermvs_conv_params* p, void* stream);

@@ -63,7 +63,8 @@ class ConvParams(C.Structure):
                 ("weight", C.c_void_p * 3), ("bias", C.c_void_p * 3), ("seg_end", C.c_int32 * 3), ("n_seg", C.c_int32),
                 ("N", C.c_int32), ("Cin", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cout", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dilation", C.c_int32),
-                ("transposed", C.c_int32), ("act", C.c_int32), ("weight_format", C.c_int32), ("add_mode", C.c_int32), ("out_layout", C.c_int32)]
+                ("transposed", C.c_int32), ("act", C.c_int32), ("weight_format", C.c_int32), ("add_mode", C.c_int32), ("out_layout", C.c_int32),
+                ("split_cout", C.c_int32), ("act_b", C.c_int32), ("out_b", C.c_void_p), ("out_b_sn", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/itermvs_hip.h declares

@@ -43,6 +43,9 @@ struct TileArgs {
     const float* bias[3];
     int seg_end[3];
     int N, Cin, Hin, Win, Cout, CoutPad, Hout, Wout;
+    float* out_b;             // second result (channels >= split) or nullptr
+    int64_t out_b_sn;
+    int split, act_b;
     int pad, act, add_mode, out_nhwc, nchunk, nstage, tiles_x, tiles_y, ncb, total;
     uint32_t rcp_tiles_x, rcp_tiles_y;   // floor(2^32 / d) + 1
 };
@@ -324,7 +327,18 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
         e.aux2 = a.aux2 ? a.aux2 + (int64_t)cur.n * a.aux2_sn : nullptr;
         e.Cout = a.Cout; e.P = P; e.act = a.act;
         e.add_mode = a.add_mode; e.Hout = a.Hout; e.Wout = a.Wout; e.out_nhwc = a.out_nhwc;
-        conv_epilogue<MB, NB>(e, acc, m0, q, pix_off, py, px);
+        int me = m0;
+        if (a.split) {          // two results from one launch: channels below / from `split` (uniform per workgroup)
+            if (m0 >= a.split) {
+                e.out = a.out_b + (int64_t)cur.n * a.out_b_sn;
+                e.act = a.act_b;
+                e.Cout = a.Cout - a.split;
+                me = m0 - a.split;
+            } else {
+                e.Cout = a.split;
+            }
+        }
+        conv_epilogue<MB, NB>(e, acc, me, q, pix_off, py, px);
         TILE_STAMP(4);
 #ifdef ITERMVS_TILE_TRACE
         ++trace_tile;
@@ -552,6 +566,7 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
     a.N = p->N; a.Cin = p->Cin; a.Hin = p->Hin; a.Win = p->Win;
     a.Cout = p->Cout; a.CoutPad = (p->Cout + 15) / 16 * 16; a.Hout = hout; a.Wout = wout;
     a.pad = p->pad; a.act = p->act; a.add_mode = p->add_mode; a.out_nhwc = p->out_layout;
+    a.split = p->split_cout; a.act_b = p->act_b; a.out_b = p->out_b; a.out_b_sn = p->out_b_sn;
     const int S = p->Cin <= 4 ? 1 : p->Cin <= 8 ? 2 : 4;
     a.nchunk = (p->Cin + 4 * S - 1) / (4 * S);
     const int mt = a.CoutPad / 16;
@@ -565,7 +580,7 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
     bool found = false;
     for (int sh = 2; sh >= 0 && !found; --sh)
         for (int m : {3, 2, 1}) {
-            if (mt % m != 0) continue;
+            if (mt % m != 0 || (p->split_cout && (p->split_cout / 16) % m != 0)) continue;
             const int64_t b = blocks(sh, m);
             if (b >= 512) { shape = sh; mb = m; found = true; break; }
             if (b > best) { best = b; shape = sh; mb = m; }
@@ -573,7 +588,7 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
     // the weights of the channel block must fit LDS next to at least one input stage: narrow the block
     int rc = 1;
     for (; rc == 1 && mb >= 1; --mb) {
-        if (mt % mb != 0) continue;
+        if (mt % mb != 0 || (p->split_cout && (p->split_cout / 16) % mb != 0)) continue;
         if (S == 1) {
             if (!s1d1) return 1;
             rc = launch_mb<1, 1, 1>(a, mt, mb, shape, stream);
@@ -607,6 +622,7 @@ int itermvs_deconv2d_tile(const itermvs_conv_params* p, hipStream_t stream) {
     a.N = p->N; a.Cin = p->Cin; a.Hin = p->Hin; a.Win = p->Win;
     a.Cout = p->Cout; a.CoutPad = (p->Cout + 15) / 16 * 16; a.Hout = 2 * p->Hin; a.Wout = 2 * p->Win;
     a.pad = 1; a.act = p->act; a.add_mode = 0; a.out_nhwc = 0;
+    a.split = 0; a.act_b = 0; a.out_b = nullptr; a.out_b_sn = 0;
     const int S = p->Cin <= 8 ? 2 : 4;
     a.nchunk = (p->Cin + 4 * S - 1) / (4 * S);
     const int mt = a.CoutPad / 16;

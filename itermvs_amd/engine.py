@@ -87,6 +87,7 @@ class InferenceEngine:
             self._pack_weights()
             dh = "iter_mvs.update.depth_head."
             self.head_w1, self.head_w2 = ops.pack_head_weights(w[dh + "2.weight"], w[dh + "4.weight"])
+            self.pk_zr = ops.MfmaWeight(self.w_zr)
 
     def _pack_weights(self) -> None:
         """Re-lay every conv weight once (BatchNorm already folded): regular convolutions in the
@@ -323,9 +324,9 @@ class InferenceEngine:
                     ops.pack_scores(scores, hx, hx2, HIDDEN + 1)
                 # ConvGRU (module.py:59-66): gate math fused into the conv epilogues
                 zbuf = ws["zbuf"]
-                self._conv(hx, g + "convz.", bias=True, pad=2, dilation=2, act="sigmoid", out=zbuf)
-                self._conv(hx, g + "convr.", bias=True, pad=2, dilation=2, act="gru_rh", aux1=hx[:, :HIDDEN],
-                           out=hx2[:, :HIDDEN])
+                # update and reset gates read the same input: one launch, two results (z -> zbuf, r*h -> hx2)
+                ops.conv2d(hx, self.pk_zr, self.b_zr, pad=2, dilation=2, act="sigmoid", out=zbuf, aux1=hx[:, :HIDDEN],
+                           split=(HIDDEN, "gru_rh", hx2[:, :HIDDEN]))
                 self._conv(hx2, g + "convq.", bias=True, pad=2, dilation=2, act="gru_out", aux1=hx[:, :HIDDEN],
                            aux2=zbuf, out=hx[:, :HIDDEN], out2=hidden)
             else:

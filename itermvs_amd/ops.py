@@ -415,12 +415,14 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
            act: str = "none", add: Optional[Tensor] = None, aux1: Optional[Tensor] = None,
            aux2: Optional[Tensor] = None, out: Optional[Tensor] = None, out2: Optional[Tensor] = None,
            transposed: bool = False, seg_end: Sequence[int] = (), add_up2: bool = False,
-           channels_last_out: bool = False) -> Tensor:
+           channels_last_out: bool = False, split=None) -> Tensor:
     """itermvs_conv2d.  ``weight`` / ``bias``: packed tensor(s) (see pack_conv_weight); pass lists of up to
     three for per-segment weight sets with ``seg_end`` = batch boundaries.  ``add_up2``: ``add`` is the
     half-resolution tensor whose x2 bilinear up-sampling is added (fused F.interpolate).
     ``channels_last_out``: ``out`` is written in channels-last memory format ([N,H,W,C] dense, what the
-    correlation kernels read); ``out2`` can still take the planar copy.  Returns ``out``."""
+    correlation kernels read); ``out2`` can still take the planar copy.
+    ``split`` = (channel, act_b, out_b): output channels from ``channel`` on are a second result with its own
+    activation and destination (two convolutions of one input in one launch).  Returns ``out``."""
     weights = list(weight) if isinstance(weight, (list, tuple)) else [weight]
     biases = list(bias) if isinstance(bias, (list, tuple)) else [bias] * len(weights)
     n, cin, hin, win = x.shape
@@ -440,6 +442,11 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     else:
         span = (ksize - 1) * dilation + 1
         hout, wout = (hin + 2 * pad - span) // stride + 1, (win + 2 * pad - span) // stride + 1
+    cout_total = cout
+    if split is not None:
+        if not (mfma and ksize == 3 and not transposed):
+            raise RuntimeError("conv2d: split results need the tiled matrix-core kernel (3x3 MfmaWeight)")
+        cout = int(split[0])
     if out is None:
         out = torch.empty((n, cout, hout, wout), device=x.device, dtype=torch.float32,
                           memory_format=torch.channels_last if channels_last_out else torch.contiguous_format)
@@ -473,13 +480,19 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
         p.bias[i] = None if bs is None else _dev(bs, "bias").data_ptr()
     for i, e in enumerate(seg_end):
         p.seg_end[i] = e
-    p.N, p.Cin, p.Hin, p.Win, p.Cout = n, cin, hin, win, cout
+    p.N, p.Cin, p.Hin, p.Win, p.Cout = n, cin, hin, win, cout_total
+    if split is not None:
+        ob = split[2]
+        if tuple(ob.shape) != (n, cout_total - cout, hout, wout):
+            raise RuntimeError(f"conv2d: split output has shape {tuple(ob.shape)}, expected {(n, cout_total - cout, hout, wout)}")
+        p.split_cout, p.act_b = cout, ACT[split[1]]
+        p.out_b, p.out_b_sn = _planes(ob, "split output")
     p.ksize, p.stride, p.pad, p.dilation = ksize, stride, pad, dilation
     p.transposed, p.act = int(transposed), ACT[act]
     p.weight_format = (2 if tiled else 1) if mfma else 0
     p.add_mode = int(add_up2)
     if CONV_FLOP_COUNTER["enabled"]:
-        CONV_FLOP_COUNTER["flops"] += 2.0 * n * hout * wout * cout * cin * ksize * ksize / (4.0 if transposed else 1.0)
+        CONV_FLOP_COUNTER["flops"] += 2.0 * n * hout * wout * cout_total * cin * ksize * ksize / (4.0 if transposed else 1.0)
         CONV_FLOP_COUNTER["launches"] += 1
     check(_lib.load().itermvs_conv2d(C.byref(p), _stream()), "itermvs_conv2d")
     return out

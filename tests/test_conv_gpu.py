@@ -134,6 +134,26 @@ def test_transposed_conv_with_skip_and_segments(fmt):
         assert rel_err(got, want) <= 2e-6
 
 
+def test_split_results_gru_gates():
+    """ConvGRU update + reset gates as ONE launch with two results (module.py:61-63): z = sigmoid(conv_z(hx)) and
+    r*h = sigmoid(conv_r(hx)) * h, identical to the two separate launches"""
+    gen = torch.Generator().manual_seed(11)
+    b, hh, ww = 1, 40, 56
+    hx = torch.randn((b, 43, hh, ww), generator=gen).to(DEV)
+    wz, wr = ((torch.randn((32, 43, 3, 3), generator=gen) / (43 * 9) ** 0.5).to(DEV) for _ in range(2))
+    bz, br = (torch.randn((32,), generator=gen).to(DEV) for _ in range(2))
+    h = hx[:, :32]
+    z1 = ops().conv2d(hx, ops().MfmaWeight(wz), bz, pad=2, dilation=2, act="sigmoid")
+    rh1 = ops().conv2d(hx, ops().MfmaWeight(wr), br, pad=2, dilation=2, act="gru_rh", aux1=h)
+    rh2 = torch.empty_like(rh1)
+    z2 = ops().conv2d(hx, ops().MfmaWeight(torch.cat([wz, wr])), torch.cat([bz, br]), pad=2, dilation=2, act="sigmoid",
+                      aux1=h, split=(32, "gru_rh", rh2))
+    assert z2.shape == z1.shape and torch.equal(z2, z1) and torch.equal(rh2, rh1)
+    want_z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=2, dilation=2))
+    want_rh = torch.sigmoid(F.conv2d(hx, wr, br, padding=2, dilation=2)) * h
+    assert rel_err(z2, want_z) <= 2e-5 and rel_err(rh2, want_rh) <= 2e-5
+
+
 @pytest.mark.parametrize("fmt", ["mfma", "valu"])
 def test_segmented_conv_and_channel_slices(fmt):
     gen = torch.Generator().manual_seed(6)
