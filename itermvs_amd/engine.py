@@ -124,9 +124,19 @@ class InferenceEngine:
         return ops.conv2d(x, self.pk["feature_net." + name], self.cbr[name][1], stride=stride, act=act, add=add)
 
     def _res_hip(self, x: Tensor, name: str, stride: int) -> Tensor:
-        y = self._cbr_hip(x, name + "conv1.", stride, "relu")
-        sc = x if stride == 1 else self._cbr_hip(x, name + "downsample.", stride, "none")
-        return self._cbr_hip(y, name + "conv2.", 1, "relu", add=sc)          # relu(x + y), module.py:50
+        if stride == 1:
+            y = self._cbr_hip(x, name + "conv1.", 1, "relu")
+            return self._cbr_hip(y, name + "conv2.", 1, "relu", add=x)      # relu(x + y), module.py:50
+        # stride-2 block: conv1 (+ReLU) and the down-sampling shortcut read the same input -> one launch, two results
+        key = "feature_net." + name + "conv1+downsample"
+        if key not in self.pk:
+            (w1, b1), (wd, bd) = self.cbr[name + "conv1."], self.cbr[name + "downsample."]
+            self.pk[key] = (ops.MfmaWeight(torch.cat([w1, wd])), torch.cat([b1, bd]).contiguous(), w1.shape[0])
+        wt, bias, c = self.pk[key]
+        n, _, hh, ww = x.shape
+        sc = torch.empty((n, c, (hh - 1) // 2 + 1, (ww - 1) // 2 + 1), device=x.device)
+        y = ops.conv2d(x, wt, bias, stride=2, act="relu", split=(c, "none", sc))
+        return self._cbr_hip(y, name + "conv2.", 1, "relu", add=sc)
 
     def feature_net(self, x: Tensor) -> Dict[int, Tensor]:
         """net.py:36-65 with BN folded; x [M,3,H,W] -> NCHW pyramids {1,2,3}."""
