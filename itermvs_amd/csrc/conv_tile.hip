@@ -575,16 +575,38 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
         const int th = shape == 2 && p->stride == 1 ? 8 : 4, tw = shape == 0 ? 16 : 32;
         return (int64_t)((hout + th - 1) / th) * ((wout + tw - 1) / tw) * (mt / mb) * p->N;   // work items
     };
+    // LDS bytes of a candidate when ALL chunks of a tile are staged together (launch_cps picks that when it fits)
+    auto full_stage_fits = [&](int sh, int m) {
+        const int th = sh == 2 && p->stride == 1 ? 8 : 4, tw = sh == 0 ? 16 : 32;
+        const int in_px = ((th - 1) * p->stride + 2 * p->dilation + 1) * ((tw - 1) * p->stride + 2 * p->dilation + 1);
+        const int pl = (in_px * S + 63) / 64 * 64 + (S == 4 ? 0 : S == 2 ? 32 : 16);
+        const int cps = a.nchunk == 4 ? 2 : a.nchunk;
+        return (cps * 4 * pl + a.nchunk * 36 * 16 * m * S) * 4 <= kLdsBudget;
+    };
+    const bool deep = a.nchunk >= 2 && a.nchunk <= 4;
+    static const char* force = getenv("ITERMVS_TILE_FORCE");      // "shape,mb" (experiments)
     int shape = 0, mb = 1;
     int64_t best = -1;
     bool found = false;
-    for (int sh = 2; sh >= 0 && !found; --sh)
-        for (int m : {3, 2, 1}) {
-            if (mt % m != 0 || (p->split_cout && (p->split_cout / 16) % m != 0)) continue;
-            const int64_t b = blocks(sh, m);
-            if (b >= 512) { shape = sh; mb = m; found = true; break; }
-            if (b > best) { best = b; shape = sh; mb = m; }
-        }
+    // multi-chunk layers: prefer candidates that stage a whole tile at once (one barrier pair and one weight
+    // copy per tile instead of one per chunk)
+    for (int pass = deep ? 0 : 1; pass < 2 && !found; ++pass) {
+        best = -1;
+        for (int sh = 2; sh >= 0 && !found; --sh)
+            for (int m : {3, 2, 1}) {
+                if (mt % m != 0 || (p->split_cout && (p->split_cout / 16) % m != 0)) continue;
+                if (pass == 0 && !full_stage_fits(sh, m)) continue;
+                const int64_t b = blocks(sh, m);
+                if (b >= 512) { shape = sh; mb = m; found = true; break; }
+                if (b > best) { best = b; shape = sh; mb = m; }
+            }
+        if (best >= 0) found = true;       // pass 0 found a full-stage candidate (the one with the most work items)
+    }
+    if (force) {
+        shape = force[0] - '0';
+        mb = force[2] - '0';
+        if (shape < 0 || shape > 2 || mb < 1 || mb > 3 || mt % mb != 0) return 1;
+    }
     // the weights of the channel block must fit LDS next to at least one input stage: narrow the block
     int rc = 1;
     for (; rc == 1 && mb >= 1; --mb) {

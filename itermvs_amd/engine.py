@@ -426,15 +426,14 @@ class GraphedRunner:
     def __call__(self, imgs: Tensor, projs: Dict[int, Tensor], depth_min: Tensor, depth_max: Tensor):
         """copy the sample into the static inputs (unless it already IS them) and replay ON THE CURRENT
         STREAM; returns the static (depth, confidence) buffers, valid in stream order like any other torch op"""
-        if imgs is not self.imgs:
-            self.imgs.copy_(imgs, non_blocking=True)
-        for l in self.projs:
-            if projs[l] is not self.projs[l]:
-                self.projs[l].copy_(projs[l], non_blocking=True)
-        if depth_min is not self.depth_min:
-            self.depth_min.copy_(depth_min, non_blocking=True)
-        if depth_max is not self.depth_max:
-            self.depth_max.copy_(depth_max, non_blocking=True)
+        dst, src = [], []
+        for d, t in [(self.imgs, imgs), (self.depth_min, depth_min), (self.depth_max, depth_max)] + \
+                    [(self.projs[l], projs[l]) for l in self.projs]:
+            if t is not d:
+                dst.append(d)
+                src.append(t)
+        if dst:
+            torch._foreach_copy_(dst, src)          # one multi-tensor launch instead of six staging copies
         for i, g in enumerate(self.graphs):
             g.replay()
             if i < len(self.eager_calls):
