@@ -583,7 +583,9 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
         const int cps = a.nchunk == 4 ? 2 : a.nchunk;
         return (cps * 4 * pl + a.nchunk * 36 * 16 * m * S) * 4 <= kLdsBudget;
     };
-    const bool deep = a.nchunk >= 2 && a.nchunk <= 4;
+    // (only for layers of a few hundred tiles, where the per-tile chain of barriers and weight copies is what
+    //  bounds the launch; large layers amortise it over big tiles)
+    const bool deep = a.nchunk >= 2 && a.nchunk <= 4 && blocks(2, 1) < 1024;
     static const char* force = getenv("ITERMVS_TILE_FORCE");      // "shape,mb" (experiments)
     int shape = 0, mb = 1;
     int64_t best = -1;

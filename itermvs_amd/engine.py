@@ -78,7 +78,11 @@ class InferenceEngine:
         self.b_zr = torch.cat([w[g + "convz.bias"], w[g + "convr.bias"]], 0).contiguous()
         self.offsets = sample_offsets()
         self._ws: Dict[tuple, dict] = {}
+        self._side = None          # second HIP stream for the independent branches (_fork / _join)
         import os
+        # measured: 607 depth-maps/s with the two side branches forked vs 628 in one stream (cfg 1) -- the fork/join
+        # dependencies cost more than the ~40 us of overlap they buy; off unless ITERMVS_SIDE_STREAM=1
+        self._use_side = os.environ.get("ITERMVS_SIDE_STREAM", "0") == "1"
         self.backend = backend or os.environ.get("ITERMVS_CONV_BACKEND", "hip")
         if self.backend not in ("hip", "miopen"):
             raise ValueError(f"unknown conv backend {self.backend!r}")
@@ -213,13 +217,30 @@ class InferenceEngine:
         x = F.relu_(F.conv2d(x, w[p + "2.weight"]))
         return F.conv2d(x, w[p + "4.weight"], w[p + "4.bias"])
 
-    def confidence(self, hidden: Tensor) -> Tensor:
+    def confidence(self, hidden: Tensor, mid: Tensor = None, out: Tensor = None) -> Tensor:
         w, p = self.w, "iter_mvs.update.confidence_head."
         if self.backend == "hip":
-            x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu")
-            return self._conv(x, p + "2.", bias=True, ksize=1, pad=0, act="sigmoid")
+            x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu", out=mid)
+            return self._conv(x, p + "2.", bias=True, ksize=1, pad=0, act="sigmoid", out=out)
         x = F.relu_(F.conv2d(hidden, w[p + "0.weight"], padding=2, dilation=2))
         return torch.sigmoid_(F.conv2d(x, w[p + "2.weight"], w[p + "2.bias"]))
+
+    # -- independent branches on a second HIP stream (fork / join; captured as parallel graph branches) --------
+    def _fork(self, fn) -> None:
+        """run ``fn`` on the side stream, ordered after everything enqueued so far on the current stream.
+        ``fn`` must only write pre-allocated workspace buffers (no allocation on the side stream)."""
+        if not self._use_side:
+            return fn()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            fn()
+
+    def _join(self) -> None:
+        if self._use_side and self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
 
     # -- workspace ------------------------------------------------------------------------------
     def _workspace(self, b: int, h: int, w: int) -> dict:
@@ -235,6 +256,11 @@ class InferenceEngine:
                 "agg_all": torch.empty((b * (nx - 1), 8, h, w), device=dev),   # the three levels' CorrNet inputs, back to back
                 "zbuf": torch.empty((b, HIDDEN, h, w), device=dev),
                 "nan_flag": torch.zeros((1,), device=dev, dtype=torch.int32),
+                # outputs / intermediates of the two side branches (allocated here, on the main stream)
+                "up_mid": torch.empty((b, 64, h, w), device=dev),
+                "up_logits": torch.empty((b, 144, h, w), device=dev),
+                "conf_mid": torch.empty((b, HIDDEN, h, w), device=dev),
+                "conf": torch.empty((b, 1, h, w), device=dev),
             }
             o, views = 0, []
             for l in (1, 2, 3):
@@ -277,7 +303,10 @@ class InferenceEngine:
             ref2_nchw = feats[2][:1] if b == 1 else feats[2].view(b, v, *feats[2].shape[1:])[:, 0].contiguous()
         u = "iter_mvs.upsample."
         if self.backend == "hip":
-            up_logits = self._conv(self._conv(ref2_nchw, u + "0.", act="relu"), u + "2.", ksize=1, pad=0)
+            # only needed by the final convex up-sampling: a side branch next to the initialisation chain
+            up_logits = ws["up_logits"]
+            self._fork(lambda: self._conv(self._conv(ref2_nchw, u + "0.", act="relu", out=ws["up_mid"]), u + "2.",
+                                          ksize=1, pad=0, out=up_logits))
         else:
             up_logits = F.conv2d(F.relu_(F.conv2d(ref2_nchw, w[u + "0.weight"], padding=1)), w[u + "2.weight"])
 
@@ -310,6 +339,8 @@ class InferenceEngine:
                          init_score=score0, hidden0=hidden0.clone(), logits0=logits, nd0=hx[:, HIDDEN:HIDDEN + 1].clone(),
                          best0=best, up_logits=up_logits, iters=[])
 
+        if self.backend == "hip":
+            self._join()        # the side branch ends inside this graph segment
         # ---- iterations (itermvs.py:288-324) -----------------------------------------------
         g = "iter_mvs.update.gru."
         conf = None
@@ -346,9 +377,15 @@ class InferenceEngine:
                 ops.gru_rh(zr, hx, hx2, HIDDEN)
                 q = F.conv2d(hx2, w[g + "convq.weight"], w[g + "convq.bias"], padding=2, dilation=2)
                 ops.gru_out(zr, q, hx, hidden, HIDDEN)
-            if it == self.iteration - 1:
-                conf = self.confidence(hidden)                                                  # itermvs.py:197-199
+            last = it == self.iteration - 1
+            if last and self.backend == "hip":                                                  # itermvs.py:197-199
+                conf = ws["conf"]
+                self._fork(lambda: self.confidence(hidden, ws["conf_mid"], conf))               # next to the depth head
+            elif last:
+                conf = self.confidence(hidden)
             logits, best = self.depth_regress(hidden, [(hx, HIDDEN), (hx2, HIDDEN)], trace is not None)
+            if last and self.backend == "hip":
+                self._join()
             if trace is not None:
                 trace["iters"].append(dict(nd_in=nd_in, aggs=[a.clone() for a in aggs], score=torch.cat(scores, 1),
                                            hidden=hidden.clone(), logits=logits, best=best,
