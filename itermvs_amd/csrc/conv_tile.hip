@@ -571,7 +571,7 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
     const int S = p->Cin <= 4 ? 1 : p->Cin <= 8 ? 2 : 4;
     a.nchunk = (p->Cin + 4 * S - 1) / (4 * S);
     const int mt = a.CoutPad / 16;
-    // largest tile / channel blocking that still gives every CU >= 2 workgroups; otherwise the most workgroups
+    // largest tile / channel blocking that still gives every CU >= 4 workgroups; otherwise the most workgroups
     auto blocks = [&](int shape, int mb) -> int64_t {
         const int th = shape == 2 && p->stride == 1 ? 8 : 4, tw = shape == 0 ? 16 : 32;
         return (int64_t)((hout + th - 1) / th) * ((wout + tw - 1) / tw) * (mt / mb) * p->N;   // work items
@@ -588,6 +588,7 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
     //  bounds the launch; large layers amortise it over big tiles)
     const bool deep = a.nchunk >= 2 && a.nchunk <= 4 && blocks(2, 1) < 1024;
     static const char* force = getenv("ITERMVS_TILE_FORCE");      // "shape,mb" (experiments)
+    static const int min_work = [] { const char* e = getenv("ITERMVS_TILE_MINWORK"); return e ? atoi(e) : 1024; }();   // work items wanted: 4 workgroups per CU
     int shape = 0, mb = 1;
     int64_t best = -1;
     bool found = false;
@@ -600,7 +601,7 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
                 if (mt % m != 0 || (p->split_cout && (p->split_cout / 16) % m != 0)) continue;
                 if (pass == 0 && !full_stage_fits(sh, m)) continue;
                 const int64_t b = blocks(sh, m);
-                if (b >= 512) { shape = sh; mb = m; found = true; break; }
+                if (b >= min_work) { shape = sh; mb = m; found = true; break; }
                 if (b > best) { best = b; shape = sh; mb = m; }
             }
         if (best >= 0) found = true;       // pass 0 found a full-stage candidate (the one with the most work items)
