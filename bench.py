@@ -110,8 +110,12 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    # graph mode, one stream: TWO runners replayed alternately on that stream -- while step i runs, the event pairs
+    # embedded in the graph of step i-1 (around its corr_iter / corr_init launches) are read, so every launch of the
+    # timed region is measured without ever draining the stream
+    ab = 2 if (args.streams == 1 and not args.eager) else 1
     models, streams = [], []
-    for _ in range(args.streams):
+    for _ in range(args.streams * ab):
         m = Pipeline(iteration=args.iters, test=True)
         m.load_state_dict(synthetic.random_state_dict(0))
         m.use_graphs = not args.eager
@@ -130,25 +134,43 @@ def main() -> None:
                         s["depth_min"].to(dev), s["depth_max"].to(dev)))
 
     sink = []
+    graph_prof = []                                    # (kind, ms) of the timed region's captured launches
+    n_models = len(models)
+
+    def read_pairs(i: int) -> None:
+        """event pairs of the graph replayed at step i (waits for that replay only)"""
+        runner = next(iter(models[i % n_models]._runners.values()))
+        first, count = runner.profile_pairs
+        got = ops.profile_graph_read(first, count)
+        if i >= args.warmup:
+            graph_prof.extend(got)
 
     def step(i: int) -> None:
         imgs, projs, dmin, dmax = samples[i % n_resident]
-        k = i % args.streams
+        k = i % n_models
         with torch.cuda.stream(streams[k]):
-            out = models[k](imgs, projs, dmin, dmax)      # graph mode: replays on this stream
+            out = models[k](imgs, projs, dmin, dmax)      # graph mode: one hipGraph replay on this stream
         sink[:] = [out["depths_upsampled"], out["confidence_upsampled"]]
+        if ab == 2 and i >= 1:
+            read_pairs(i - 1)
 
-    for k in range(args.streams):                      # set-up, not a step: capture every runner's hipGraph segments
+    # HIP-event pairs around the fused kernels' launches (on their launch stream).  Graph mode: external
+    # event-record nodes captured with the launches (enabled BEFORE the capture below); eager mode: plain records.
+    per_step = args.iters + 1
+    # (graph mode: only the corr_iter launches carry event nodes -- each node costs ~5 us of graph time)
+    ops.profile_enable((args.steps + args.warmup) * per_step + 8 * per_step, mask=0x1 if ab == 2 else 0x3)
+    for k in range(n_models):                          # set-up, not a step: capture every runner's hipGraph
         with torch.cuda.stream(streams[k]):
             models[k](*samples[0])
     torch.cuda.synchronize()
+    ops.profile_collect(max_samples=4096)              # drop the set-up launches' samples
 
-    # HIP-event pairs around the fused kernels' launches (on their launch stream); the samples of
-    # the warm-up steps are dropped so the figures cover exactly the timed region
-    per_step = args.iters + (1 if args.eager else 0)   # graph mode: corr_init is inside a captured segment
-    ops.profile_enable((args.steps + args.warmup) * per_step + 8 * per_step)
     elapsed = shard.timed_steps(step, args.steps, args.warmup)
-    prof = ops.profile_collect(max_samples=(args.steps + args.warmup) * per_step + 8 * per_step)[-args.steps * per_step:]
+    if ab == 2:
+        read_pairs(args.warmup + args.steps - 1)
+        prof = graph_prof
+    else:
+        prof = ops.profile_collect(max_samples=(args.steps + args.warmup) * per_step + 8 * per_step)[-args.steps * per_step:]
     ops.profile_enable(0)
     maps = world * args.steps * args.batch
     value = maps / elapsed
@@ -164,7 +186,8 @@ def main() -> None:
         roofline = {"bound": "hbm", "kernel": "itermvs_corr_iter (corr_iter_kernel<32>)", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": b_iter, "avg_launch_ms": avg_ms, "launches_timed": len(t_iter),
-                    "timing": "hipEvent pairs on the launch stream inside the timed region"}
+                    "timing": ("external hipEvent record nodes around the launch inside the replayed hipGraph, every replay of "
+                               "the timed region read" if ab == 2 else "hipEvent pairs on the launch stream inside the timed region")}
         pmc_file = os.path.join(ROOT, "profiles", "r01_corr_iter_pmc.json")
         if os.path.exists(pmc_file):      # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
             pmc = json.load(open(pmc_file))
@@ -246,7 +269,7 @@ def main() -> None:
                                    f"random-init weights, {args.batch} ref view(s) per step and GPU",
                        "views": args.views, "height": args.height, "width": args.width, "iterations": args.iters,
                        "batch_per_gpu": args.batch, "streams_per_gpu": args.streams,
-                       "launch": "eager" if args.eager else "hipGraph segments + eager corr_iter",
+                       "launch": "eager" if args.eager else "one hipGraph per depth map",
                        "parallelism": f"ref-view sharding x{world}, no collective",
                        "algorithmic_MB_per_depth_map": b_map / 1e6},
             "roofline": roofline,

@@ -302,6 +302,12 @@ int itermvs_profile_enable(int32_t capacity);
  * (kind 3).  Default 0x3. */
 int itermvs_profile_set_mask(int32_t mask);
 int itermvs_profile_collect(int32_t* kind, float* ms, int32_t max_samples);
+/* Launches captured into a hipGraph while profiling is enabled are bracketed by external event-record nodes:
+ * itermvs_profile_graph_count() = number of such pairs so far (capture order);
+ * itermvs_profile_graph_read(first, count, kind, ms) waits for pairs [first, first+count) of the LATEST replay of
+ * their graph and returns how many were read. */
+int itermvs_profile_graph_count(void);
+int itermvs_profile_graph_read(int32_t first, int32_t count, int32_t* kind, float* ms);
 
 #ifdef __cplusplus
 }

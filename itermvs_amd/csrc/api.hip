@@ -1,4 +1,5 @@
 // Library identification, error strings and the optional per-launch timing hooks.
+#include <stdio.h>
 #include <mutex>
 #include <vector>
 
@@ -36,14 +37,57 @@ bool g_enabled = false;
 int g_mask = 0x3;   // kinds 1 (corr_iter) and 2 (corr_init) by default; bit 2 = itermvs_conv2d launches
 }  // namespace
 
-static bool capturing(hipStream_t stream) {   // launches recorded into a hipGraph are not timed
+static bool capturing(hipStream_t stream) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     return hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
 }
 
+// Launches captured into a hipGraph are bracketed by EXTERNAL event-record nodes (hipEventRecordExternal):
+// every replay of the graph re-records the same pair, which itermvs_profile_graph_read turns into that replay's
+// kernel duration (tools/ubench/graph_event_timing.hip: identical to eager event timing).  The pairs live as long
+// as the library; they are created only while profiling is enabled at capture time.
+namespace {
+std::vector<Sample> g_graph;      // pairs embedded in captured graphs, in capture order
+std::vector<Sample> g_graph_free; // created by itermvs_profile_enable (events cannot be created while capturing)
+Sample g_open;                    // pair whose begin was captured and whose end is pending
+bool g_open_valid = false;
+}  // namespace
+
+// An event-record NODE spliced into the stream capture: the graph being captured and its current frontier come
+// from hipStreamGetCaptureInfo_v2, the node is added by hand and made the new frontier.  (hipEventRecordWithFlags(
+// ..., hipEventRecordExternal) does the same in one call on ROCm 7.2 but returns hipErrorInvalidValue with the
+// HIP runtime bundled in the PyTorch 2.10+rocm7.0 wheel, which is the one loaded in a torch process.)
+static bool capture_event_record(hipEvent_t ev, hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t* deps = nullptr;
+    size_t ndeps = 0;
+    hipGraphNode_t node = nullptr;
+    bool ok = hipStreamGetCaptureInfo_v2(stream, &st, &id, &graph, &deps, &ndeps) == hipSuccess &&
+              st == hipStreamCaptureStatusActive && graph != nullptr &&
+              hipGraphAddEventRecordNode(&node, graph, deps, ndeps, ev) == hipSuccess &&
+              hipStreamUpdateCaptureDependencies(stream, &node, 1, hipStreamSetCaptureDependencies) == hipSuccess;
+    if (!ok) {
+        fprintf(stderr, "[itermvs] could not add an event-record node to the captured graph: %s\n",
+                hipGetErrorString(hipGetLastError()));
+    }
+    return ok;
+}
+
 void itermvs_profile_begin(int kind, hipStream_t stream) {
-    if (!g_enabled || !((g_mask >> (kind - 1)) & 1) || capturing(stream)) return;
+    if (!g_enabled || !((g_mask >> (kind - 1)) & 1)) return;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (capturing(stream)) {
+        if (g_graph_free.empty()) return;
+        Sample s = g_graph_free.back();
+        g_graph_free.pop_back();
+        s.kind = kind;
+        if (!capture_event_record(s.t0, stream)) return;
+        g_open = s;
+        g_open_valid = true;
+        return;
+    }
     if (g_used >= (int)g_pool.size()) return;
     g_pool[g_used].kind = kind;
     (void)hipEventRecord(g_pool[g_used].t0, stream);
@@ -52,11 +96,37 @@ void itermvs_profile_begin(int kind, hipStream_t stream) {
 void itermvs_profile_cancel() {}  // a begun sample without an end is simply overwritten by the next begin
 
 void itermvs_profile_end(int kind, hipStream_t stream) {
-    if (!g_enabled || !((g_mask >> (kind - 1)) & 1) || capturing(stream)) return;
+    if (!g_enabled || !((g_mask >> (kind - 1)) & 1)) return;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (capturing(stream)) {
+        if (!g_open_valid || g_open.kind != kind) return;
+        g_open_valid = false;
+        if (!capture_event_record(g_open.t1, stream)) return;
+        g_graph.push_back(g_open);
+        return;
+    }
     if (g_used >= (int)g_pool.size() || g_pool[g_used].kind != kind) return;
     (void)hipEventRecord(g_pool[g_used].t1, stream);
     ++g_used;
+}
+
+extern "C" int itermvs_profile_graph_count(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return (int)g_graph.size();
+}
+
+extern "C" int itermvs_profile_graph_read(int32_t first, int32_t count, int32_t* kind, float* ms) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    for (int i = first; i < first + count && i < (int)g_graph.size() && i >= 0; ++i) {
+        if (hipEventSynchronize(g_graph[i].t1) != hipSuccess) break;
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, g_graph[i].t0, g_graph[i].t1) != hipSuccess) break;
+        if (kind) kind[n] = g_graph[i].kind;
+        if (ms) ms[n] = t;
+        ++n;
+    }
+    return n;
 }
 
 extern "C" int itermvs_profile_set_mask(int32_t mask) {
@@ -74,6 +144,13 @@ extern "C" int itermvs_profile_enable(int32_t capacity) {
     g_pool.clear();
     g_used = 0;
     g_enabled = capacity > 0;
+    // spare pairs for launches captured into hipGraphs while profiling is on (kept by the graphs that use them)
+    while (g_enabled && (int)g_graph_free.size() < 64) {
+        Sample s;
+        s.kind = 0;
+        if (hipEventCreate(&s.t0) != hipSuccess || hipEventCreate(&s.t1) != hipSuccess) return ITERMVS_ERR_LAUNCH;
+        g_graph_free.push_back(s);
+    }
     for (int i = 0; i < capacity; ++i) {
         Sample s;
         s.kind = 0;

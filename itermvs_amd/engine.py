@@ -273,7 +273,7 @@ class InferenceEngine:
 
     # -- one batch of reference views -----------------------------------------------------------
     def run(self, imgs: Tensor, projs: Dict[int, Tensor], depth_min: Tensor, depth_max: Tensor,
-            trace: dict = None, seg=None) -> Tuple[Tensor, Tensor]:
+            trace: dict = None) -> Tuple[Tensor, Tensor]:
         """imgs [B,V,3,H,W]; projs[l] [B,V,4,4] (l = 1..3); depth_min/max [B]
         -> (depth [B,1,H,W], confidence [B,1,H,W]) like itermvs.py:326-327 / net.py:125-128."""
         b, v, _, hh, ww = imgs.shape
@@ -347,9 +347,7 @@ class InferenceEngine:
         for it in range(self.iteration):
             k1 = lambda: ops.corr_iter(src, ref_q, proj, view_w, inv_min, inv_max,
                                        norm_depth=hx[:, HIDDEN:HIDDEN + 1], offsets=self.offsets, out=ws["agg"])
-            # (graph capture: the fused correlation launch stays an eager launch between two captured
-            #  segments so that it can be bracketed by HIP events -- see GraphedRunner)
-            aggs = seg.eager(k1) if seg is not None else k1()
+            aggs = k1()
             nd_in = hx[:, HIDDEN:HIDDEN + 1].clone() if trace is not None else None
             if self.backend == "hip":
                 # three CorrNets: one launch per layer over all 10*B maps; for B = 1 the last layer writes
@@ -403,15 +401,14 @@ class InferenceEngine:
 
 
 class GraphedRunner:
-    """One depth map per replay with (almost) no host work: ``InferenceEngine.run`` captured into hipGraph
-    segments (torch.cuda.CUDAGraph) on a private stream, with static input / output buffers.
+    """One depth map per replay with no host work: ``InferenceEngine.run`` captured into ONE hipGraph
+    (torch.cuda.CUDAGraph) on a private stream, with static input / output buffers.
 
-    The step is split at the ``iteration`` launches of ``itermvs_corr_iter``: those stay eager launches
-    between two captured segments, so bench.py can bracket them with HIP events inside the timed region
-    (event records cannot be timed inside a graph).  A replay is ``iteration + 1`` graph launches plus
-    ``iteration`` direct kernel launches instead of ~120 Python-driven launches; several runners on
-    different streams keep independent reference views in flight on one GPU (replay happens on the caller's
-    current stream; only the capture uses a private stream).
+    A replay is one graph launch instead of ~110 Python-driven kernel launches; several runners on different
+    streams keep independent reference views in flight on one GPU (replay happens on the caller's current
+    stream; only the capture uses a private stream).  When the library's timing hooks are enabled at capture
+    time, the ``itermvs_corr_iter`` launches are bracketed by external event-record nodes inside the graph
+    (``profile_pairs`` = their range for ``ops.profile_graph_read``), so bench.py times them in the timed region.
     Outputs are static buffers, overwritten by the next replay on the same runner."""
 
     def __init__(self, engine: InferenceEngine, imgs: Tensor, projs: Dict[int, Tensor], depth_min: Tensor,
@@ -422,38 +419,20 @@ class GraphedRunner:
         self.proj_stack = torch.stack([projs[1], projs[2], projs[3]]).contiguous()      # static [3,B,V,4,4]
         self.projs = {l: self.proj_stack[l - 1] for l in (1, 2, 3)}
         self.depth_min, self.depth_max = depth_min.clone(), depth_max.clone()
-        self.graphs: List["torch.cuda.CUDAGraph"] = []
-        self.eager_calls = []
         self.key = (tuple(imgs.shape), tuple(depth_min.shape))
         self.stream.wait_stream(torch.cuda.current_stream(imgs.device))
         with torch.cuda.stream(self.stream):
             for _ in range(2):                                  # warm-up: allocates the workspaces, primes caches
                 engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max)
             torch.cuda.synchronize(imgs.device)
-            self._pool = torch.cuda.graph_pool_handle()          # one memory pool shared by all segments
-            self._begin()
-            self.out = engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max, seg=self)
-            self._end()
+            first = ops.profile_graph_count()
+            self.graph = torch.cuda.CUDAGraph()
+            self.graph.capture_begin()
+            self.out = engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max)
+            self.graph.capture_end()
+            self.profile_pairs = (first, ops.profile_graph_count() - first)
         torch.cuda.synchronize(imgs.device)
 
-    # -- capture-time protocol used by InferenceEngine.run ----------------------------------------------
-    def _begin(self):
-        g = torch.cuda.CUDAGraph()
-        g.capture_begin(pool=self._pool)
-        self._cur = g
-
-    def _end(self):
-        self._cur.capture_end()
-        self.graphs.append(self._cur)
-
-    def eager(self, fn):
-        self._end()
-        res = fn()
-        self.eager_calls.append(fn)
-        self._begin()
-        return res
-
-    # -- replay --------------------------------------------------------------------------------------------
     @property
     def static_inputs(self):
         """(imgs, projs, depth_min, depth_max) buffers the graph reads: a producer (data loader, H2D copy)
@@ -474,8 +453,5 @@ class GraphedRunner:
             dst, src = dst[1:], src[1:]
         if dst:
             torch._foreach_copy_(dst, src)          # cameras + depth range: one multi-tensor launch instead of five copies
-        for i, g in enumerate(self.graphs):
-            g.replay()
-            if i < len(self.eager_calls):
-                self.eager_calls[i]()
+        self.graph.replay()
         return self.out

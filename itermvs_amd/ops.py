@@ -508,6 +508,19 @@ def profile_enable(capacity: int, mask: int = 0x3) -> None:
     check(_lib.load().itermvs_profile_enable(capacity), "itermvs_profile_enable")
 
 
+def profile_graph_count() -> int:
+    """event pairs embedded so far in captured hipGraphs (see itermvs_profile_graph_read)"""
+    return _lib.load().itermvs_profile_graph_count()
+
+
+def profile_graph_read(first: int, count: int):
+    """-> list of (kind, milliseconds) of pairs [first, first+count) for the latest replay of their graph (waits)"""
+    kinds = (C.c_int32 * max(count, 1))()
+    ms = (C.c_float * max(count, 1))()
+    n = _lib.load().itermvs_profile_graph_read(first, count, kinds, ms)
+    return [(kinds[i], ms[i]) for i in range(n)]
+
+
 def profile_collect(max_samples: int = 4096):
     """-> list of (kind, milliseconds); kind 1 = corr_iter, 2 = corr_init."""
     kinds = (C.c_int32 * max_samples)()
