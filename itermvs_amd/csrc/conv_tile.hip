@@ -587,7 +587,8 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
     // (only for layers of a few hundred tiles, where the per-tile chain of barriers and weight copies is what
     //  bounds the launch; large layers amortise it over big tiles)
     const bool deep = a.nchunk >= 2 && a.nchunk <= 4 && blocks(2, 1) < 1024;
-    static const char* force = getenv("ITERMVS_TILE_FORCE");      // "shape,mb" (experiments)
+    const char* force = getenv("ITERMVS_TILE_FORCE");             // "shape,mb" (tools/conv_bench.py --sweep)
+    static const bool tuned = [] { const char* e = getenv("ITERMVS_TILE_TUNED"); return !e || e[0] != '0'; }();
     static const int min_work = [] { const char* e = getenv("ITERMVS_TILE_MINWORK"); return e ? atoi(e) : 1024; }();   // work items wanted: 4 workgroups per CU
     int shape = 0, mb = 1;
     int64_t best = -1;
@@ -605,6 +606,24 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
                 if (b > best) { best = b; shape = sh; mb = m; }
             }
         if (best >= 0) found = true;       // pass 0 found a full-stage candidate (the one with the most work items)
+    }
+    // 16+ input channels (S = 4): measured sweep over all (tile shape, channel blocking) pairs on the layers of
+    // the path (tools/conv_bench.py --sweep): the 8x32 tile never wins there.  An even number of channel blocks
+    // runs best as 4x16 tiles with two blocks per wave (the stride-2 stages, 32->32, 48->32, 32->64: -10..-25 %),
+    // an odd one as 4x32 tiles with one block (16->16, 48->48, 48->16); the dilated ConvGRU convolutions as 4x32.
+    if (tuned && S == 4 && !p->split_cout) {
+        if (p->dilation == 2) {
+            if (a.nchunk == 3) { shape = 1; mb = 1; }
+        } else if (mt % 2 == 0) {
+            shape = 0; mb = 2;
+        } else {
+            shape = 1; mb = 1;
+        }
+    } else if (tuned && S == 2 && p->stride == 2 && mt % 2 == 0 && (!p->split_cout || (p->split_cout / 16) % 2 == 0)) {
+        shape = 0; mb = 2;                                                            // 8 -> 16+16, stride 2
+    } else if (tuned && S == 4 && p->split_cout) {
+        if (p->dilation == 2) { shape = 1; mb = 1; }                                  // z / r gates
+        else if ((p->split_cout / 16) % 2 == 0 && mt % 2 == 0) { shape = 0; mb = 2; }  // stride-2 conv + shortcut
     }
     if (force) {
         shape = force[0] - '0';
