@@ -161,6 +161,12 @@ def main() -> None:
     ops.profile_enable((args.steps + args.warmup) * per_step + 8 * per_step, mask=0x1 if ab == 2 else 0x3)
     for k in range(n_models):                          # set-up, not a step: capture every runner's hipGraph
         with torch.cuda.stream(streams[k]):
+            if ab == 2:
+                # an event-record node costs ~5 us of graph time: runner A carries them on iterations 0, 2, ...,
+                # runner B on 1, 3, ... -- every iteration position is sampled in every second replay
+                from itermvs_amd.engine import InferenceEngine
+                models[k]._engine = InferenceEngine(models[k].weights(), models[k].iteration)
+                models[k]._engine.profile_iterations = set(range(k % 2, args.iters, 2))
             models[k](*samples[0])
     torch.cuda.synchronize()
     ops.profile_collect(max_samples=4096)              # drop the set-up launches' samples
@@ -187,7 +193,7 @@ def main() -> None:
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": b_iter, "avg_launch_ms": avg_ms, "launches_timed": len(t_iter),
                     "timing": ("external hipEvent record nodes around the launch inside the replayed hipGraph, every replay of "
-                               "the timed region read" if ab == 2 else "hipEvent pairs on the launch stream inside the timed region")}
+                               "the timed region read; the two alternating runners carry the nodes on even / odd GRU iterations" if ab == 2 else "hipEvent pairs on the launch stream inside the timed region")}
         pmc_file = os.path.join(ROOT, "profiles", "r01_corr_iter_pmc.json")
         if os.path.exists(pmc_file):      # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
             pmc = json.load(open(pmc_file))

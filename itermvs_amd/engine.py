@@ -79,6 +79,7 @@ class InferenceEngine:
         self.offsets = sample_offsets()
         self._ws: Dict[tuple, dict] = {}
         self._side = None          # second HIP stream for the independent branches (_fork / _join)
+        self.profile_iterations = None   # set of iteration indices whose corr_iter launch carries timing events (None = all)
         import os
         # measured: 607 depth-maps/s with the two side branches forked vs 628 in one stream (cfg 1) -- the fork/join
         # dependencies cost more than the ~40 us of overlap they buy; off unless ITERMVS_SIDE_STREAM=1
@@ -345,9 +346,10 @@ class InferenceEngine:
         g = "iter_mvs.update.gru."
         conf = None
         for it in range(self.iteration):
-            k1 = lambda: ops.corr_iter(src, ref_q, proj, view_w, inv_min, inv_max,
-                                       norm_depth=hx[:, HIDDEN:HIDDEN + 1], offsets=self.offsets, out=ws["agg"])
-            aggs = k1()
+            # (bench.py: only the iterations in ``profile_iterations`` get timing events around this launch)
+            timed = self.profile_iterations is None or it in self.profile_iterations
+            aggs = ops.corr_iter(src, ref_q, proj, view_w, inv_min, inv_max, norm_depth=hx[:, HIDDEN:HIDDEN + 1],
+                                 offsets=self.offsets, out=ws["agg"], timed=timed)
             nd_in = hx[:, HIDDEN:HIDDEN + 1].clone() if trace is not None else None
             if self.backend == "hip":
                 # three CorrNets: one launch per layer over all 10*B maps; for B = 1 the last layer writes

@@ -135,7 +135,7 @@ def ref_quarter(ref1: Tensor, ref2: Tensor, ref3: Tensor) -> Tensor:
 def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, view_w: Tensor,
               inv_min: Tensor, inv_max: Tensor, depth: Optional[Dict[int, Tensor]] = None,
               norm_depth: Optional[Tensor] = None, offsets: Optional[Dict[int, Sequence[float]]] = None,
-              out: Optional[List[Tensor]] = None, impl: int = 0) -> List[Tensor]:
+              out: Optional[List[Tensor]] = None, impl: int = 0, timed: bool = True) -> List[Tensor]:
     """itermvs.py:84-120 fused (see include/itermvs_hip.h).  ``src[l]`` = S channels-last maps of
     level l; ``proj`` [3,B,S,12]; ``view_w`` [B,S,H,W]; hypotheses either explicit
     ``depth[l]`` [B,N_l,H,W] or generated from ``norm_depth`` [B,1,H,W] + ``offsets[l]``.
@@ -178,7 +178,12 @@ def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, vie
     view_w = _dev(view_w, "view_w").contiguous()
     p.ref_q, p.proj, p.view_w = _dev(ref_q, "ref_q").data_ptr(), proj.data_ptr(), view_w.data_ptr()
     p.inv_depth_min, p.inv_depth_max = _dev(inv_min, "inv_min").data_ptr(), _dev(inv_max, "inv_max").data_ptr()
-    check(_lib.load().itermvs_corr_iter(C.byref(p), _stream()), "itermvs_corr_iter")
+    lib = _lib.load()
+    if not timed:               # no timing events around this launch (itermvs_profile_*): mask bit 0 off for the call
+        lib.itermvs_profile_set_mask(_PROFILE_MASK[0] & ~1)
+    check(lib.itermvs_corr_iter(C.byref(p), _stream()), "itermvs_corr_iter")
+    if not timed:
+        lib.itermvs_profile_set_mask(_PROFILE_MASK[0])
     return outs
 
 
@@ -502,8 +507,12 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
 CONV_FLOP_COUNTER = {"enabled": False, "flops": 0.0, "launches": 0}
 
 
+_PROFILE_MASK = [0x3]
+
+
 def profile_enable(capacity: int, mask: int = 0x3) -> None:
     """mask: bit 0 corr_iter, bit 1 corr_init, bit 2 every itermvs_conv2d launch"""
+    _PROFILE_MASK[0] = mask
     check(_lib.load().itermvs_profile_set_mask(mask), "itermvs_profile_set_mask")
     check(_lib.load().itermvs_profile_enable(capacity), "itermvs_profile_enable")
 
