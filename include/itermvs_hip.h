@@ -165,6 +165,12 @@ int itermvs_view_aggregate(const float* corr, const float* w, int32_t S, int32_t
  *   out[m,p] = max_n softmax_n(x[m,n,p]);  x [M,N,P] contiguous, out [M,P]. */
 int itermvs_softmax_max(const float* x, int32_t M, int32_t N, int32_t P, float* out, void* stream);
 
+/* itermvs_pvw_tail -- models/itermvs.py:343-348 (PixelViewWeight after its 3x3 layer), fused:
+ *   out[m,p] = max_n softmax_n( sum_c w[c] * x[m*N+n, c, p] + bias )
+ * x [M*N, C, P] planes (C = 16, N <= 32), w [C], bias [1] or NULL, out [M,P]. */
+int itermvs_pvw_tail(const float* x, const float* w, const float* bias, int32_t M, int32_t N, int32_t C,
+                     int32_t P, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * itermvs_prob_regress -- models/itermvs.py:171-190 and :201-219
  *   p = softmax(logits over 256 bins); k* = first argmax p; window k*-4..k*+4 clamped to

@@ -431,9 +431,69 @@ __global__ void softmax_max_kernel(const float* __restrict__ x, int M, int N, in
     out[t] = 1.0f / sum;
 }
 
+// PixelViewWeight tail (itermvs.py:343-348): 1x1 convolution C -> 1 (+bias), softmax over the N hypotheses, max.
+// x [M*N, C, P] planes (output of the 3x3 layer).  A block owns 64 pixels of one m; wave g evaluates the logits
+// of hypotheses g*N/8 .. (g+1)*N/8 - 1 (64 coalesced plane loads per lane for N = 32, C = 16), the eight waves
+// combine max and sum through LDS.  Replaces a 1x1 convolution launch + softmax_max_kernel (two passes of
+// strided loads by only M*P threads).
+template <int C, int NPW>
+__global__ void __launch_bounds__(512) pvw_tail_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, int N, int P,
+                                                       float* __restrict__ out) {
+    __shared__ float red[8][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int m = blockIdx.y;
+    const int p = blockIdx.x * 64 + lane;
+    const bool live = p < P;
+    const float b0 = bias ? bias[0] : 0.0f;
+    float wt[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) wt[c] = w[c];
+    float v[NPW];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int n = g * NPW + i;
+        const float* xp = x + ((size_t)(m * N + n) * C) * P + (live ? p : 0);
+        float acc = b0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc = fmaf(xp[(size_t)c * P], wt[c], acc);
+        v[i] = n < N ? acc : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    red[g][lane] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mx = fmaxf(mx, red[k][lane]);
+    __syncthreads();
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) sum += expf(v[i] - mx);
+    red[g][lane] = sum;
+    __syncthreads();
+    if (g == 0 && live) {
+        float tot = red[0][lane];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) tot += red[k][lane];
+        out[(size_t)m * P + p] = 1.0f / tot;      // the largest probability belongs to the largest logit: exp(0) / sum
+    }
+}
+
 }  // namespace itermvs
 
 using namespace itermvs;
+
+extern "C" int itermvs_pvw_tail(const float* x, const float* w, const float* bias, int32_t M, int32_t N, int32_t C,
+                                int32_t P, float* out, void* stream) {
+    ITERMVS_RETURN_IF(!x || !w || !out, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(M < 1 || P < 1 || N < 1 || N > 32, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(C != 16, ITERMVS_ERR_CHANNELS);
+    const dim3 grid((P + 63) / 64, M);
+    if (N <= 8) hipLaunchKernelGGL((pvw_tail_kernel<16, 1>), grid, dim3(512), 0, (hipStream_t)stream, x, w, bias, N, P, out);
+    else if (N <= 16) hipLaunchKernelGGL((pvw_tail_kernel<16, 2>), grid, dim3(512), 0, (hipStream_t)stream, x, w, bias, N, P, out);
+    else hipLaunchKernelGGL((pvw_tail_kernel<16, 4>), grid, dim3(512), 0, (hipStream_t)stream, x, w, bias, N, P, out);
+    return itermvs_launch_status();
+}
 
 int itermvs_corr_iter_lds(const itermvs_corr_iter_params* p, hipStream_t stream);  // corr_lds.hip
 

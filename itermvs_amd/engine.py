@@ -321,11 +321,12 @@ class InferenceEngine:
         pv = "iter_mvs.evaluation.pixel_view_weight."
         if self.backend == "hip":
             x = self._conv(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), pv + "conv.0.conv.", act="relu")
-            x = self._conv(x, pv + "conv.1.", bias=True, ksize=1, pad=0)
+            vw = ops.pvw_tail(x, w[pv + "conv.1.weight"], w[pv + "conv.1.bias"], INIT_SAMPLES)     # 1x1 + softmax + max
         else:
             x = F.relu_(F.conv2d(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), w[pv + "conv.0.conv.weight"], padding=1))
             x = F.conv2d(x, w[pv + "conv.1.weight"], w[pv + "conv.1.bias"])
-        vw = ops.softmax_max(x.view(b * s, INIT_SAMPLES, h3, w3))                               # [B*S,1,h3,w3]
+        if self.backend != "hip":
+            vw = ops.softmax_max(x.view(b * s, INIT_SAMPLES, h3, w3))                           # [B*S,1,h3,w3]
         view_w = ops.bilinear_up(vw, 2).view(b, s, h, wd)                                       # itermvs.py:56-57,71
         agg0 = ops.view_aggregate(corr_v, vw.view(b, s, h3, w3))                                # [B,32,8,h3,w3]
         score0 = self.corr_net(agg0.view(b * INIT_SAMPLES, 8, h3, w3), 3).view(b, INIT_SAMPLES, h3, w3)

@@ -221,6 +221,20 @@ def view_aggregate(corr: Tensor, w: Tensor) -> Tensor:
     return out
 
 
+def pvw_tail(x: Tensor, weight: Tensor, bias: Optional[Tensor], n_hyp: int) -> Tensor:
+    """itermvs.py:343-348 fused: x [M*N,16,h,w] (after the 3x3 layer + ReLU), weight [1,16,1,1] -> [M,1,h,w]."""
+    _dev(x, "x")
+    mn, c, h, w = x.shape
+    if mn % n_hyp or not x.is_contiguous():
+        raise RuntimeError("pvw_tail: x must be contiguous [M*N,C,H,W]")
+    m = mn // n_hyp
+    out = torch.empty((m, 1, h, w), device=x.device, dtype=torch.float32)
+    wv = _dev(weight, "weight").reshape(-1).contiguous()
+    check(_lib.load().itermvs_pvw_tail(x.data_ptr(), wv.data_ptr(), _ptr(bias), m, n_hyp, c, h * w, out.data_ptr(), _stream()),
+          "itermvs_pvw_tail")
+    return out
+
+
 def softmax_max(x: Tensor) -> Tensor:
     """itermvs.py:347-348.  x [M,N,H,W] -> max over N of softmax over N, [M,1,H,W]."""
     x = _dev(x, "x").contiguous()

@@ -152,6 +152,21 @@ def test_softmax_max():
     assert maxdiff(ops().softmax_max(cu(x)), want) <= 1e-6
 
 
+@pytest.mark.parametrize("shape", [(4, 32, 16, 20), (3, 32, 7, 9), (2, 16, 8, 12), (5, 5, 8, 12)])
+def test_pvw_tail_fused(shape):
+    """PixelViewWeight's 1x1 layer + softmax over the hypotheses + max in one launch (itermvs.py:343-348)"""
+    m, n, h, w = shape
+    gen = torch.Generator().manual_seed(m * 10 + n)
+    x = torch.relu(torch.randn((m * n, 16, h, w), generator=gen))
+    wt = torch.randn((1, 16, 1, 1), generator=gen) * 0.7
+    b = torch.randn((1,), generator=gen)
+    logits = F.conv2d(x, wt, b).view(m, n, h, w)
+    want = torch.softmax(logits, 1).max(1, keepdim=True)[0]
+    got = ops().pvw_tail(cu(x), cu(wt), cu(b), n)
+    assert got.shape == (m, 1, h, w) and maxdiff(got, want) <= 2e-6
+    assert maxdiff(ops().pvw_tail(cu(x), cu(wt), None, n), torch.softmax(F.conv2d(x, wt).view(m, n, h, w), 1).max(1, keepdim=True)[0]) <= 2e-6
+
+
 @pytest.mark.parametrize("tag", ["seed0", "dtu"])
 @pytest.mark.parametrize("mode", ["explicit", "generated"])
 @pytest.mark.parametrize("impl", [1, 2])
