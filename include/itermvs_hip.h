@@ -237,6 +237,11 @@ int itermvs_convex_upsample(const float* logits, int64_t sb, int64_t sc, int64_t
  * (hidden_init, itermvs.py:162). */
 int itermvs_bilinear_up(const float* x, int32_t M, int32_t H, int32_t W, int32_t scale,
                         int32_t act, float* out, void* stream);
+/* same for x [B,C,H,W] with up to two destinations given as [C,sH,sW] planes at batch strides out_sb / out2_sb
+ * (elements): lets the initial hidden state (itermvs.py:161-163) land in `hidden` and in channels 0..31 of the
+ * GRU input buffer in one launch.  out2 may be NULL. */
+int itermvs_bilinear_up2(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, int32_t scale, int32_t act,
+                         float* out, int64_t out_sb, float* out2, int64_t out2_sb, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * itermvs_conv2d -- the small-channel 2-D convolutions of the path, with fused epilogues:

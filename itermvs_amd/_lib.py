@@ -97,6 +97,7 @@ PROTOTYPES = {
     "itermvs_convex_upsample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "itermvs_bilinear_up2": (C.c_int, [C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "itermvs_bilinear_up": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                       C.c_void_p]),
     "itermvs_conv2d": (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),

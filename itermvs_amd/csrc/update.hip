@@ -237,9 +237,52 @@ __global__ void bilinear_up_kernel(const float* __restrict__ x, int M, int H, in
     out[t] = v;
 }
 
+// bilinear_up with up to two destinations addressed by batch strides (channel slices of wider buffers):
+// the initial hidden state goes to `hidden` and to channels 0..31 of the GRU input buffer in one launch
+__global__ void bilinear_up2_kernel(const float* __restrict__ x, int B, int C, int H, int W, int scale, int act,
+                                    float* __restrict__ out, int64_t out_sb, float* __restrict__ out2, int64_t out2_sb) {
+    const int OH = H * scale, OW = W * scale;
+    const int64_t per = (int64_t)C * OH * OW;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)B * per) return;
+    const int b = (int)(t / per);
+    const int64_t r = t - (int64_t)b * per;
+    const int ox = (int)(r % OW);
+    const int oy = (int)((r / OW) % OH);
+    const int c = (int)(r / ((int64_t)OW * OH));
+    const float rs = 1.0f / (float)scale;
+    float sy = ((float)oy + 0.5f) * rs - 0.5f;
+    float sx = ((float)ox + 0.5f) * rs - 0.5f;
+    sy = sy < 0.0f ? 0.0f : sy;
+    sx = sx < 0.0f ? 0.0f : sx;
+    int y0 = (int)sy, x0 = (int)sx;
+    y0 = y0 > H - 1 ? H - 1 : y0;
+    x0 = x0 > W - 1 ? W - 1 : x0;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+    const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    const float* xm = x + ((size_t)b * C + c) * H * W;
+    const float top = xm[(size_t)y0 * W + x0] * lx0 + xm[(size_t)y0 * W + x1] * lx1;
+    const float bot = xm[(size_t)y1 * W + x0] * lx0 + xm[(size_t)y1 * W + x1] * lx1;
+    float v = top * ly0 + bot * ly1;
+    if (act == 1) v = tanhf(v);
+    out[b * out_sb + r] = v;
+    if (out2) out2[b * out2_sb + r] = v;
+}
+
 }  // namespace itermvs
 
 using namespace itermvs;
+
+extern "C" int itermvs_bilinear_up2(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, int32_t scale, int32_t act,
+                                    float* out, int64_t out_sb, float* out2, int64_t out2_sb, void* stream) {
+    ITERMVS_RETURN_IF(!x || !out, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(B < 1 || C < 1 || H < 1 || W < 1 || scale < 1, ITERMVS_ERR_DIMS);
+    const int64_t total = (int64_t)B * C * H * W * scale * scale;
+    hipLaunchKernelGGL(bilinear_up2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       B, C, H, W, scale, act, out, out_sb, out2, out2_sb);
+    return itermvs_launch_status();
+}
 
 extern "C" int itermvs_prob_regress(const float* logits, int64_t sb, int64_t sc, int64_t sp, int32_t B, int32_t P,
                                     float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, float* prob,

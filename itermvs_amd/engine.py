@@ -335,9 +335,12 @@ class InferenceEngine:
             x = self._conv(self._conv(score0, hi + "0.", act="relu"), hi + "2.", bias=True, ksize=1, pad=0)
         else:
             x = F.conv2d(F.relu_(F.conv2d(score0, w[hi + "0.weight"], padding=1)), w[hi + "2.weight"], w[hi + "2.bias"])
-        hidden0 = ops.bilinear_up(x, 2, act="tanh")                                             # itermvs.py:161-163
-        hidden.copy_(hidden0)
-        hx[:, :HIDDEN].copy_(hidden0)
+        if self.backend == "hip":                                                               # itermvs.py:161-163
+            hidden0 = ops.bilinear_up_into(x, 2, hidden, hx[:, :HIDDEN], act="tanh")            # both copies in one launch
+        else:
+            hidden0 = ops.bilinear_up(x, 2, act="tanh")
+            hidden.copy_(hidden0)
+            hx[:, :HIDDEN].copy_(hidden0)
         logits, best = self.depth_regress(hidden, [(hx, HIDDEN), (hx2, HIDDEN)], trace is not None)
         if trace is not None:
             trace.update(feats=feats, proj=proj, ref_q=ref_q, corr_views=corr_v, view_weights=view_w, init_agg=agg0,

@@ -363,6 +363,21 @@ def convex_upsample(logits: Tensor, nd: Tensor, inv_min: Tensor, inv_max: Tensor
     return (depth, norm) if want_norm else depth
 
 
+def bilinear_up_into(x: Tensor, scale: int, out: Tensor, out2: Optional[Tensor] = None, act: str = "none") -> Tensor:
+    """F.interpolate(x, scale_factor=scale, 'bilinear') (+tanh) written into ``out`` and ``out2`` -- [B,C,sH,sW] views with
+    dense planes, e.g. channel slices of wider buffers (itermvs_bilinear_up2)."""
+    x = _dev(x, "x").contiguous()
+    b, c, h, w = x.shape
+    for t in (out, out2):
+        if t is not None and tuple(t.shape) != (b, c, h * scale, w * scale):
+            raise RuntimeError(f"bilinear_up_into: destination has shape {tuple(t.shape)}")
+    po, so = _planes(out, "out")
+    p2, s2 = _planes(out2, "out2") if out2 is not None else (None, 0)
+    check(_lib.load().itermvs_bilinear_up2(x.data_ptr(), b, c, h, w, scale, 1 if act == "tanh" else 0, po, so, p2, s2, _stream()),
+          "itermvs_bilinear_up2")
+    return out
+
+
 def bilinear_up(x: Tensor, scale: int, act: str = "none") -> Tensor:
     """F.interpolate(x, scale_factor=scale, mode='bilinear') (+ tanh): x [B,C,H,W] -> [B,C,sH,sW]."""
     x = _dev(x, "x").contiguous()

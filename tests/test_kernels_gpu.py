@@ -145,6 +145,17 @@ def test_corr_init_and_aggregate(tag):
     assert maxdiff(agg, want) <= 5e-5 * max(1.0, float(want.abs().max()))
 
 
+def test_bilinear_up_into_two_destinations():
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn((2, 32, 9, 11), generator=gen)
+    want = torch.tanh(F.interpolate(x, scale_factor=2, mode="bilinear"))
+    a = torch.zeros((2, 32, 18, 22), device=DEV)
+    wide = torch.zeros((2, 43, 18, 22), device=DEV)
+    ops().bilinear_up_into(cu(x), 2, a, wide[:, :32], act="tanh")
+    assert maxdiff(a, want) <= 1e-6 and torch.equal(wide[:, :32], a) and float(wide[:, 32:].abs().max()) == 0.0
+    assert torch.equal(a, ops().bilinear_up(cu(x), 2, act="tanh"))
+
+
 def test_softmax_max():
     gen = torch.Generator().manual_seed(9)
     x = torch.randn((6, 32, 8, 12), generator=gen) * 3
