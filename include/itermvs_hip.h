@@ -302,6 +302,22 @@ typedef struct itermvs_conv_params {
 int itermvs_conv2d(const itermvs_conv_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * itermvs_fuse_depth -- the filter that follows the depth-inference path:
+ *   reproject_with_depth (eval.py:154-194), check_geometric_consistency (eval.py:197-212) and the per-reference
+ *   arithmetic of filter_depth (eval.py:238-269) for ONE reference view against its S source views, one pass.
+ * depth_ref / conf_ref [H,W] fp32; depth_src: HOST array of S device pointers to [H,W] fp32 depth maps;
+ * mats: device [S][60] fp32 = per pair  inv(K_ref)(9) | (E_src inv(E_ref)) rows 0..2 (12) | K_src(9) | inv(K_src)(9) |
+ *   (E_ref inv(E_src)) rows 0..2 (12) | K_ref(9), inverted / composed on the host in float32 like eval.py does.
+ * Outputs: depth_avg [H,W] fp64 = (sum of consistent reprojected depths + depth_ref) / (count + 1); optional uint8
+ *   masks photo (conf > photo_thres), geo (count >= geo_mask_thres), final (both); optional int32 count.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_fuse_depth(const float* depth_ref, const float* conf_ref, const float* const* depth_src,
+                       const float* mats, int32_t S, int32_t H, int32_t W, double geo_pixel_thres,
+                       float geo_depth_thres, float photo_thres, int32_t geo_mask_thres, double* depth_avg,
+                       uint8_t* photo_mask, uint8_t* geo_mask, uint8_t* final_mask, int32_t* geo_sum,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optional per-launch timing (HIP events recorded on the launch stream around the kernels of
  * itermvs_corr_iter / itermvs_corr_init).  Used by bench.py for the roofline figure.
  * itermvs_profile_enable(n) allocates n event pairs (n = 0 disables and frees);

@@ -103,6 +103,9 @@ PROTOTYPES = {
     "itermvs_conv2d": (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
     "itermvs_profile_enable": (C.c_int, [C.c_int32]),
     "itermvs_profile_set_mask": (C.c_int, [C.c_int32]),
+    "itermvs_fuse_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                     C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     "itermvs_profile_graph_count": (C.c_int, []),
     "itermvs_profile_graph_read": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "itermvs_profile_collect": (C.c_int, [C.POINTER(C.c_int32), c_float_p, C.c_int32]),

@@ -536,6 +536,29 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
 CONV_FLOP_COUNTER = {"enabled": False, "flops": 0.0, "launches": 0}
 
 
+def fuse_depth(depth_ref: Tensor, conf_ref: Tensor, depth_src: Sequence[Tensor], mats: Tensor, geo_pixel_thres: float = 1.0,
+               geo_depth_thres: float = 0.01, photo_thres: float = 0.3, geo_mask_thres: int = 3):
+    """itermvs_fuse_depth (eval.py:154-269 for one reference view).  depth_ref / conf_ref [H,W], depth_src: S maps [H,W],
+    mats [S,60] (itermvs_amd.fusion.pair_matrices).  -> (depth_avg float64 [H,W], photo, geo, final uint8, count int32)."""
+    h, w = depth_ref.shape
+    s = len(depth_src)
+    depth_ref, conf_ref = _dev(depth_ref, "depth_ref").contiguous(), _dev(conf_ref, "conf_ref").contiguous()
+    srcs = [_dev(t, "depth_src").contiguous() for t in depth_src]
+    if any(tuple(t.shape) != (h, w) for t in srcs + [conf_ref]) or tuple(mats.shape) != (s, 60):
+        raise RuntimeError("fuse_depth: all maps must be [H,W] and mats [S,60]")
+    mats = _dev(mats, "mats").float().contiguous()
+    ptrs = (C.c_void_p * s)(*[t.data_ptr() for t in srcs])
+    dev = depth_ref.device
+    avg = torch.empty((h, w), device=dev, dtype=torch.float64)
+    photo, geo, final = (torch.empty((h, w), device=dev, dtype=torch.uint8) for _ in range(3))
+    cnt = torch.empty((h, w), device=dev, dtype=torch.int32)
+    check(_lib.load().itermvs_fuse_depth(depth_ref.data_ptr(), conf_ref.data_ptr(), ptrs, mats.data_ptr(), s, h, w,
+                                         float(geo_pixel_thres), float(geo_depth_thres), float(photo_thres), int(geo_mask_thres),
+                                         avg.data_ptr(), photo.data_ptr(), geo.data_ptr(), final.data_ptr(), cnt.data_ptr(),
+                                         _stream()), "itermvs_fuse_depth")
+    return avg, photo, geo, final, cnt
+
+
 _PROFILE_MASK = [0x3]
 
 
