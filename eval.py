@@ -9,7 +9,9 @@ for the MI355X engine.  Same flags, checkpoint format and output layout
 Each rank takes the reference views ``rank, rank + world, ...`` (no collective on the data path).
 ``--dataset module:Class`` accepts any dataset yielding the reference's sample dict
 (datasets/dtu_yao_eval.py:154-158); the reference's own loaders (cv2 / PIL based) are outside this
-repository's scope.  The filter/fusion stage of the reference's eval.py is the next row of the build.
+repository's scope.  ``--filter`` runs the reference's filter / fusion stage (eval.py:215-325) afterwards: for every scan
+folder under ``--testpath`` that has a ``pair.txt`` and ``cams_1/``, the depth / confidence PFMs written above are fused
+into ``<outdir>/<scan>.ply`` by ``itermvs_amd.fusion.filter_depth`` (one HIP launch per reference view).
 """
 from __future__ import annotations
 
@@ -49,6 +51,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--geo_depth_thres", type=float, default=0.01)
     p.add_argument("--photo_thres", type=float, default=0.3)
     p.add_argument("--num_samples", type=int, default=8, help="synthetic dataset: number of reference views")
+    p.add_argument("--filter", action="store_true", help="fuse the saved depth maps of every scan into a point cloud (eval.py:311-325)")
     return p
 
 
@@ -133,7 +136,29 @@ def save_depth(args) -> int:
     return done
 
 
+def fuse_scans(args) -> int:
+    """eval.py:311-325: one point cloud per scan; scans are sharded over the ranks like the reference views"""
+    from itermvs_amd import fusion
+    rank, local_rank, world = shard.init_distributed()
+    dev = "cuda:%d" % local_rank
+    scans = sorted(d for d in os.listdir(args.testpath)
+                   if os.path.isfile(os.path.join(args.testpath, d, "pair.txt")) and os.path.isdir(os.path.join(args.outdir, d)))
+    n = 0
+    for i in shard.shard_indices(len(scans), rank, world):
+        scan = scans[i]
+        stats = fusion.filter_depth(os.path.join(args.testpath, scan), os.path.join(args.outdir, scan),
+                                    os.path.join(args.outdir, scan + ".ply"), args.geo_pixel_thres, args.geo_depth_thres,
+                                    args.photo_thres, device=dev)
+        for v, (g, ph, f) in stats.items():
+            print("processing {}, ref-view{:0>2}, geo_mask:{:3f} photo_mask:{:3f} final_mask: {:3f}".format(scan, v, g, ph, f))
+        n += 1
+    shard.barrier()
+    return n
+
+
 if __name__ == "__main__":
     a = build_parser().parse_args()
     print("argv:", sys.argv[1:])
     save_depth(a)
+    if a.filter:
+        fuse_scans(a)
