@@ -13,7 +13,7 @@ import sys
 
 root, needle, out = sys.argv[1:4]
 vals = collections.defaultdict(list)
-for f in glob.glob(f"{root}/*/*counter_collection.csv"):
+for f in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if needle in r["Kernel_Name"]:
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -24,6 +24,6 @@ if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
     res["fetch_bytes_corrected"] = mean["FETCH_SIZE"] * 2 * 1024
     res["write_bytes"] = mean["WRITE_SIZE"] * 1024
 res["workload"] = [5, 512, 640, 1]
-res["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --steps 3 --warmup 2`, FETCH_SIZE x2 per MI355X_MICROARCH.md"
+res["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --steps 3 --warmup 2 --eager`, FETCH_SIZE x2 per MI355X_MICROARCH.md"
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
