@@ -1,5 +1,13 @@
-import os, sys, torch
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""VALU one-thread-per-pixel convolution vs the matrix-core kernels on the layers with almost no contraction
+(3->8 full resolution, 8->8 / 8->1 CorrNet, 8->16 PixelViewWeight); hipGraph replays of 20 launches (GPU box only).
+Result that set engine._pack_weights: VALU wins for 3->8 (31 vs 39 us) and 8->1 (6.7 vs 10.2 us), loses elsewhere."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from itermvs_amd import ops
 dev = torch.device("cuda")
 gen = torch.Generator().manual_seed(0)
