@@ -150,18 +150,27 @@ class InferenceEngine:
         """net.py:36-65 with BN folded; x [M,3,H,W] -> NCHW pyramids {1,2,3}."""
         w, p = self.w, "feature_net."
         if self.backend == "hip":
-            f0 = self._cbr_hip(x, "conv1.", 1, "relu")
-            f1 = self._res_hip(self._res_hip(f0, "layer1.0.", 2), "layer1.1.", 1)
-            f2 = self._res_hip(self._res_hip(f1, "layer2.0.", 2), "layer2.1.", 1)
-            f3 = self._res_hip(self._res_hip(f2, "layer3.0.", 2), "layer3.1.", 1)
-            # the three outputs are written channels-last (the layout the correlation kernels gather from);
-            # level 2 also keeps a planar copy for the up-sampling head (itermvs.py:262)
-            o3 = self._conv(f3, p + "output3.", bias=True, channels_last_out=True)
-            mid = self._conv(f2, p + "inner2.", bias=True, ksize=1, pad=0, add=f3, add_up2=True)   # net.py:46 (fused F.interpolate)
-            self.o2_planar = torch.empty((mid.shape[0], self.w[p + "output2.bias"].shape[0], *mid.shape[2:]), device=mid.device)
-            o2 = self._conv(mid, p + "output2.", bias=True, channels_last_out=True, out2=self.o2_planar)
-            mid = self._conv(f1, p + "inner1.", bias=True, ksize=1, pad=0, add=mid, add_up2=True)  # net.py:49
-            o1 = self._conv(mid, p + "output1.", bias=True, channels_last_out=True)
+            m, _, hh, ww = x.shape
+            dev = x.device
+            cl = lambda c, s: torch.empty((m, c, hh // s, ww // s), device=dev, memory_format=torch.channels_last)
+            o1, o2, o3 = cl(16, 2), cl(32, 4), cl(48, 8)
+            self.o2_planar = torch.empty((m, 32, hh // 4, ww // 4), device=dev)
+
+            def branch(lo: int, hi: int) -> None:
+                """views lo..hi-1 through the pyramid; the three outputs land in their batch slices (channels-last, the
+                layout the correlation kernels gather from; level 2 also keeps a planar copy for the up-sampling head)"""
+                f0 = self._cbr_hip(x[lo:hi], "conv1.", 1, "relu")
+                f1 = self._res_hip(self._res_hip(f0, "layer1.0.", 2), "layer1.1.", 1)
+                f2 = self._res_hip(self._res_hip(f1, "layer2.0.", 2), "layer2.1.", 1)
+                f3 = self._res_hip(self._res_hip(f2, "layer3.0.", 2), "layer3.1.", 1)
+                self._conv(f3, p + "output3.", bias=True, channels_last_out=True, out=o3[lo:hi])
+                mid = self._conv(f2, p + "inner2.", bias=True, ksize=1, pad=0, add=f3, add_up2=True)   # net.py:46 (fused F.interpolate)
+                self._conv(mid, p + "output2.", bias=True, channels_last_out=True, out=o2[lo:hi], out2=self.o2_planar[lo:hi])
+                mid = self._conv(f1, p + "inner1.", bias=True, ksize=1, pad=0, add=mid, add_up2=True)  # net.py:49
+                self._conv(mid, p + "output1.", bias=True, channels_last_out=True, out=o1[lo:hi])
+
+            # (running two groups of views on two streams was measured: 694 vs 707 depth-maps/s -- not kept)
+            branch(0, m)
             return {1: o1, 2: o2, 3: o3}
         f0 = self._cbr(x, "conv1.", 1, True)
         f1 = self._res(self._res(f0, "layer1.0.", 2), "layer1.1.", 1)
