@@ -199,6 +199,13 @@ int itermvs_head_regress(const float* x, int64_t x_sb, int32_t B, int32_t P, con
                          const float* w2_packed, const float* bias2, float* nd_out0, int64_t nd_sb0,
                          float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream);
 
+/* itermvs_head_fused -- the whole depth head in one launch: its first layer (3x3, dilation 2, 32 -> 32, ReLU; weights in
+ * itermvs_conv2d's weight_format 2 = [9][2][4][32][4]) evaluated from an LDS tile of `hidden` [B,32,H,W] (planes, batch
+ * stride hidden_sb) and chained in registers into itermvs_head_regress (models/itermvs.py:121-126, 171-190, 201-219). */
+int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W,
+                       const float* w0_tile, const float* w1_packed, const float* w2_packed, const float* bias2,
+                       float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * ConvGRU gates -- models/module.py:59-66 (the three 3x3 dilated convolutions stay in MIOpen)
  * itermvs_gru_rh :  rh[b,c,p] = sigmoid(zr[b,32+c,p]) * h[b,c,p]           (r * h, :63-64)

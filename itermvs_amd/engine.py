@@ -84,6 +84,7 @@ class InferenceEngine:
         # measured: 607 depth-maps/s with the two side branches forked vs 628 in one stream (cfg 1) -- the fork/join
         # dependencies cost more than the ~40 us of overlap they buy; off unless ITERMVS_SIDE_STREAM=1
         self._use_side = os.environ.get("ITERMVS_SIDE_STREAM", "0") == "1"
+        self._head_fused = os.environ.get("ITERMVS_HEAD_FUSED", "1") != "0"   # whole depth head in one launch
         self.backend = backend or os.environ.get("ITERMVS_CONV_BACKEND", "hip")
         if self.backend not in ("hip", "miopen"):
             raise ValueError(f"unknown conv backend {self.backend!r}")
@@ -213,8 +214,11 @@ class InferenceEngine:
         256-bin logits never reach memory."""
         if self.backend == "hip" and not trace_logits:
             p = "iter_mvs.update.depth_head."
-            x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu")
-            ops.head_regress(x, self.head_w1, self.head_w2, self.w[p + "4.bias"], nd_out=nd_out)
+            if self._head_fused:
+                ops.head_fused(hidden, self.pk[p + "0.weight"], self.head_w1, self.head_w2, self.w[p + "4.bias"], nd_out=nd_out)
+            else:
+                x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu")
+                ops.head_regress(x, self.head_w1, self.head_w2, self.w[p + "4.bias"], nd_out=nd_out)
             return None, None
         logits = self.depth_head(hidden)
         _, _, best = ops.prob_regress(logits, nd_out=nd_out, want_best=trace_logits)

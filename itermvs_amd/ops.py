@@ -280,6 +280,34 @@ def head_regress(x: Tensor, w1p: Tensor, w2p: Tensor, bias2: Tensor,
     return nd, best
 
 
+def head_fused(hidden: Tensor, w0: "MfmaWeight", w1p: Tensor, w2p: Tensor, bias2: Tensor,
+               nd_out: Optional[Sequence[Tuple[Tensor, int]]] = None, want_best: bool = False):
+    """itermvs_head_fused: hidden [B,32,H,W] -> normalised depth (and arg-max bin); the dilated 3x3 layer (``w0``: its
+    MfmaWeight), both 1x1 layers and the regression in one launch.  Returns (nd | None, best | None)."""
+    _dev(hidden, "hidden")
+    b, c, h, w = hidden.shape
+    if c != 32 or w0.tile is None or w0.cin != 32 or w0.cout != 32:
+        raise RuntimeError("head_fused: expects the 32-channel hidden state and the 32 -> 32 3x3 weight")
+    ptr, sb = _planes(hidden, "hidden")
+    p = h * w
+    nd, dests = None, []
+    if nd_out is None:
+        nd = torch.empty((b, 1, h, w), device=hidden.device, dtype=torch.float32)
+        dests.append((nd.data_ptr(), p))
+    else:
+        for buf, ch in nd_out:
+            _dev(buf, "nd_out")
+            assert buf.is_contiguous() and buf.shape[2:] == (h, w)
+            dests.append((buf.data_ptr() + 4 * ch * p, buf.shape[1] * p))
+    while len(dests) < 2:
+        dests.append((None, 0))
+    best = torch.empty((b, 1, h, w), device=hidden.device, dtype=torch.int64) if want_best else None
+    check(_lib.load().itermvs_head_fused(ptr, sb, b, h, w, w0.tile.data_ptr(), _dev(w1p, "w1").data_ptr(),
+                                         _dev(w2p, "w2").data_ptr(), _dev(bias2, "bias2").data_ptr(), dests[0][0], dests[0][1],
+                                         dests[1][0], dests[1][1], _ptr(best), _stream()), "itermvs_head_fused")
+    return nd, best
+
+
 def prob_regress(logits: Tensor, nd_out: Optional[Sequence[Tuple[Tensor, int]]] = None, want_prob: bool = False,
                  want_best: bool = False):
     """itermvs.py:171-190 / 201-219.  logits [B,256,H,W] (NCHW or channels-last).

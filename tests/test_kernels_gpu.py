@@ -276,6 +276,27 @@ def test_head_regress_fused_matches_chain(tag):
         assert float(buf0[:, :3].abs().max()) == 0.0 and float(buf1[:, 2:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("size", [(1, 16, 32), (2, 23, 37), (1, 128, 160)])
+def test_head_fused_equals_conv_plus_head_regress(size):
+    """the one-launch depth head (3x3 dilated layer + two 1x1 layers + regression) against the two-launch form: same
+    operand order in every GEMM, so the results are identical"""
+    b, h, w = size
+    wts = load_weights("seed0")
+    p = "iter_mvs.update.depth_head."
+    w0, w1, w2, b2 = (cu(wts[p + k]) for k in ("0.weight", "2.weight", "4.weight", "4.bias"))
+    gen = torch.Generator().manual_seed(h * w)
+    hidden = torch.tanh(torch.randn((b, 32, h, w), generator=gen)).to(DEV)
+    pk0 = ops().MfmaWeight(w0)
+    a1, a2 = ops().pack_head_weights(w1, w2)
+    x = ops().conv2d(hidden, pk0, None, pad=2, dilation=2, act="relu")
+    nd_ref, best_ref = ops().head_regress(x, a1, a2, b2, want_best=True)
+    nd, best = ops().head_fused(hidden, pk0, a1, a2, b2, want_best=True)
+    assert torch.equal(best, best_ref) and torch.equal(nd, nd_ref)
+    wide = torch.zeros((b, 43, h, w), device=DEV)
+    ops().head_fused(hidden, pk0, a1, a2, b2, nd_out=[(wide, 32)])
+    assert torch.equal(wide[:, 32:33], nd) and float(wide[:, :32].abs().max()) == 0.0 and float(wide[:, 33:].abs().max()) == 0.0
+
+
 def test_head_regress_edges_and_ties():
     """window clamps at both ends and exact ties (first max): weights that route x straight to chosen bins"""
     h, wd = 2, 40
