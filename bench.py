@@ -257,11 +257,11 @@ def main() -> None:
         ops.profile_enable(0)
         if conv_ms and len(conv_ms) == ops.CONV_FLOP_COUNTER["launches"]:
             tf = ops.CONV_FLOP_COUNTER["flops"] / (sum(conv_ms) * 1e-3) / 1e12
-            conv_roofline = {"bound": "mfma", "kernel": "itermvs_conv2d (conv_mfma_kernel / deconv_s2_kernel)",
+            conv_roofline = {"bound": "mfma", "kernel": "itermvs_conv2d (conv_tile_kernel / deconv_tile_kernel / conv_mfma_kernel / conv_direct_kernel)",
                              "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
                              "launches_per_step": len(conv_ms) // n_extra, "ms_per_step": sum(conv_ms) / n_extra,
                              "gflop_per_step": ops.CONV_FLOP_COUNTER["flops"] / n_extra / 1e9,
-                             "timing": "hipEvent pairs around every launch, 3 extra steps after the timed region",
+                             "timing": "hipEvent pairs around every launch (each pair adds ~3 us to a 5-60 us launch), 3 extra eager steps after the timed region",
                              "peak_note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) = vector fp32 peak"}
 
     if rank == 0:
