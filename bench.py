@@ -85,8 +85,8 @@ def cpu_baseline(args, target_seconds: float = 15.0):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--views", type=int, default=5)
