@@ -127,3 +127,33 @@ def test_bench_algorithmic_bytes_match_design():
     import bench
     it, init, per_map = bench.algorithmic_bytes(4, 512, 640, 1, 4)
     assert abs(it / 1e6 - 50.2) < 0.3 and abs(per_map / 1e6 - 229.0) < 3.0
+
+
+def test_weight_packings_follow_the_documented_layouts():
+    """host-side re-layouts of the convolution / head weights (include/itermvs_hip.h), element by element"""
+    import torch
+    from itermvs_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    for cout, cin in ((16, 3), (16, 8), (32, 43), (48, 48)):
+        w = torch.randn((cout, cin, 3, 3), generator=gen)
+        pk = ops.MfmaWeight(w)
+        s = ops.tile_k_split(cin)
+        nch = (cin + 4 * s - 1) // (4 * s)
+        cp = (cout + 15) // 16 * 16
+        assert pk.data.shape == (9, (cin + 3) // 4 * 4, cp) and pk.tile.shape == (9, nch, 4, cp, s)
+        for tap, ch, q, co, k in ((0, 0, 0, 0, 0), (4, nch - 1, 3, cout - 1, s - 1), (8, 0, 2, 5, 0), (7, nch // 2, 1, cp - 1, s - 1)):
+            c = ch * 4 * s + q * s + k
+            want = float(w[co, c, tap // 3, tap % 3]) if (c < cin and co < cout) else 0.0
+            assert float(pk.tile[tap, ch, q, co, k]) == want
+            assert float(pk.data[tap, min(c, pk.data.shape[1] - 1), co]) == (want if c < pk.data.shape[1] else float(pk.data[tap, -1, co]))
+    wt = torch.randn((32, 16, 3, 3), generator=gen)                    # ConvTranspose2d weight [Cin, Cout, k, k]
+    pt = ops.MfmaWeight(wt, transposed=True)
+    assert pt.transposed and pt.cin == 32 and pt.cout == 16
+    assert float(pt.tile[5, 1, 2, 7, 3]) == float(wt[1 * 16 + 2 * 4 + 3, 7, 1, 2])
+    w1, w2 = torch.randn((64, 32, 1, 1), generator=gen), torch.randn((256, 64, 1, 1), generator=gen)
+    a1, a2 = ops.pack_head_weights(w1, w2)
+    assert a1.shape == (4, 2, 4, 16, 4) and a2.shape == (16, 4, 4, 16, 4)
+    assert float(a1[3, 1, 2, 5, 3]) == float(w1[3 * 16 + 5, 1 * 16 + 2 * 4 + 3, 0, 0])
+    assert float(a2[9, 2, 1, 15, 0]) == float(w2[9 * 16 + 15, 2 * 16 + 1 * 4 + 0, 0, 0])
+    v = ops.pack_conv_weight(w)                                        # VALU format [Cin, k, k, Cout]
+    assert v.shape == (48, 3, 3, 48) and float(v[7, 2, 1, 40]) == float(w[40, 7, 2, 1])
