@@ -10,8 +10,10 @@ Each rank takes the reference views ``rank, rank + world, ...`` (no collective o
 ``--dataset module:Class`` accepts any dataset yielding the reference's sample dict
 (datasets/dtu_yao_eval.py:154-158); the reference's own loaders (cv2 / PIL based) are outside this
 repository's scope.  ``--filter`` runs the reference's filter / fusion stage (eval.py:215-325) afterwards: for every scan
-folder under ``--testpath`` that has a ``pair.txt`` and ``cams_1/``, the depth / confidence PFMs written above are fused
-into ``<outdir>/<scan>.ply`` by ``itermvs_amd.fusion.filter_depth`` (one HIP launch per reference view).
+folder under ``--testpath`` that has a ``pair.txt``, ``cams_1/`` and ``images/``, the depth / confidence PFMs written above
+are fused into ``<outdir>/<scan>.ply`` by ``itermvs_amd.fusion.filter_depth`` (one HIP launch per reference view); the
+camera intrinsics are rescaled by ``--img_wh`` / original image size and the points coloured from the resized images like
+eval.py:231-232,251-252,295.
 """
 from __future__ import annotations
 
@@ -126,6 +128,7 @@ def save_depth(args) -> int:
             out = model(cu["imgs"], cu["proj_matrices"], cu["depth_min"], cu["depth_max"])
             depth = out["depths_upsampled"].cpu().numpy()      # D2H + sync, like tensor2numpy (eval.py:135)
             conf = out["confidence_upsampled"].cpu().numpy()
+            model.check_projection_finite()                    # module.py:83,87 (deferred; the device is already idle)
             print("Iter {}/{}, time = {:.3f}".format(i // args.batch_size, (len(mine) + args.batch_size - 1) // args.batch_size,
                                                       time.time() - t0))
             for name, d, c in zip(sample["filename"], depth, conf):
@@ -148,7 +151,7 @@ def fuse_scans(args) -> int:
         scan = scans[i]
         stats = fusion.filter_depth(os.path.join(args.testpath, scan), os.path.join(args.outdir, scan),
                                     os.path.join(args.outdir, scan + ".ply"), args.geo_pixel_thres, args.geo_depth_thres,
-                                    args.photo_thres, device=dev)
+                                    args.photo_thres, device=dev, img_wh=tuple(args.img_wh))
         for v, (g, ph, f) in stats.items():
             print("processing {}, ref-view{:0>2}, geo_mask:{:3f} photo_mask:{:3f} final_mask: {:3f}".format(scan, v, g, ph, f))
         n += 1

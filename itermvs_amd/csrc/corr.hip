@@ -454,7 +454,8 @@ __global__ void __launch_bounds__(512) pvw_tail_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
         const int n = g * NPW + i;
-        const float* xp = x + ((size_t)(m * N + n) * C) * P + (live ? p : 0);
+        // hypotheses past N (N not a multiple of 8 * NPW) re-read the last plane; their logit is masked below
+        const float* xp = x + ((size_t)(m * N + min(n, N - 1)) * C) * P + (live ? p : 0);
         float acc = b0;
 #pragma unroll
         for (int c = 0; c < C; ++c) acc = fmaf(xp[(size_t)c * P], wt[c], acc);

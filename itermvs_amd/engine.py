@@ -78,6 +78,9 @@ class InferenceEngine:
         self.b_zr = torch.cat([w[g + "convz.bias"], w[g + "convr.bias"]], 0).contiguous()
         self.offsets = sample_offsets()
         self._ws: Dict[tuple, dict] = {}
+        # OR-ed with 1 by itermvs_compose_proj when a composed projection is NaN (module.py:83,87 assert on the host);
+        # read and cleared by check_projection_finite()
+        self.nan_flag = torch.zeros((1,), device=dev, dtype=torch.int32)
         self._side = None          # second HIP stream for the independent branches (_fork / _join)
         self.profile_iterations = None   # set of iteration indices whose corr_iter launch carries timing events (None = all)
         import os
@@ -272,7 +275,6 @@ class InferenceEngine:
                 "hidden": torch.empty((b, HIDDEN, h, w), device=dev),
                 "agg_all": torch.empty((b * (nx - 1), 8, h, w), device=dev),   # the three levels' CorrNet inputs, back to back
                 "zbuf": torch.empty((b, HIDDEN, h, w), device=dev),
-                "nan_flag": torch.zeros((1,), device=dev, dtype=torch.int32),
                 # outputs / intermediates of the two side branches (allocated here, on the main stream)
                 "up_mid": torch.empty((b, 64, h, w), device=dev),
                 "up_logits": torch.empty((b, 144, h, w), device=dev),
@@ -308,7 +310,7 @@ class InferenceEngine:
 
         # projs: {1,2,3: [B,V,4,4]} like the reference's sample dict, or the same stacked [3,B,V,4,4]
         pstack = projs if torch.is_tensor(projs) else torch.stack([projs[1], projs[2], projs[3]])
-        proj, inv_min, inv_max = ops.compose_proj(pstack.reshape(3 * b, v, 4, 4), ws["nan_flag"], (depth_min, depth_max))
+        proj, inv_min, inv_max = ops.compose_proj(pstack.reshape(3 * b, v, 4, 4), self.nan_flag, (depth_min, depth_max))
         proj = proj.view(3, b, s, 12)
 
         # convex up-sampling logits from the reference level-2 feature (itermvs.py:262-263)
@@ -415,11 +417,13 @@ class InferenceEngine:
         conf_up = ops.bilinear_up(conf, 4)                                                      # itermvs.py:323-324
         return depth_up, conf_up
 
-    def check_projection_finite(self, b: int, h: int, w: int) -> None:
-        """Deferred form of the reference's NaN asserts (module.py:83,87); synchronises."""
-        ws = self._ws.get((b, h, w))
-        if ws is not None and int(ws["nan_flag"].item()) != 0:
-            raise AssertionError("nan in proj")
+    def check_projection_finite(self) -> None:
+        """Deferred form of the reference's NaN asserts (module.py:83,87) for every ``run`` / graph replay enqueued since
+        the last check: waits for them (one 4-byte read), clears the flag, raises ``AssertionError`` like the reference."""
+        bad = int(self.nan_flag.item())
+        if bad:
+            self.nan_flag.zero_()
+            raise AssertionError("nan in proj (singular or non-finite camera matrix, module.py:83,87)")
 
 
 class GraphedRunner:

@@ -71,22 +71,62 @@ def write_ply(filename: str, xyz: np.ndarray, rgb: np.ndarray) -> None:
         f.write(v.tobytes())
 
 
-def filter_depth(scan_folder: str, out_folder: str, plyfilename: str, geo_pixel_thres: float, geo_depth_thres: float,
-                 photo_thres: float, images: Dict[int, np.ndarray] = None, intrinsics_scale: Tuple[float, float] = (1.0, 1.0),
-                 geo_mask_thres: int = 3, device: str = "cuda") -> Dict[str, float]:
-    """eval.py:215-309: for every reference view of ``pair.txt`` fuse its depth map with its source views' and append the
-    surviving pixels to one point cloud.  ``images[view]`` = [H,W,3] float RGB in 0..1 at the depth maps' resolution
-    (the reference loads and resizes them with PIL + cv2; without them the cloud is written grey); ``intrinsics_scale``
-    = (img_w / original_w, img_h / original_h) applied to the camera files' intrinsics (eval.py:231-232)."""
-    pairs = read_pair_file(os.path.join(scan_folder, "pair.txt"))
-    cams, depths = {}, {}
+def read_scan_image(filename: str, img_wh: Tuple[int, int], want_pixels: bool = True):
+    """eval.py:68-74 ``read_img``: -> (RGB float32 [H,W,3] in 0..1 resized to ``img_wh`` or None, original_h, original_w).
+    The reference resizes with ``cv2.resize(INTER_LINEAR)``; cv2 is not a dependency here, PIL's bilinear filter takes its
+    place (vertex colours only -- the geometry never reads the pixels)."""
+    from PIL import Image
+    with Image.open(filename) as im:
+        original_w, original_h = im.size
+        px = None
+        if want_pixels:
+            im = im.convert("RGB")
+            if (original_w, original_h) != tuple(img_wh):
+                im = im.resize(tuple(img_wh), Image.BILINEAR)
+            px = np.asarray(im, dtype=np.float32) / 255.0
+    return px, original_h, original_w
 
-    def cam(v):
-        if v not in cams:
+
+def filter_depth(scan_folder: str, out_folder: str, plyfilename: str, geo_pixel_thres: float, geo_depth_thres: float,
+                 photo_thres: float, images: Dict[int, np.ndarray] = None, intrinsics_scale: Tuple[float, float] = None,
+                 geo_mask_thres: int = 3, device: str = "cuda", img_wh: Tuple[int, int] = None) -> Dict[str, float]:
+    """eval.py:215-309: for every reference view of ``pair.txt`` fuse its depth map with its source views' and append the
+    surviving pixels to one point cloud.
+
+    Like the reference (eval.py:231-232, 251-252) the ``cams_1`` intrinsics of EVERY view are rescaled by
+    ``img_wh / original image size`` and the points are coloured from the resized reference image.  Either
+      * ``img_wh`` = (width, height) of the depth maps: ``<scan_folder>/images/{view:08d}.jpg`` is opened for its original
+        size (and, for reference views, its pixels); a missing image raises -- the filter refuses to run with a guessed K; or
+      * ``images[view]`` = [H,W,3] float RGB in 0..1 at the depth maps' resolution plus ``intrinsics_scale`` =
+        (img_w / original_w, img_h / original_h) for callers that hold the images already (default (1, 1))."""
+    pairs = read_pair_file(os.path.join(scan_folder, "pair.txt"))
+    if img_wh is None and images is None and intrinsics_scale is None:
+        raise ValueError("filter_depth: pass img_wh (images/ folder is read for the original sizes and colours) or "
+                         "images + intrinsics_scale; fusing with unscaled intrinsics would be silently wrong")
+    cams, depths, pixels = {}, {}, {}
+
+    def image_path(v):
+        base = os.path.join(scan_folder, "images/{:0>8}".format(v))
+        for ext in (".jpg", ".png", ".jpeg"):
+            if os.path.isfile(base + ext):
+                return base + ext
+        raise FileNotFoundError(f"{base}.jpg: the filter needs every view's image for the intrinsics scale (eval.py:231-232)")
+
+    def scale_of(v, want_pixels):
+        if img_wh is None:
+            return intrinsics_scale or (1.0, 1.0)
+        px, oh, ow = read_scan_image(image_path(v), img_wh, want_pixels)
+        if px is not None:
+            pixels[v] = px
+        return img_wh[0] / ow, img_wh[1] / oh
+
+    def cam(v, want_pixels=False):
+        if v not in cams or (want_pixels and img_wh is not None and v not in pixels):
             k, e = read_camera_parameters(os.path.join(scan_folder, "cams_1/{:0>8}_cam.txt".format(v)))
+            sx, sy = scale_of(v, want_pixels)
             k = k.copy()
-            k[0] *= intrinsics_scale[0]
-            k[1] *= intrinsics_scale[1]
+            k[0] *= sx           # python float * float32 row -> float32, like eval.py:231-232
+            k[1] *= sy
             cams[v] = (k, e)
         return cams[v]
 
@@ -98,7 +138,7 @@ def filter_depth(scan_folder: str, out_folder: str, plyfilename: str, geo_pixel_
 
     vertexs, colors, stats = [], [], {}
     for ref_view, src_views in pairs:
-        k_ref, e_ref = cam(ref_view)
+        k_ref, e_ref = cam(ref_view, want_pixels=True)
         conf = np.squeeze(read_pfm(os.path.join(out_folder, "confidence/{:0>8}.pfm".format(ref_view)))[0])
         avg, photo, geo, final, _ = fuse_reference_view(depth(ref_view), conf, k_ref, e_ref, [depth(v) for v in src_views],
                                                         [cam(v)[0] for v in src_views], [cam(v)[1] for v in src_views],
@@ -111,7 +151,14 @@ def filter_depth(scan_folder: str, out_folder: str, plyfilename: str, geo_pixel_
         xyz_ref = np.matmul(np.linalg.inv(k_ref), np.vstack((x, y, np.ones_like(x))) * d)          # eval.py:291-292
         xyz_world = np.matmul(np.linalg.inv(e_ref), np.vstack((xyz_ref, np.ones_like(x))))[:3]    # eval.py:293-294
         vertexs.append(xyz_world.transpose((1, 0)))
-        img = images[ref_view] if images is not None else np.full((h, w, 3), 0.5, np.float32)
+        if images is not None:
+            img = images[ref_view]
+        elif ref_view in pixels:
+            img = pixels.pop(ref_view)
+        else:
+            img = np.full((h, w, 3), 0.5, np.float32)
+        if img.shape[:2] != (h, w):
+            raise ValueError(f"view {ref_view}: image is {img.shape[:2]}, depth map is {(h, w)}")
         colors.append((img[final_np] * 255).astype(np.uint8))
     write_ply(plyfilename, np.concatenate(vertexs, 0).astype(np.float32), np.concatenate(colors, 0))
     return stats

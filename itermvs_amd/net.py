@@ -54,8 +54,9 @@ def _default_init(name: str, shape) -> torch.Tensor:
     schema = state_dict_schema()
     wname = name if name.endswith("weight") else name[: -len("bias")] + "weight"
     wshape = schema[wname]
-    transposed = wname.endswith("conv3.weight") or wname.endswith("conv4.weight")  # ConvTranspose2d
-    fan_in = (wshape[0] if transposed else wshape[1]) * wshape[2] * wshape[3]
+    # torch.nn.init._calculate_fan_in_and_fan_out takes size(1) * k * k for every weight, ConvTranspose2d's [in,out,k,k]
+    # included (so CorrNet's conv3 / conv4 draw from 1/sqrt(16*9) and 1/sqrt(8*9))
+    fan_in = wshape[1] * wshape[2] * wshape[3]
     bound = 1.0 / math.sqrt(fan_in)
     return (torch.rand(shape) * 2 - 1) * bound
 
@@ -75,7 +76,11 @@ class Pipeline(nn.Module):
             _attach(self, name, _default_init(name, shape), is_buffer)
         self._engine = None
         self._runners = {}
-        self.use_graphs = False        # test mode: replay hipGraph segments instead of launching kernel by kernel
+        self.use_graphs = False        # test mode: replay one hipGraph per depth map instead of launching kernel by kernel
+        # module.py:83,87 assert on NaN projections inside every forward.  Eager test mode does the same (one 4-byte read
+        # after the launches are enqueued); the graph mode never stalls the host: call check_projection_finite() when the
+        # outputs are fetched (eval.py does, per batch).  None = follow that default.
+        self.check_nan = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     # -- weights ----------------------------------------------------------------------------
@@ -89,8 +94,17 @@ class Pipeline(nn.Module):
         return self.load_state_dict(strip_module_prefix(state), strict=strict)
 
     def train(self, mode: bool = True):
-        self.invalidate()
+        # the folded inference weights do not depend on the flag: only a real mode change drops them, so a loop that calls
+        # model.eval() per sample (train.py:test_sample) does not re-fold / re-capture every time
+        if mode != self.training:
+            self.invalidate()
         return super().train(mode)
+
+    def check_projection_finite(self) -> None:
+        """Raise ``AssertionError`` if any forward since the last check composed a NaN projection (module.py:83,87);
+        synchronises with the device."""
+        if self._engine is not None:
+            self._engine.check_projection_finite()
 
     def _apply(self, fn, *a, **k):
         self.invalidate()
@@ -125,6 +139,8 @@ class Pipeline(nn.Module):
                     depth_up, conf_up = runner(x.float(), projs, depth_min, depth_max)
                 else:
                     depth_up, conf_up = self._engine.run(x.float(), projs, depth_min, depth_max)
+            if self.check_nan if self.check_nan is not None else not self.use_graphs:
+                self._engine.check_projection_finite()
             return {"depths_upsampled": depth_up, "confidence_upsampled": conf_up}
         from .train_graph import train_forward
         return train_forward(self.weights(), x.float(), projs, depth_min, depth_max, self.iteration,

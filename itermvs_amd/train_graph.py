@@ -157,8 +157,9 @@ def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor
     s = v - 1
     feats = net.features(imgs.reshape(b * v, 3, hh, ww))
     pv = {l: f.view(b, v, *f.shape[1:]) for l, f in feats.items()}
+    nan_flag = torch.zeros((1,), device=imgs.device, dtype=torch.int32)
     with torch.no_grad():
-        proj = ops.compose_proj(torch.stack([projs[1], projs[2], projs[3]]).reshape(3 * b, v, 4, 4)).view(3, b, s, 12)
+        proj = ops.compose_proj(torch.stack([projs[1], projs[2], projs[3]]).reshape(3 * b, v, 4, 4), nan_flag).view(3, b, s, 12)
     h, wd = feats[2].shape[2:]
     inv_min = (1.0 / depth_min).view(b, 1, 1, 1)
     inv_max = (1.0 / depth_max).view(b, 1, 1, 1)
@@ -219,6 +220,8 @@ def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor
             depths_up.append(_unnorm(_convex_upsample(nd, up_w), inv_min, inv_max))
             conf_up = F.interpolate(torch.sigmoid(conf0), scale_factor=4, mode="bilinear")
         nd = nd.detach()
+    # module.py:83,87: the reference asserts inside every warp; here once per forward, after everything is enqueued
+    assert int(nan_flag.item()) == 0, "nan in proj (singular or non-finite camera matrix, module.py:83,87)"
     return {"depths": depths, "depths_upsampled": depths_up, "confidences": confidences,
             "confidence_upsampled": conf_up}
 

@@ -56,3 +56,26 @@ def test_train_driver_steps_and_checkpoint(tmp_path):
     eargs = E.build_parser().parse_args(["--n_views", "3", "--img_wh", "96", "64", "--iteration", "2", "--loadckpt", path])
     m2 = E.load_model(eargs, dev)                                                    # reference-format checkpoint
     assert torch.equal(m2.state_dict()["iter_mvs.update.gru.convq.weight"], after["iter_mvs.update.gru.convq.weight"])
+
+
+def test_validation_mode_scalars_and_no_weight_change():
+    """train.py --mode val (train.py:177-190, 245-295): eval-mode BatchNorm, no optimiser step, the reference's scalars"""
+    import train as T
+    args = T.build_parser().parse_args(["--mode", "val", "--regress", "--n_views", "3", "--img_wh", "96", "64",
+                                        "--iteration", "2", "--steps_per_epoch", "2"])
+    dev = torch.device("cuda")
+    from itermvs_amd import synthetic
+    from itermvs_amd.net import Pipeline
+    model = Pipeline(iteration=2, test=False)
+    model.load_state_dict(synthetic.random_state_dict(0))
+    model = model.to(dev)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    means = T.validate(model, args, 0, 1, dev)
+    want = {"loss", "abs_error_initial", "thres1mm_initial", "abs_error_final_full", "thres1mm_final_full",
+            "thres2mm_final_full", "thres4mm_final_full", "thres8mm_final_full", "thres1mm_gru_1", "abs_error_gru_1",
+            "thres1mm_gru_2", "abs_error_gru_2"}
+    assert set(means) == want and all(np.isfinite(v) for v in means.values())
+    assert means["thres8mm_final_full"] <= means["thres1mm_final_full"] <= 1.0
+    after = model.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)                     # running stats untouched too
+    assert not model.training

@@ -118,26 +118,54 @@ def test_fuse_kernel_matches_oracle_bit_for_bit(case):
         assert final.mean() > 0.2
 
 
+def test_read_scan_image_reports_original_size_and_resizes(tmp_path):
+    """eval.py:68-74: pixels in 0..1 at img_wh, plus the ORIGINAL height / width the intrinsics scale is built from"""
+    from PIL import Image
+    from itermvs_amd import fusion
+    rgb = np.zeros((40, 60, 3), np.uint8)
+    rgb[..., 0], rgb[..., 1], rgb[..., 2] = 255, 128, 0
+    Image.fromarray(rgb).save(str(tmp_path / "a.png"))
+    px, oh, ow = fusion.read_scan_image(str(tmp_path / "a.png"), (30, 20))
+    assert (oh, ow) == (40, 60) and px.shape == (20, 30, 3) and px.dtype == np.float32
+    assert np.allclose(px[..., 0], 1.0) and np.allclose(px[..., 1], 128 / 255.0) and np.allclose(px[..., 2], 0.0)
+    none, oh, ow = fusion.read_scan_image(str(tmp_path / "a.png"), (30, 20), want_pixels=False)
+    assert none is None and (oh, ow) == (40, 60)
+    (tmp_path / "pair.txt").write_text("0\n")
+    with pytest.raises(ValueError, match="img_wh"):      # neither img_wh nor an explicit scale: refuse instead of guessing K
+        fusion.filter_depth(str(tmp_path), str(tmp_path), str(tmp_path / "x.ply"), 1.0, 0.01, 0.3)
+
+
 @pytest.mark.gpu
-def test_filter_depth_scene_folder(tmp_path):
-    """eval.py:215-309 end to end on a synthetic scan folder: PFMs + cams + pair.txt -> PLY on the plane"""
+@pytest.mark.parametrize("orig_scale", [1.0, 2.0])
+def test_filter_depth_scene_folder(tmp_path, orig_scale):
+    """eval.py:215-309 end to end on a synthetic scan folder: PFMs + cams + images + pair.txt -> PLY on the plane.
+    ``orig_scale`` = 2: the images on disk (and the intrinsics in cams_1, which describe them) are twice the size of the
+    depth maps, so the fused cloud only lands on the plane if every view's K is rescaled like eval.py:231-232,251-252."""
+    from PIL import Image
     from itermvs_amd import fusion
     from itermvs_amd.data_io import save_pfm
-    views = _scene(64, 96, 5, 5, 0.001)
+    h, w = 64, 96
+    views = _scene(h, w, 5, 5, 0.001)
     scan, out = tmp_path / "scan1", tmp_path / "out"
     (scan / "cams_1").mkdir(parents=True)
+    (scan / "images").mkdir(parents=True)
     (out / "depth_est").mkdir(parents=True)
     (out / "confidence").mkdir(parents=True)
     lines = ["5"]
     for v, (k, e, d, conf) in enumerate(views):
         rows = lambda m: "\n".join(" ".join(repr(float(x)) for x in r) for r in m)
-        (scan / "cams_1" / "{:0>8}_cam.txt".format(v)).write_text(f"extrinsic\n{rows(e)}\n\nintrinsic\n{rows(k)}\n\n425 2.5\n")
+        k_disk = k.copy()
+        k_disk[:2] *= orig_scale                    # intrinsics of the full-size image on disk
+        (scan / "cams_1" / "{:0>8}_cam.txt".format(v)).write_text(f"extrinsic\n{rows(e)}\n\nintrinsic\n{rows(k_disk)}\n\n425 2.5\n")
+        img = np.zeros((int(h * orig_scale), int(w * orig_scale), 3), np.uint8)
+        img[..., 0], img[..., 1], img[..., 2] = 10 + 40 * v, 200, 7
+        Image.fromarray(img).save(str(scan / "images" / "{:0>8}.jpg".format(v)), quality=100)
         save_pfm(str(out / "depth_est" / "{:0>8}.pfm".format(v)), d)
         save_pfm(str(out / "confidence" / "{:0>8}.pfm".format(v)), np.full_like(conf, 0.9))
         srcs = [u for u in range(5) if u != v]
         lines += [str(v), f"{len(srcs)} " + " ".join(f"{u} 1.0" for u in srcs)]
     (scan / "pair.txt").write_text("\n".join(lines) + "\n")
-    stats = fusion.filter_depth(str(scan), str(out), str(tmp_path / "fused.ply"), 1.0, 0.01, 0.3, device=DEV)
+    stats = fusion.filter_depth(str(scan), str(out), str(tmp_path / "fused.ply"), 1.0, 0.01, 0.3, device=DEV, img_wh=(w, h))
     assert len(stats) == 5 and all(s[2] > 0.3 for s in stats.values())
     head, body = (tmp_path / "fused.ply").read_bytes().split(b"end_header\n")
     n = int(head.split(b"element vertex ")[1].split(b"\n")[0])
@@ -145,3 +173,9 @@ def test_filter_depth_scene_folder(tmp_path):
     assert len(pts) == n > 1000
     plane = 0.1 * pts["x"] - 0.05 * pts["y"] + 1.0 * pts["z"]
     assert np.abs(plane - 700.0).max() < 5.0                                 # every fused point lies on the plane
+    assert np.abs(pts["g"].astype(int) - 200).max() <= 3 and set(np.round((pts["r"].astype(int) - 10) / 40.0).astype(int)) <= set(range(5))
+    if orig_scale != 1.0:       # and with the camera files taken at face value it does not
+        with pytest.raises(AssertionError):
+            st = fusion.filter_depth(str(scan), str(out), str(tmp_path / "bad.ply"), 1.0, 0.01, 0.3, device=DEV,
+                                     intrinsics_scale=(1.0, 1.0))
+            assert all(s[2] > 0.3 for s in st.values())

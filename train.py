@@ -100,6 +100,46 @@ def train_step(model, optimizer, batch, regress: bool):
     return float(loss.detach()), float(err)
 
 
+@torch.no_grad()
+def val_step(model, batch, regress: bool, iteration: int):
+    """train.py:245-295 (test_sample): eval-mode BatchNorm, the training-form outputs, loss and the reference's scalars."""
+    imgs, projs, dmin, dmax, gt, mask = batch
+    model.eval()
+    out = model(imgs, projs, dmin, dmax)
+    loss = full_loss(out["depths"], out["depths_upsampled"], out["confidences"], gt, mask, dmin, dmax, regress)
+    m0, m2 = mask["level_0"] > 0.5, mask["level_2"] > 0.5
+    abs_err = lambda est, g, m: float((est[m] - g[m]).abs().mean())                       # utils.py AbsDepthError_metrics
+    thres = lambda est, g, m, t: float(((est[m] - g[m]).abs() > t).float().mean())        # utils.py Thres_metrics
+    final, first = out["depths_upsampled"][-1], out["depths"]["combine"][0]
+    scalars = {"loss": float(loss), "abs_error_initial": abs_err(first, gt["level_2"], m2),
+               "thres1mm_initial": thres(first, gt["level_2"], m2, 1.0),
+               "abs_error_final_full": abs_err(final, gt["level_0"], m0)}
+    for t in (1, 2, 4, 8):
+        scalars[f"thres{t}mm_final_full"] = thres(final, gt["level_0"], m0, float(t))
+    for j in range(1, iteration + 1):
+        scalars[f"thres1mm_gru_{j}"] = thres(out["depths"]["combine"][j], gt["level_2"], m2, 1.0)
+        scalars[f"abs_error_gru_{j}"] = abs_err(out["depths"]["combine"][j], gt["level_2"], m2)
+    return scalars
+
+
+def validate(model, args, rank: int, world: int, dev) -> dict:
+    """train.py:177-190 (test): every rank scores its share of the validation steps; the means are averaged over ranks"""
+    total, n = {}, 0
+    for step in range(args.steps_per_epoch):
+        sc = val_step(model, synthetic_batch(args, 10_000_019 + step, rank, dev), args.regress, args.iteration)
+        for k, v in sc.items():
+            total[k] = total.get(k, 0.0) + v
+        n += 1
+        if rank == 0:
+            print("Iter {}/{}, test loss = {:.3f}".format(step, args.steps_per_epoch, sc["loss"]))
+    keys = sorted(total)
+    t = torch.tensor([total[k] / max(n, 1) for k in keys], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t)
+        t /= world
+    return dict(zip(keys, t.tolist()))
+
+
 def main() -> None:
     args = build_parser().parse_args()
     rank, local_rank, world = shard.init_distributed()
@@ -121,6 +161,12 @@ def main() -> None:
     sched = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma=gamma, last_epoch=start_epoch - 1)
     if args.dataset != "synthetic":
         raise SystemExit("only --dataset synthetic is built in; plug a dataset module in via itermvs_amd")
+    if args.mode == "val":                                                               # train.py:297-300
+        means = validate(model, args, rank, world, dev)
+        if rank == 0:
+            print("final", means)
+        shard.barrier()
+        return
     for epoch in range(start_epoch, args.epochs):
         for step in range(args.steps_per_epoch):
             t0 = time.time()
@@ -132,6 +178,9 @@ def main() -> None:
         sched.step()
         if rank == 0 and (epoch + 1) % args.save_freq == 0:
             save_checkpoint("{}/model_{:0>6}.ckpt".format(args.logdir, epoch), epoch, model, optimizer)
+        means = validate(model, args, rank, world, dev)                                   # train.py:160-175
+        if rank == 0:
+            print("avg_test_scalars:", means)
     shard.barrier()
 
 
