@@ -106,64 +106,6 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(const ConvArgs a) {
     }
 }
 
-// ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1): thread = input pixel (y, x) -> the
-// 2x2 output block at (2y, 2x); all 9 taps are useful:
-//   out(2y  ,2x  ) = in(y,x) W11
-//   out(2y  ,2x+1) = in(y,x) W12 + in(y,x+1) W10
-//   out(2y+1,2x  ) = in(y,x) W21 + in(y+1,x) W01
-//   out(2y+1,2x+1) = in(y,x) W22 + in(y,x+1) W20 + in(y+1,x) W02 + in(y+1,x+1) W00
-template <int CT>
-__global__ void __launch_bounds__(256) deconv_s2_kernel(const ConvArgs a) {
-    const int Pin = a.Hin * a.Win;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const int co0 = blockIdx.y * CT;
-    const int n = blockIdx.z;
-    const int seg = (n >= a.seg_end[0]) + (n >= a.seg_end[1]);
-    const float* __restrict__ w = a.weight[seg] + co0;
-    const float* __restrict__ bias = a.bias[seg];
-    if (p >= Pin) return;
-    const int y = p / a.Win, x = p - y * a.Win;
-    const bool hx = x + 1 < a.Win, hy = y + 1 < a.Hin;
-    const int o01 = hx ? p + 1 : p, o10 = hy ? p + a.Win : p, o11 = (hx && hy) ? p + a.Win + 1 : p;
-
-    float acc[4][CT];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[q][c] = bias ? bias[co0 + c] : 0.0f;
-
-    const float* __restrict__ ip = a.in + (int64_t)n * a.in_sn;
-    const int wstep = 9 * a.Cout;
-    for (int ci = 0; ci < a.Cin; ++ci) {
-        const float v00 = ip[p];
-        const float v01 = hx ? ip[o01] : 0.0f;
-        const float v10 = hy ? ip[o10] : 0.0f;
-        const float v11 = (hx && hy) ? ip[o11] : 0.0f;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            // packed weight index: (ky*3 + kx)*Cout + c
-            acc[0][c] = fmaf(v00, w[4 * a.Cout + c], acc[0][c]);
-            acc[1][c] = fmaf(v01, w[3 * a.Cout + c], fmaf(v00, w[5 * a.Cout + c], acc[1][c]));
-            acc[2][c] = fmaf(v10, w[1 * a.Cout + c], fmaf(v00, w[7 * a.Cout + c], acc[2][c]));
-            acc[3][c] = fmaf(v11, w[0 * a.Cout + c],
-                             fmaf(v10, w[2 * a.Cout + c], fmaf(v01, w[6 * a.Cout + c], fmaf(v00, w[8 * a.Cout + c], acc[3][c]))));
-        }
-        ip += Pin;
-        w += wstep;
-    }
-    const int P = a.Hout * a.Wout;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int op = (2 * y + (q >> 1)) * a.Wout + 2 * x + (q & 1);
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const int64_t ch = (int64_t)(co0 + c) * P + op;
-            const float ad = a.add ? a.add[(int64_t)n * a.add_sn + ch] : 0.0f;
-            a.out[(int64_t)n * a.out_sn + ch] = epilogue(acc[q][c], a.act, ad, 0.0f, 0.0f);
-        }
-    }
-}
-
 template <int KS>
 static int launch_direct(const ConvArgs& a, int ct, hipStream_t stream) {
     const int P = a.Hout * a.Wout;
@@ -235,21 +177,7 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
         const int rc = itermvs_deconv2d_tile(p, (hipStream_t)stream);
         return rc == 1 ? ITERMVS_ERR_DIMS : rc;
     }
-    if (p->transposed) {
-        ITERMVS_RETURN_IF(p->weight_format != 0, ITERMVS_ERR_DIMS);
-        ITERMVS_RETURN_IF(p->ksize != 3 || p->stride != 2 || p->pad != 1 || p->act > 1, ITERMVS_ERR_DIMS);
-        a.Hout = 2 * p->Hin; a.Wout = 2 * p->Win;
-        if (ct > 16) ct = 16;       // 4 output pixels x CT accumulators per thread
-        while (ct > 1 && (int64_t)((p->Hin * p->Win + 255) / 256) * (p->Cout / ct) * p->N < 1024) ct /= 2;
-        const dim3 grid((p->Hin * p->Win + 255) / 256, p->Cout / ct, p->N);
-        switch (ct) {
-            case 16: hipLaunchKernelGGL((deconv_s2_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-            case 8: hipLaunchKernelGGL((deconv_s2_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-            case 4: hipLaunchKernelGGL((deconv_s2_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-            default: hipLaunchKernelGGL((deconv_s2_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-        }
-        return itermvs_launch_status();
-    }
+    ITERMVS_RETURN_IF(p->transposed, ITERMVS_ERR_DIMS);   // transposed convolutions exist in weight_format 2 only
     ITERMVS_RETURN_IF(p->stride < 1 || p->dilation < 1 || p->pad < 0, ITERMVS_ERR_DIMS);
     const int span = (p->ksize - 1) * p->dilation + 1;
     a.Hout = (p->Hin + 2 * p->pad - span) / p->stride + 1;

@@ -144,7 +144,7 @@ def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, vie
     s = len(src[1])
     p = CorrIterParams()
     p.B, p.S, p.H, p.W = b, s, h, w
-    p.impl = impl          # 0 default, 1 direct gather, 2 LDS-staged tiles
+    p.impl = impl          # kernel form (include/itermvs_hip.h): 0 default, 1 views in the lane, 2 views across waves
     keep = []
     outs: List[Tensor] = []
     for i, l in enumerate((1, 2, 3)):

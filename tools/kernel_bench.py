@@ -2,8 +2,8 @@
 """Micro-benchmark of the fused correlation kernels on cfg-1-shaped inputs (GPU box only).
 
 Times back-to-back launches with HIP events (torch.cuda.Event on the launch stream) and checks
-that the kernel variants agree.  `--depth noise|smooth` selects the spatial statistics of the
-normalised depth map, which decide whether the LDS-staged tile kernel can stage its footprints.
+that the kernel forms agree, for a noise-like and a smooth normalised depth map (the spatial statistics
+decide the cache behaviour of the gathers).
 """
 import argparse
 import os
@@ -64,13 +64,13 @@ def main():
     for kind in ("noise", "smooth"):
         d = build(args.height, args.width, args.views, kind, dev)
         outs = {}
-        for impl in (1, 3, 4, 2):
+        for impl in (1, 2, 7, 3, 4, 5, 6, 12, 22, 17, 27, 1, 2):
             buf = [torch.empty((1, len(offs[l]), 8, args.height // 4, args.width // 4), device=dev) for l in (1, 2, 3)]
             run = lambda: ops.corr_iter(d["src"], d["ref_q"], d["proj"], d["vw"], d["inv_min"], d["inv_max"],
                                         norm_depth=d["nd"], offsets=offs, out=buf, impl=impl)
             us = time_it(run)
             outs[impl] = [b.clone() for b in buf]
-            print(f"corr_iter depth={kind:6s} impl={impl}: {us:8.2f} us/launch")
+            print(f"corr_iter depth={kind:6s} impl={impl:2d}: {us:8.2f} us/launch", flush=True)
         diff = max(float((a - b).abs().max()) for a, b in zip(outs[1], outs[2]))
         scale = max(float(a.abs().max()) for a in outs[1])
         print(f"  impl 1 vs 2: max abs diff {diff:.3e} (scale {scale:.2f})")
