@@ -1,31 +1,33 @@
 """MI355X inference engine for the IterMVS matching hot path (test mode of ``Pipeline``).
 
-Data flow per batch of reference views (all buffers stay resident in HBM):
+Every compute kernel of a depth map is a hand-written HIP kernel behind the C ABI (``itermvs_amd.ops``); PyTorch-ROCm
+provides device memory, streams and hipGraph capture only.  Data flow per batch of reference views (all buffers stay
+resident in HBM; ``K`` = one launch):
 
-    FeatureNet (MIOpen, BN folded, all B*V views in one batch)           net.py:36-65
-      -> channels-last pyramids f1 [BV,16,H/2,W/2], f2 [BV,32,H/4,W/4], f3 [BV,48,H/8,W/8]
-    K  compose_proj      src @ inv(ref) for 3 levels x S views            module.py:77-90
-    K  ref_quarter       reference features on the 1/4 grid, packed       itermvs.py:95-98
-    K  corr_init         per-view group correlation, 32 hypotheses        itermvs.py:48-51
-       PixelViewWeight convs (MIOpen) + K softmax_max + K bilinear_up     itermvs.py:333-350,56
-    K  view_aggregate    view-weighted mean                               itermvs.py:59-69
-       CorrNet (MIOpen) -> hidden_init convs -> K bilinear_up(tanh)       itermvs.py:159-164
-       depth_head (MIOpen) -> K prob_regress                              itermvs.py:171-190
-    per iteration:
-    K  corr_iter         samples + warp + gather + group corr + view mean, 3 levels, 1 launch
-       3 x CorrNet (MIOpen) -> K pack_scores -> GRU convs (MIOpen) + K gru_rh / gru_out
-       depth_head (MIOpen) -> K prob_regress (probability volume never stored)
-    K  convex_upsample   9-tap softmax + convex x4 + un-normalise         module.py:127-152
-    K  bilinear_up x4    confidence                                       itermvs.py:323
+    feature_net      FeatureNet, BN folded, all B*V views in one batch, MFMA convs              net.py:36-65
+                       -> channels-last pyramids f1 [BV,H/2,W/2,16], f2 [BV,H/4,W/4,32], f3 [BV,H/8,W/8,48]
+    K  compose_proj    src @ inv(ref) for 3 levels x S views (+ inverse depth range)             module.py:77-90
+    K  ref_quarter     reference features on the 1/4 grid, packed                                itermvs.py:95-98
+    stage_init       K corr_init (per-view group correlation, 32 hypotheses)                     itermvs.py:48-51
+                       PixelViewWeight: K conv 3x3 + K pvw_tail (1x1 + softmax + max), K bilinear_up   :333-350,56
+                     K view_aggregate, CorrNet (6 K), hidden-init head (2 K) + K bilinear_up2(tanh)    :59-70,159-164
+    stage_head       K head_fused: depth head + softmax + arg-max window regression               itermvs.py:139-145,171-190
+    per iteration (itermvs.py:288-324):
+      stage_corr     K corr_iter: hypotheses + warp + gather + group corr + view mean, 3 levels
+      stage_corrnets 3 x CorrNet in 6 K (three weight sets per launch) -> scores into the GRU input buffers
+      stage_gru      ConvGRU: K (z, r gates, one launch two results) + K (q, state update)       module.py:52-66
+      stage_head     (+ confidence head on the last iteration)
+    K  convex_upsample 9-tap softmax + convex x4 + un-normalise                                  module.py:127-152
+    K  bilinear_up x4  confidence                                                                itermvs.py:323
 
-``K`` = hand-written HIP kernel behind the C ABI (itermvs_amd.ops).
+The stages read and write the persistent workspace of ``_workspace`` (GRU input buffers ``hx`` / ``hx2``, hidden state,
+CorrNet inputs); ``run`` is their composition, the teacher-forced parity tests drive them one by one.
 """
 from __future__ import annotations
 
 from typing import Dict, List, Mapping, Tuple
 
 import torch
-import torch.nn.functional as F
 
 from . import ops
 
@@ -54,12 +56,9 @@ def fold_batchnorm(w: Mapping[str, Tensor], prefix: str, eps: float = 1e-5) -> T
 
 
 class InferenceEngine:
-    """``backend``: "hip" (default) runs every convolution in the hand-written direct-conv kernels
-    (itermvs_conv2d, fused bias / ReLU / residual / GRU-gate epilogues, the three CorrNets of an
-    iteration batched per layer); "miopen" keeps the dense layers on PyTorch-ROCm/MIOpen (the
-    round-1 baseline, kept for A/B measurements)."""
+    """Test-mode ``IterMVS.forward`` (itermvs.py:253-329) on hand-written HIP kernels."""
 
-    def __init__(self, weights: Mapping[str, Tensor], iteration: int, backend: str = None):
+    def __init__(self, weights: Mapping[str, Tensor], iteration: int):
         w = {k: v.detach() for k, v in weights.items()}
         dev = w["feature_net.conv1.conv.weight"].device
         if dev.type != "cuda":
@@ -81,27 +80,14 @@ class InferenceEngine:
         # OR-ed with 1 by itermvs_compose_proj when a composed projection is NaN (module.py:83,87 assert on the host);
         # read and cleared by check_projection_finite()
         self.nan_flag = torch.zeros((1,), device=dev, dtype=torch.int32)
-        self._side = None          # second HIP stream for the independent branches (_fork / _join)
         self.profile_iterations = None   # set of iteration indices whose corr_iter launch carries timing events (None = all)
-        import os
-        # measured: 607 depth-maps/s with the two side branches forked vs 628 in one stream (cfg 1) -- the fork/join
-        # dependencies cost more than the ~40 us of overlap they buy; off unless ITERMVS_SIDE_STREAM=1
-        self._use_side = os.environ.get("ITERMVS_SIDE_STREAM", "0") == "1"
-        self._head_fused = os.environ.get("ITERMVS_HEAD_FUSED", "1") != "0"   # whole depth head in one launch
-        self.backend = backend or os.environ.get("ITERMVS_CONV_BACKEND", "hip")
-        if self.backend not in ("hip", "miopen"):
-            raise ValueError(f"unknown conv backend {self.backend!r}")
-        self.pk: Dict[str, Tensor] = {}
-        if self.backend == "hip":
-            self._pack_weights()
-            dh = "iter_mvs.update.depth_head."
-            self.head_w1, self.head_w2 = ops.pack_head_weights(w[dh + "2.weight"], w[dh + "4.weight"])
-            self.pk_zr = ops.MfmaWeight(self.w_zr)
+        self.pk: Dict[str, object] = {}
+        self._pack_weights()
 
+    # -- weights --------------------------------------------------------------------------------
     def _pack_weights(self) -> None:
-        """Re-lay every conv weight once (BatchNorm already folded): regular convolutions in the
-        matrix-core format [k*k, Cin_pad4, Cout_pad16], CorrNet's two transposed convolutions in the
-        VALU format [Cin,k,k,Cout]."""
+        """Re-lay every conv weight once (BatchNorm already folded) in the matrix-core formats of ``ops.MfmaWeight``
+        (CorrNet's two transposed convolutions included)."""
         w, pk = self.w, self.pk
         # the two layers with almost no contraction to feed a matrix core (3 -> 8 on the full-resolution images,
         # 8 -> 1 at the end of CorrNet) run faster on the one-thread-per-pixel VALU kernel: 31 vs 39 us, 6.7 vs 10.2 us
@@ -115,30 +101,22 @@ class InferenceEngine:
                 pk[k] = ops.MfmaWeight(v, transposed=True)
             else:
                 pk[k] = pack(v)
+        dh = "iter_mvs.update.depth_head."
+        self.head_w1, self.head_w2 = ops.pack_head_weights(w[dh + "2.weight"], w[dh + "4.weight"])
+        self.pk_zr = ops.MfmaWeight(self.w_zr)
 
     def _conv(self, x: Tensor, name: str, bias: bool = False, **kw) -> Tensor:
         """one layer by state-dict name (``name`` + "weight"/"bias")"""
         return ops.conv2d(x, self.pk[name + "weight"], self.w[name + "bias"] if bias else None, **kw)
 
-    # -- dense stacks on MIOpen ---------------------------------------------------------------
-    def _cbr(self, x: Tensor, name: str, stride: int, relu: bool) -> Tensor:
-        wt, b = self.cbr[name]
-        y = F.conv2d(x, wt, b, stride=stride, padding=1)
-        return F.relu_(y) if relu else y
-
-    def _res(self, x: Tensor, name: str, stride: int) -> Tensor:
-        y = self._cbr(self._cbr(x, name + "conv1.", stride, True), name + "conv2.", 1, False)
-        if stride != 1:
-            x = self._cbr(x, name + "downsample.", stride, False)
-        return F.relu_(y.add_(x))
-
-    def _cbr_hip(self, x: Tensor, name: str, stride: int, act: str, add: Tensor = None) -> Tensor:
+    # -- FeatureNet -----------------------------------------------------------------------------
+    def _cbr(self, x: Tensor, name: str, stride: int, act: str, add: Tensor = None) -> Tensor:
         return ops.conv2d(x, self.pk["feature_net." + name], self.cbr[name][1], stride=stride, act=act, add=add)
 
-    def _res_hip(self, x: Tensor, name: str, stride: int) -> Tensor:
+    def _res(self, x: Tensor, name: str, stride: int) -> Tensor:
         if stride == 1:
-            y = self._cbr_hip(x, name + "conv1.", 1, "relu")
-            return self._cbr_hip(y, name + "conv2.", 1, "relu", add=x)      # relu(x + y), module.py:50
+            y = self._cbr(x, name + "conv1.", 1, "relu")
+            return self._cbr(y, name + "conv2.", 1, "relu", add=x)      # relu(x + y), module.py:50
         # stride-2 block: conv1 (+ReLU) and the down-sampling shortcut read the same input -> one launch, two results
         key = "feature_net." + name + "conv1+downsample"
         if key not in self.pk:
@@ -148,45 +126,29 @@ class InferenceEngine:
         n, _, hh, ww = x.shape
         sc = torch.empty((n, c, (hh - 1) // 2 + 1, (ww - 1) // 2 + 1), device=x.device)
         y = ops.conv2d(x, wt, bias, stride=2, act="relu", split=(c, "none", sc))
-        return self._cbr_hip(y, name + "conv2.", 1, "relu", add=sc)
+        return self._cbr(y, name + "conv2.", 1, "relu", add=sc)
 
     def feature_net(self, x: Tensor) -> Dict[int, Tensor]:
-        """net.py:36-65 with BN folded; x [M,3,H,W] -> NCHW pyramids {1,2,3}."""
-        w, p = self.w, "feature_net."
-        if self.backend == "hip":
-            m, _, hh, ww = x.shape
-            dev = x.device
-            cl = lambda c, s: torch.empty((m, c, hh // s, ww // s), device=dev, memory_format=torch.channels_last)
-            o1, o2, o3 = cl(16, 2), cl(32, 4), cl(48, 8)
-            self.o2_planar = torch.empty((m, 32, hh // 4, ww // 4), device=dev)
-
-            def branch(lo: int, hi: int) -> None:
-                """views lo..hi-1 through the pyramid; the three outputs land in their batch slices (channels-last, the
-                layout the correlation kernels gather from; level 2 also keeps a planar copy for the up-sampling head)"""
-                f0 = self._cbr_hip(x[lo:hi], "conv1.", 1, "relu")
-                f1 = self._res_hip(self._res_hip(f0, "layer1.0.", 2), "layer1.1.", 1)
-                f2 = self._res_hip(self._res_hip(f1, "layer2.0.", 2), "layer2.1.", 1)
-                f3 = self._res_hip(self._res_hip(f2, "layer3.0.", 2), "layer3.1.", 1)
-                self._conv(f3, p + "output3.", bias=True, channels_last_out=True, out=o3[lo:hi])
-                mid = self._conv(f2, p + "inner2.", bias=True, ksize=1, pad=0, add=f3, add_up2=True)   # net.py:46 (fused F.interpolate)
-                self._conv(mid, p + "output2.", bias=True, channels_last_out=True, out=o2[lo:hi], out2=self.o2_planar[lo:hi])
-                mid = self._conv(f1, p + "inner1.", bias=True, ksize=1, pad=0, add=mid, add_up2=True)  # net.py:49
-                self._conv(mid, p + "output1.", bias=True, channels_last_out=True, out=o1[lo:hi])
-
-            # (running two groups of views on two streams was measured: 694 vs 707 depth-maps/s -- not kept)
-            branch(0, m)
-            return {1: o1, 2: o2, 3: o3}
-        f0 = self._cbr(x, "conv1.", 1, True)
+        """net.py:36-65 with BN folded; x [M,3,H,W] -> channels-last pyramids {1,2,3} (the layout the correlation kernels
+        gather from); level 2 also keeps a planar copy (``o2_planar``) for the up-sampling head."""
+        p = "feature_net."
+        m, _, hh, ww = x.shape
+        dev = x.device
+        cl = lambda c, s: torch.empty((m, c, hh // s, ww // s), device=dev, memory_format=torch.channels_last)
+        o1, o2, o3 = cl(16, 2), cl(32, 4), cl(48, 8)
+        self.o2_planar = torch.empty((m, 32, hh // 4, ww // 4), device=dev)
+        f0 = self._cbr(x, "conv1.", 1, "relu")
         f1 = self._res(self._res(f0, "layer1.0.", 2), "layer1.1.", 1)
         f2 = self._res(self._res(f1, "layer2.0.", 2), "layer2.1.", 1)
         f3 = self._res(self._res(f2, "layer3.0.", 2), "layer3.1.", 1)
-        o3 = F.conv2d(f3, w[p + "output3.weight"], w[p + "output3.bias"], padding=1)
-        mid = ops.bilinear_up(f3, 2).add_(F.conv2d(f2, w[p + "inner2.weight"], w[p + "inner2.bias"]))   # net.py:46
-        o2 = F.conv2d(mid, w[p + "output2.weight"], w[p + "output2.bias"], padding=1)
-        mid = ops.bilinear_up(mid, 2).add_(F.conv2d(f1, w[p + "inner1.weight"], w[p + "inner1.bias"]))  # net.py:49
-        o1 = F.conv2d(mid, w[p + "output1.weight"], w[p + "output1.bias"], padding=1)
+        self._conv(f3, p + "output3.", bias=True, channels_last_out=True, out=o3)
+        mid = self._conv(f2, p + "inner2.", bias=True, ksize=1, pad=0, add=f3, add_up2=True)   # net.py:46 (fused F.interpolate)
+        self._conv(mid, p + "output2.", bias=True, channels_last_out=True, out=o2, out2=self.o2_planar)
+        mid = self._conv(f1, p + "inner1.", bias=True, ksize=1, pad=0, add=mid, add_up2=True)  # net.py:49
+        self._conv(mid, p + "output1.", bias=True, channels_last_out=True, out=o1)
         return {1: o1, 2: o2, 3: o3}
 
+    # -- small stacks ---------------------------------------------------------------------------
     def corr_nets(self, x: Tensor, levels, seg_end=(), out: Tensor = None, out2: Tensor = None) -> Tensor:
         """itermvs.py:352-381 for one or three levels in ONE launch per layer: x [M,8,h,w] whose batch
         items [0,seg_end[0]) / [seg_end[0],seg_end[1]) / rest belong to levels[0..2] -> [M,1,h,w]."""
@@ -199,68 +161,23 @@ class InferenceEngine:
         u0 = ops.conv2d(u1, wl("conv4.weight"), None, transposed=True, stride=2, add=c0, seg_end=seg_end)
         return ops.conv2d(u0, wl("conv5.weight"), [self.w[p + "conv5.bias"] for p in ps], seg_end=seg_end, out=out, out2=out2)
 
-    def corr_net(self, x: Tensor, level: int) -> Tensor:
-        """itermvs.py:352-381 on [M,8,h,w] -> [M,1,h,w]."""
-        if self.backend == "hip":
-            return self.corr_nets(x, [level])
-        w, p = self.w, f"iter_mvs.evaluation.corr_conv1.{level - 1}."
-        c0 = F.relu_(F.conv2d(x, w[p + "conv0.conv.weight"], padding=1))
-        c1 = F.relu_(F.conv2d(c0, w[p + "conv1.conv.weight"], stride=2, padding=1))
-        c2 = F.relu_(F.conv2d(c1, w[p + "conv2.conv.weight"], stride=2, padding=1))
-        u1 = F.conv_transpose2d(c2, w[p + "conv3.weight"], stride=2, padding=1, output_padding=1).add_(c1)
-        u0 = F.conv_transpose2d(u1, w[p + "conv4.weight"], stride=2, padding=1, output_padding=1).add_(c0)
-        return F.conv2d(u0, w[p + "conv5.weight"], w[p + "conv5.bias"], padding=1)
-
-    def depth_regress(self, hidden: Tensor, nd_out, trace_logits: bool):
-        """depth head + softmax regression (itermvs.py:121-126, 171-190): -> (logits | None, best | None).
-        Without a trace the two 1x1 layers and the regression are ONE launch (itermvs_head_regress) and the
-        256-bin logits never reach memory."""
-        if self.backend == "hip" and not trace_logits:
-            p = "iter_mvs.update.depth_head."
-            if self._head_fused:
-                ops.head_fused(hidden, self.pk[p + "0.weight"], self.head_w1, self.head_w2, self.w[p + "4.bias"], nd_out=nd_out)
-            else:
-                x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu")
-                ops.head_regress(x, self.head_w1, self.head_w2, self.w[p + "4.bias"], nd_out=nd_out)
-            return None, None
-        logits = self.depth_head(hidden)
-        _, _, best = ops.prob_regress(logits, nd_out=nd_out, want_best=trace_logits)
-        return logits, best
-
     def depth_head(self, hidden: Tensor) -> Tensor:
-        w, p = self.w, "iter_mvs.update.depth_head."
-        if self.backend == "hip":
-            x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu")
-            x = self._conv(x, p + "2.", ksize=1, pad=0, act="relu")
-            return self._conv(x, p + "4.", bias=True, ksize=1, pad=0)
-        x = F.relu_(F.conv2d(hidden, w[p + "0.weight"], padding=2, dilation=2))
-        x = F.relu_(F.conv2d(x, w[p + "2.weight"]))
-        return F.conv2d(x, w[p + "4.weight"], w[p + "4.bias"])
+        """itermvs.py:139-145 layer by layer -> logits [B,256,h,w] (traced / teacher-forced runs only)"""
+        p = "iter_mvs.update.depth_head."
+        x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu")
+        x = self._conv(x, p + "2.", ksize=1, pad=0, act="relu")
+        return self._conv(x, p + "4.", bias=True, ksize=1, pad=0)
 
     def confidence(self, hidden: Tensor, mid: Tensor = None, out: Tensor = None) -> Tensor:
-        w, p = self.w, "iter_mvs.update.confidence_head."
-        if self.backend == "hip":
-            x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu", out=mid)
-            return self._conv(x, p + "2.", bias=True, ksize=1, pad=0, act="sigmoid", out=out)
-        x = F.relu_(F.conv2d(hidden, w[p + "0.weight"], padding=2, dilation=2))
-        return torch.sigmoid_(F.conv2d(x, w[p + "2.weight"], w[p + "2.bias"]))
+        """itermvs.py:147-151 + sigmoid (:198)"""
+        p = "iter_mvs.update.confidence_head."
+        x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu", out=mid)
+        return self._conv(x, p + "2.", bias=True, ksize=1, pad=0, act="sigmoid", out=out)
 
-    # -- independent branches on a second HIP stream (fork / join; captured as parallel graph branches) --------
-    def _fork(self, fn) -> None:
-        """run ``fn`` on the side stream, ordered after everything enqueued so far on the current stream.
-        ``fn`` must only write pre-allocated workspace buffers (no allocation on the side stream)."""
-        if not self._use_side:
-            return fn()
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        cur = torch.cuda.current_stream(self.device)
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
-            fn()
-
-    def _join(self) -> None:
-        if self._use_side and self._side is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self._side)
+    def upsample_logits(self, ref2_nchw: Tensor, ws: dict) -> Tensor:
+        """itermvs.py:262-263 (the softmax over the 9 taps is part of convex_upsample)"""
+        u = "iter_mvs.upsample."
+        return self._conv(self._conv(ref2_nchw, u + "0.", act="relu", out=ws["up_mid"]), u + "2.", ksize=1, pad=0, out=ws["up_logits"])
 
     # -- workspace ------------------------------------------------------------------------------
     def _workspace(self, b: int, h: int, w: int) -> dict:
@@ -275,7 +192,6 @@ class InferenceEngine:
                 "hidden": torch.empty((b, HIDDEN, h, w), device=dev),
                 "agg_all": torch.empty((b * (nx - 1), 8, h, w), device=dev),   # the three levels' CorrNet inputs, back to back
                 "zbuf": torch.empty((b, HIDDEN, h, w), device=dev),
-                # outputs / intermediates of the two side branches (allocated here, on the main stream)
                 "up_mid": torch.empty((b, 64, h, w), device=dev),
                 "up_logits": torch.empty((b, 144, h, w), device=dev),
                 "conf_mid": torch.empty((b, HIDDEN, h, w), device=dev),
@@ -287,130 +203,129 @@ class InferenceEngine:
                 views.append(ws["agg_all"][o:o + n].view(b, len(self.offsets[l]), 8, h, w))
                 o += n
             ws["agg"] = views
+            ws["b"] = b
             self._ws[key] = ws
         return ws
 
+    # -- stages (each reads / writes the workspace; see the module docstring) ---------------------
+    def stage_init(self, ws: dict, src3: List[Tensor], ref3: Tensor, proj3: Tensor, inv_min: Tensor, inv_max: Tensor,
+                   trace: dict = None) -> Tensor:
+        """itermvs.py:36-70 + :159-164: view weights [B,S,h,w] (returned) and the initial hidden state (``hidden``, ``hx``)"""
+        b, _, h3, w3 = ref3.shape
+        s = len(src3)
+        w = self.w
+        corr_v = ops.corr_init(src3, ref3, proj3, inv_min, inv_max, INIT_SAMPLES)                 # [B,S,32,8,h3,w3]
+        pv = "iter_mvs.evaluation.pixel_view_weight."
+        x = self._conv(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), pv + "conv.0.conv.", act="relu")
+        vw = ops.pvw_tail(x, w[pv + "conv.1.weight"], w[pv + "conv.1.bias"], INIT_SAMPLES)        # 1x1 + softmax + max
+        view_w = ops.bilinear_up(vw, 2).view(b, s, 2 * h3, 2 * w3)                                 # itermvs.py:56-57,71
+        agg0 = ops.view_aggregate(corr_v, vw.view(b, s, h3, w3))                                   # [B,32,8,h3,w3]
+        score0 = self.stage_score0(agg0)
+        self.stage_hidden0(ws, score0)
+        if trace is not None:
+            trace.update(corr_views=corr_v, view_weights=view_w, init_agg=agg0, init_score=score0,
+                         hidden0=ws["hidden"].clone())
+        return view_w
+
+    def stage_score0(self, agg0: Tensor) -> Tensor:
+        """itermvs.py:70: CorrNet[2] on the aggregated initial correlation [B,32,8,h3,w3] -> [B,32,h3,w3]"""
+        b, n, _, h3, w3 = agg0.shape
+        return self.corr_nets(agg0.view(b * n, 8, h3, w3), [3]).view(b, n, h3, w3)
+
+    def stage_hidden0(self, ws: dict, score0: Tensor) -> None:
+        """itermvs.py:159-164: hidden-init head + x2 bilinear + tanh, written to ``hidden`` and ``hx[:, :32]`` in one launch"""
+        hi = "iter_mvs.update.hidden_init_head."
+        x = self._conv(self._conv(score0, hi + "0.", act="relu"), hi + "2.", bias=True, ksize=1, pad=0)
+        ops.bilinear_up_into(x, 2, ws["hidden"], ws["hx"][:, :HIDDEN], act="tanh")
+
+    def stage_head(self, ws: dict, want_logits: bool = False, want_best: bool = False):
+        """depth head + softmax regression (itermvs.py:139-145, 171-190 / 201-219) on ``hidden``; the normalised depth goes
+        to channel 32 of both GRU input buffers.  Default: ONE launch (itermvs_head_fused), the 256-bin logits never reach
+        memory; ``want_logits`` evaluates the head layer by layer.  Returns (logits | None, arg-max bins | None)."""
+        hidden, nd_out = ws["hidden"], [(ws["hx"], HIDDEN), (ws["hx2"], HIDDEN)]
+        if not want_logits:
+            p = "iter_mvs.update.depth_head."
+            _, best = ops.head_fused(hidden, self.pk[p + "0.weight"], self.head_w1, self.head_w2, self.w[p + "4.bias"],
+                                     nd_out=nd_out, want_best=want_best)
+            return None, best
+        logits = self.depth_head(hidden)
+        _, _, best = ops.prob_regress(logits, nd_out=nd_out, want_best=True)
+        return logits, best
+
+    def stage_corr(self, ws: dict, src, ref_q: Tensor, proj: Tensor, view_w: Tensor, inv_min: Tensor, inv_max: Tensor,
+                   timed: bool = True) -> List[Tensor]:
+        """itermvs.py:290-293 + :84-120: hypotheses around ``hx[:, 32]`` -> the three CorrNet inputs (``agg``)"""
+        return ops.corr_iter(src, ref_q, proj, view_w, inv_min, inv_max, norm_depth=ws["hx"][:, HIDDEN:HIDDEN + 1],
+                             offsets=self.offsets, out=ws["agg"], timed=timed)
+
+    def stage_corrnets(self, ws: dict) -> None:
+        """itermvs.py:121-124: the three CorrNets, one launch per layer over all 10*B maps; scores -> channels 33..42 of
+        ``hx`` and ``hx2`` (for B = 1 written there directly by the last layer)"""
+        b = ws["b"]
+        hx, hx2 = ws["hx"], ws["hx2"]
+        h, wd = hx.shape[2:]
+        n1, n2 = b * len(self.offsets[1]), b * (len(self.offsets[1]) + len(self.offsets[2]))
+        if b == 1:
+            self.corr_nets(ws["agg_all"], (1, 2, 3), (n1, n2), out=hx[0, HIDDEN + 1:].unsqueeze(1), out2=hx2[0, HIDDEN + 1:].unsqueeze(1))
+        else:
+            sc = self.corr_nets(ws["agg_all"], (1, 2, 3), (n1, n2))
+            scores = [sc[:n1].view(b, -1, h, wd), sc[n1:n2].view(b, -1, h, wd), sc[n2:].view(b, -1, h, wd)]
+            ops.pack_scores(scores, hx, hx2, HIDDEN + 1)
+
+    def stage_gru(self, ws: dict) -> None:
+        """ConvGRU (module.py:59-66) with the gate math in the conv epilogues: the update and reset gates read the same
+        input -> one launch, two results (z -> ``zbuf``, r*h -> ``hx2``); then q and the state update (-> ``hx``, ``hidden``)"""
+        hx, hx2, zbuf = ws["hx"], ws["hx2"], ws["zbuf"]
+        ops.conv2d(hx, self.pk_zr, self.b_zr, pad=2, dilation=2, act="sigmoid", out=zbuf, aux1=hx[:, :HIDDEN],
+                   split=(HIDDEN, "gru_rh", hx2[:, :HIDDEN]))
+        self._conv(hx2, "iter_mvs.update.gru.convq.", bias=True, pad=2, dilation=2, act="gru_out", aux1=hx[:, :HIDDEN],
+                   aux2=zbuf, out=hx[:, :HIDDEN], out2=ws["hidden"])
+
     # -- one batch of reference views -----------------------------------------------------------
-    def run(self, imgs: Tensor, projs: Dict[int, Tensor], depth_min: Tensor, depth_max: Tensor,
-            trace: dict = None) -> Tuple[Tensor, Tensor]:
-        """imgs [B,V,3,H,W]; projs[l] [B,V,4,4] (l = 1..3); depth_min/max [B]
-        -> (depth [B,1,H,W], confidence [B,1,H,W]) like itermvs.py:326-327 / net.py:125-128."""
+    def run(self, imgs: Tensor, projs, depth_min: Tensor, depth_max: Tensor, trace: dict = None) -> Tuple[Tensor, Tensor]:
+        """imgs [B,V,3,H,W]; projs {1,2,3: [B,V,4,4]} like the reference's sample dict, or the same stacked [3,B,V,4,4];
+        depth_min/max [B] -> (depth [B,1,H,W], confidence [B,1,H,W]) like itermvs.py:326-327 / net.py:125-128.
+        ``trace`` (dict) collects the intermediate tensors and evaluates the depth head layer by layer (logits kept)."""
         b, v, _, hh, ww = imgs.shape
         s = v - 1
-        w = self.w
         feats = self.feature_net(imgs.reshape(b * v, 3, hh, ww).contiguous())
-        cl = {l: ops.channels_last(f) for l, f in feats.items()}
-        per_view = {l: cl[l].view(b, v, *cl[l].shape[1:]) for l in (1, 2, 3)}
+        per_view = {l: feats[l].view(b, v, *feats[l].shape[1:]) for l in (1, 2, 3)}
         src = {l: [per_view[l][:, i] for i in range(1, v)] for l in (1, 2, 3)}
         ref = {l: per_view[l][:, 0] for l in (1, 2, 3)}
         h, wd = feats[2].shape[2:]
-        h3, w3 = feats[3].shape[2:]
         ws = self._workspace(b, h, wd)
-        hx, hx2, hidden = ws["hx"], ws["hx2"], ws["hidden"]
+        hx = ws["hx"]
 
-        # projs: {1,2,3: [B,V,4,4]} like the reference's sample dict, or the same stacked [3,B,V,4,4]
         pstack = projs if torch.is_tensor(projs) else torch.stack([projs[1], projs[2], projs[3]])
         proj, inv_min, inv_max = ops.compose_proj(pstack.reshape(3 * b, v, 4, 4), self.nan_flag, (depth_min, depth_max))
         proj = proj.view(3, b, s, 12)
 
-        # convex up-sampling logits from the reference level-2 feature (itermvs.py:262-263)
-        # (packed copy: a strided batch-1 view would send MIOpen to its naive non-packed kernel)
-        if self.backend == "hip":
-            f2p = self.o2_planar
-            ref2_nchw = f2p[:1] if b == 1 else f2p.view(b, v, *f2p.shape[1:])[:, 0].contiguous()
-        else:
-            ref2_nchw = feats[2][:1] if b == 1 else feats[2].view(b, v, *feats[2].shape[1:])[:, 0].contiguous()
-        u = "iter_mvs.upsample."
-        if self.backend == "hip":
-            # only needed by the final convex up-sampling: a side branch next to the initialisation chain
-            up_logits = ws["up_logits"]
-            self._fork(lambda: self._conv(self._conv(ref2_nchw, u + "0.", act="relu", out=ws["up_mid"]), u + "2.",
-                                          ksize=1, pad=0, out=up_logits))
-        else:
-            up_logits = F.conv2d(F.relu_(F.conv2d(ref2_nchw, w[u + "0.weight"], padding=1)), w[u + "2.weight"])
-
+        f2p = self.o2_planar
+        ref2_nchw = f2p[:1] if b == 1 else f2p.view(b, v, *f2p.shape[1:])[:, 0].contiguous()
+        up_logits = self.upsample_logits(ref2_nchw, ws)                 # only needed by the final convex up-sampling
         ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
 
-        # ---- initialisation (itermvs.py:270-276) ------------------------------------------
-        corr_v = ops.corr_init(src[3], ref[3], proj[2], inv_min, inv_max, INIT_SAMPLES)       # [B,S,32,8,h3,w3]
-        pv = "iter_mvs.evaluation.pixel_view_weight."
-        if self.backend == "hip":
-            x = self._conv(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), pv + "conv.0.conv.", act="relu")
-            vw = ops.pvw_tail(x, w[pv + "conv.1.weight"], w[pv + "conv.1.bias"], INIT_SAMPLES)     # 1x1 + softmax + max
-        else:
-            x = F.relu_(F.conv2d(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), w[pv + "conv.0.conv.weight"], padding=1))
-            x = F.conv2d(x, w[pv + "conv.1.weight"], w[pv + "conv.1.bias"])
-        if self.backend != "hip":
-            vw = ops.softmax_max(x.view(b * s, INIT_SAMPLES, h3, w3))                           # [B*S,1,h3,w3]
-        view_w = ops.bilinear_up(vw, 2).view(b, s, h, wd)                                       # itermvs.py:56-57,71
-        agg0 = ops.view_aggregate(corr_v, vw.view(b, s, h3, w3))                                # [B,32,8,h3,w3]
-        score0 = self.corr_net(agg0.view(b * INIT_SAMPLES, 8, h3, w3), 3).view(b, INIT_SAMPLES, h3, w3)
-        hi = "iter_mvs.update.hidden_init_head."
-        if self.backend == "hip":
-            x = self._conv(self._conv(score0, hi + "0.", act="relu"), hi + "2.", bias=True, ksize=1, pad=0)
-        else:
-            x = F.conv2d(F.relu_(F.conv2d(score0, w[hi + "0.weight"], padding=1)), w[hi + "2.weight"], w[hi + "2.bias"])
-        if self.backend == "hip":                                                               # itermvs.py:161-163
-            hidden0 = ops.bilinear_up_into(x, 2, hidden, hx[:, :HIDDEN], act="tanh")            # both copies in one launch
-        else:
-            hidden0 = ops.bilinear_up(x, 2, act="tanh")
-            hidden.copy_(hidden0)
-            hx[:, :HIDDEN].copy_(hidden0)
-        logits, best = self.depth_regress(hidden, [(hx, HIDDEN), (hx2, HIDDEN)], trace is not None)
+        view_w = self.stage_init(ws, src[3], ref[3], proj[2], inv_min, inv_max, trace)          # itermvs.py:270-276
+        logits, best = self.stage_head(ws, trace is not None)
         if trace is not None:
-            trace.update(feats=feats, proj=proj, ref_q=ref_q, corr_views=corr_v, view_weights=view_w, init_agg=agg0,
-                         init_score=score0, hidden0=hidden0.clone(), logits0=logits, nd0=hx[:, HIDDEN:HIDDEN + 1].clone(),
-                         best0=best, up_logits=up_logits, iters=[])
+            trace.update(feats=feats, proj=proj, ref_q=ref_q, logits0=logits, nd0=hx[:, HIDDEN:HIDDEN + 1].clone(), best0=best,
+                         up_logits=up_logits, iters=[])
 
-        if self.backend == "hip":
-            self._join()        # the side branch ends inside this graph segment
-        # ---- iterations (itermvs.py:288-324) -----------------------------------------------
-        g = "iter_mvs.update.gru."
         conf = None
-        for it in range(self.iteration):
+        for it in range(self.iteration):                                                         # itermvs.py:288-324
             # (bench.py: only the iterations in ``profile_iterations`` get timing events around this launch)
             timed = self.profile_iterations is None or it in self.profile_iterations
-            aggs = ops.corr_iter(src, ref_q, proj, view_w, inv_min, inv_max, norm_depth=hx[:, HIDDEN:HIDDEN + 1],
-                                 offsets=self.offsets, out=ws["agg"], timed=timed)
             nd_in = hx[:, HIDDEN:HIDDEN + 1].clone() if trace is not None else None
-            if self.backend == "hip":
-                # three CorrNets: one launch per layer over all 10*B maps; for B = 1 the last layer writes
-                # the ten score planes straight into channels 33..42 of both GRU input buffers
-                n1, n2 = b * len(self.offsets[1]), b * (len(self.offsets[1]) + len(self.offsets[2]))
-                if b == 1:
-                    sc = self.corr_nets(ws["agg_all"], (1, 2, 3), (n1, n2), out=hx[0, HIDDEN + 1:].unsqueeze(1),
-                                        out2=hx2[0, HIDDEN + 1:].unsqueeze(1))
-                    scores = [sc.squeeze(1).unsqueeze(0)] if trace is not None else None
-                else:
-                    sc = self.corr_nets(ws["agg_all"], (1, 2, 3), (n1, n2))
-                    scores = [sc[:n1].view(b, -1, h, wd), sc[n1:n2].view(b, -1, h, wd), sc[n2:].view(b, -1, h, wd)]
-                    ops.pack_scores(scores, hx, hx2, HIDDEN + 1)
-                # ConvGRU (module.py:59-66): gate math fused into the conv epilogues
-                zbuf = ws["zbuf"]
-                # update and reset gates read the same input: one launch, two results (z -> zbuf, r*h -> hx2)
-                ops.conv2d(hx, self.pk_zr, self.b_zr, pad=2, dilation=2, act="sigmoid", out=zbuf, aux1=hx[:, :HIDDEN],
-                           split=(HIDDEN, "gru_rh", hx2[:, :HIDDEN]))
-                self._conv(hx2, g + "convq.", bias=True, pad=2, dilation=2, act="gru_out", aux1=hx[:, :HIDDEN],
-                           aux2=zbuf, out=hx[:, :HIDDEN], out2=hidden)
-            else:
-                scores = [self.corr_net(a.view(-1, 8, h, wd), l).view(b, -1, h, wd) for l, a in zip((1, 2, 3), aggs)]
-                ops.pack_scores(scores, hx, hx2, HIDDEN + 1)
-                zr = F.conv2d(hx, self.w_zr, self.b_zr, padding=2, dilation=2)
-                ops.gru_rh(zr, hx, hx2, HIDDEN)
-                q = F.conv2d(hx2, w[g + "convq.weight"], w[g + "convq.bias"], padding=2, dilation=2)
-                ops.gru_out(zr, q, hx, hidden, HIDDEN)
-            last = it == self.iteration - 1
-            if last and self.backend == "hip":                                                  # itermvs.py:197-199
-                conf = ws["conf"]
-                self._fork(lambda: self.confidence(hidden, ws["conf_mid"], conf))               # next to the depth head
-            elif last:
-                conf = self.confidence(hidden)
-            logits, best = self.depth_regress(hidden, [(hx, HIDDEN), (hx2, HIDDEN)], trace is not None)
-            if last and self.backend == "hip":
-                self._join()
+            aggs = self.stage_corr(ws, src, ref_q, proj, view_w, inv_min, inv_max, timed)
+            self.stage_corrnets(ws)
+            score = hx[:, HIDDEN + 1:].clone() if trace is not None else None
+            self.stage_gru(ws)
+            if it == self.iteration - 1:                                                         # itermvs.py:197-199
+                conf = self.confidence(ws["hidden"], ws["conf_mid"], ws["conf"])
+            logits, best = self.stage_head(ws, trace is not None)
             if trace is not None:
-                trace["iters"].append(dict(nd_in=nd_in, aggs=[a.clone() for a in aggs], score=torch.cat(scores, 1),
-                                           hidden=hidden.clone(), logits=logits, best=best,
+                trace["iters"].append(dict(nd_in=nd_in, aggs=[a.clone() for a in aggs], score=score,
+                                           hidden=ws["hidden"].clone(), logits=logits, best=best,
                                            nd=hx[:, HIDDEN:HIDDEN + 1].clone(), conf=conf))
 
         depth_up = ops.convex_upsample(up_logits, hx, inv_min, inv_max, nd_channel=HIDDEN)      # itermvs.py:321-322
@@ -430,11 +345,11 @@ class GraphedRunner:
     """One depth map per replay with no host work: ``InferenceEngine.run`` captured into ONE hipGraph
     (torch.cuda.CUDAGraph) on a private stream, with static input / output buffers.
 
-    A replay is one graph launch instead of ~110 Python-driven kernel launches; several runners on different
+    A replay is one graph launch instead of ~85 Python-driven kernel launches; several runners on different
     streams keep independent reference views in flight on one GPU (replay happens on the caller's current
     stream; only the capture uses a private stream).  When the library's timing hooks are enabled at capture
-    time, the ``itermvs_corr_iter`` launches are bracketed by external event-record nodes inside the graph
-    (``profile_pairs`` = their range for ``ops.profile_graph_read``), so bench.py times them in the timed region.
+    time, the ``itermvs_corr_iter`` / ``itermvs_corr_init`` launches are bracketed by external event-record nodes inside
+    the graph (``profile_pairs`` = their range for ``ops.profile_graph_read``), so bench.py times them in the timed region.
     Outputs are static buffers, overwritten by the next replay on the same runner."""
 
     def __init__(self, engine: InferenceEngine, imgs: Tensor, projs: Dict[int, Tensor], depth_min: Tensor,

@@ -165,3 +165,15 @@ def make_scene_sample(num_views: int = 5, height: int = 512, width: int = 640, s
         "depth_max": torch.full((1,), DTU_DEPTH_MAX, dtype=torch.float32),
         "depth_gt": torch.from_numpy(depth_gt[None, None].astype(np.float32)),
     }
+
+
+def make_training_sample(num_views: int = 5, height: int = 512, width: int = 640, seed: int = 2, hole_fraction: float = 0.1):
+    """One BASELINE cfg-4 shaped training sample (B = 1): the photo-consistent scene of :func:`make_scene_sample` with its
+    exact depth as ground truth and a seeded validity mask with ``hole_fraction`` of the pixels masked out, in the
+    reference's training schema (datasets/dtu_yao.py:227-232) -> (sample, depth_gt {'level_0','level_2'}, mask {...})."""
+    sample = make_scene_sample(num_views=num_views, height=height, width=width, seed=seed)
+    gt0 = sample["depth_gt"]
+    gen = torch.Generator().manual_seed(31 + seed)
+    m0 = (torch.rand(gt0.shape, generator=gen) > hole_fraction).float()
+    return sample, {"level_0": gt0, "level_2": gt0[:, :, ::4, ::4].contiguous()}, \
+        {"level_0": m0, "level_2": m0[:, :, ::4, ::4].contiguous()}

@@ -256,23 +256,35 @@ def golden_train(weights):
     save("train_small.npz", **arrays)
 
 
-def main():
-    torch.manual_seed(0)
-    torch.set_num_threads(8)
-    w0, wd = golden_weights()
-    golden_warp()
-    golden_upsample()
-    record_e2e(w0, "seed0")
-    record_e2e(wd, "dtu")
-    golden_cfg1(w0, "seed0")
-    golden_cfg1(wd, "dtu")
-    golden_cfg1(wd, "dtu", scene=True)
-    golden_train(w0)
-    golden_pfm()
-
-
-if __name__ == "__main__":
-    main()
+# ----------------------------------------------------------------------------
+# 6b. BASELINE cfg 4 at its real size: ONE training step (forward in train mode + full_loss + backward) at
+#     B=1, V=5, 640x512, 4 iterations.  Inputs are regenerated from seeds on the GPU box; only the loss, the
+#     per-parameter gradient norms and a few output statistics are stored.
+# ----------------------------------------------------------------------------
+def golden_train_cfg4(weights):
+    sample, gt, mask = synthetic.make_training_sample(num_views=5, height=512, width=640, seed=2)
+    arrays = {"iteration": np.int64(4)}
+    for regress in (True, False):
+        model = build_reference(weights, 4, test=False)
+        out = model(sample["imgs"], sample["proj_matrices"], sample["depth_min"], sample["depth_max"])
+        loss = ref_net.full_loss(out["depths"], out["depths_upsampled"], out["confidences"], gt, mask,
+                                 sample["depth_min"], sample["depth_max"], regress)
+        loss.backward()
+        tag = "regress" if regress else "noregress"
+        arrays[f"{tag}.loss"] = np.float64(loss.item())
+        names, norms = [], []
+        for k, p in model.named_parameters():
+            names.append(k)
+            norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+        arrays[f"{tag}.grad_names"] = np.array(names)
+        arrays[f"{tag}.grad_norms"] = np.array(norms, dtype=np.float64)
+        if regress:
+            d = out["depths_upsampled"][0]
+            arrays["train.depth_sub"] = npy(d[:, :, ::8, ::8])
+            arrays["train.depth_abs_err_median"] = np.float64((d - gt["level_0"]).abs().median().item())
+            arrays["train.initial_sub"] = npy(out["depths"]["initial"][0][:, :, ::4, ::4])
+        print(f"  train cfg4 {tag}: loss {loss.item():.6f}")
+    save("train_cfg4.npz", **arrays)
 
 
 # ----------------------------------------------------------------------------
@@ -289,3 +301,38 @@ def golden_pfm():
     raw = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
     back, scale = read_pfm(path)
     save("pfm.npz", image=img, file_bytes=raw, readback=np.ascontiguousarray(back), scale=np.float64(scale))
+
+
+def main():
+    """``make_golden.py`` rewrites every fixture; ``make_golden.py train_cfg4 pfm`` only the named ones"""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    only = set(sys.argv[1:])
+    want = lambda name: not only or name in only
+    w0, wd = golden_weights() if want("weights") else (synthetic.random_state_dict(0), None)
+    if wd is None and (not only or only & {"e2e", "cfg1"}):
+        wd = strip_module_prefix(torch.load(os.path.join(REF, "checkpoints/dtu/model_000015.ckpt"), map_location="cpu",
+                                            weights_only=False)["model"])
+    if want("warp"):
+        golden_warp()
+    if want("upsample"):
+        golden_upsample()
+    if want("e2e"):
+        record_e2e(w0, "seed0")
+        record_e2e(wd, "dtu")
+    if want("cfg1"):
+        golden_cfg1(w0, "seed0")
+        golden_cfg1(wd, "dtu")
+        golden_cfg1(wd, "dtu", scene=True)
+    if want("train"):
+        golden_train(w0)
+    if want("train_cfg4"):
+        golden_train_cfg4(w0)
+    if want("pfm"):
+        golden_pfm()
+
+
+if __name__ == "__main__":
+    main()
+
+

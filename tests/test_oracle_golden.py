@@ -221,3 +221,29 @@ def test_train_step_loss_and_grads(weights_seed0):
             best = torch.argmax(out["depths"]["probability"][-1], 1, keepdim=True)
             assert float((best != g["train.best_last"]).float().mean()) <= 0.01
             assert maxdiff(w["feature_net.conv1.bn.running_mean"].detach(), g["train.running_mean_conv1"]) <= 1e-6
+
+
+def test_train_step_cfg4_full_size(weights_seed0):
+    """BASELINE cfg 4 at its real size (B=1, 5 views, 640x512, 4 iterations): loss and all 102 gradient norms of the
+    reference's training step (tests/golden/train_cfg4.npz); inputs regenerated from seeds"""
+    from itermvs_amd import synthetic
+    g = golden("train_cfg4.npz")
+    sample, gt, mk = synthetic.make_training_sample(num_views=5, height=512, width=640, seed=2)
+    torch.set_num_threads(min(16, max(8, torch.get_num_threads())))
+    w = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in weights_seed0.items()}
+    out = O.pipeline_forward(w, sample["imgs"], sample["proj_matrices"], sample["depth_min"], sample["depth_max"],
+                             iteration=int(g.np("iteration")), test=False, training=True)
+    loss = O.full_loss(out["depths"], out["depths_upsampled"], out["confidences"], gt, mk, sample["depth_min"],
+                       sample["depth_max"], True)
+    ref = float(g.np("regress.loss"))
+    assert abs(loss.item() - ref) <= 2e-4 * abs(ref), (loss.item(), ref)
+    loss.backward()
+    for n, want in zip([str(n) for n in g.np("regress.grad_names")], g.np("regress.grad_norms")):
+        got = w[n].grad
+        if want < 0:
+            assert got is None or float(got.norm()) == 0.0, n
+        else:
+            assert abs(float(got.norm()) - want) <= 5e-3 * max(want, 1e-3), (n, float(got.norm()), want)
+    d = out["depths_upsampled"][0].detach()
+    rel = (d[:, :, ::8, ::8] - g["train.depth_sub"]).abs() / g["train.depth_sub"]
+    assert float(rel.median()) <= 1e-6 and float((rel > 1e-4).float().mean()) <= 0.02

@@ -39,27 +39,42 @@ def test_small_pipeline_every_seam(tag):
     trace = {}
     with torch.no_grad():
         depth, conf = eng.run(imgs, projs, g["depth_min"].to(DEV), g["depth_max"].to(DEV), trace=trace)
+    rel = lambda got, ref: maxdiff(got, ref) / max(1.0, float(ref.abs().max()))
+    m = {}
     for l in (1, 2, 3):
-        ref = g[f"feat.level{l}"]
-        assert maxdiff(trace["feats"][l].view(ref.shape), ref) <= 5e-5 * max(1.0, float(ref.abs().max()))
+        m[f"feat{l}"] = rel(trace["feats"][l].view(g[f"feat.level{l}"].shape), g[f"feat.level{l}"])
     s = trace["corr_views"].shape[1]
-    for i in range(s):
-        ref = g[f"init.corr_view{i}"]
-        assert maxdiff(trace["corr_views"][:, i].permute(0, 2, 1, 3, 4), ref) <= 3e-4 * max(1.0, float(ref.abs().max()))
-    assert maxdiff(trace["view_weights"], g["init.view_weights"]) <= 2e-3
-    ref = g["init.score"]
-    assert maxdiff(trace["init_score"], ref) <= 2e-3 * max(1.0, float(ref.abs().max()))
-    assert maxdiff(trace["hidden0"], g["hidden0"]) <= 2e-3
+    m["corr_view"] = max(rel(trace["corr_views"][:, i].permute(0, 2, 1, 3, 4), g[f"init.corr_view{i}"]) for i in range(s))
+    m["view_w"] = maxdiff(trace["view_weights"], g["init.view_weights"])
+    m["init_agg"] = rel(trace["init_agg"], g["init.agg"].permute(0, 2, 1, 3, 4))
+    m["init_score"] = rel(trace["init_score"], g["init.score"])
+    m["hidden0"] = maxdiff(trace["hidden0"], g["hidden0"])
     flips0 = float((trace["best0"].cpu() != g["best0"]).float().mean())
+    flips = float((trace["iters"][-1]["best"].cpu() != g[f"iter{iters - 1}.best"]).float().mean())
+    d, dr = depth.cpu(), g["out.depths_upsampled"]
+    drel = (d - dr).abs() / dr.abs()
+    # confidence: the sigmoid of the last iteration and its x4 up-sampling, wherever the depth agrees (an arg-max flip
+    # upstream moves the hidden state of that pixel's neighbourhood and the confidence with it)
+    c_lo, c_lo_ref = trace["iters"][-1]["conf"].cpu(), g[f"iter{iters - 1}.conf"]
+    cu_, cr = conf.cpu(), g["out.confidence_upsampled"]
+    m["conf_lo_median"] = float((c_lo - c_lo_ref).abs().median())
+    m["conf_up_median"] = float((cu_ - cr).abs().median())
+    conf_bad = float(((cu_ - cr).abs() > 1e-3).float().mean())
+    print(f"e2e_small {tag}: " + ", ".join(f"{k}={v:.1e}" for k, v in m.items()) +
+          f", flips0={flips0:.4f}, flips_last={flips:.4f}, depth median {float(drel.median()):.1e}, "
+          f"depth>1e-4 {float((drel > 1e-4).float().mean()):.4f}, conf>1e-3 {conf_bad:.4f}")
+    # un-forced run: each seam carries the deviations of the seams before it (FeatureNet 5e-5 -> correlation -> softmax)
+    for l in (1, 2, 3):
+        assert m[f"feat{l}"] <= 5e-5
+    assert m["corr_view"] <= 2e-4 and m["init_agg"] <= 2e-4
+    assert m["view_w"] <= 1e-3 and m["init_score"] <= 1e-3 and m["hidden0"] <= 1e-3
     lim = 0.02 if tag == "seed0" else 0.10
     assert flips0 <= lim, flips0
-    flips = float((trace["iters"][-1]["best"].cpu() != g[f"iter{iters - 1}.best"]).float().mean())
     assert flips <= 2 * lim, flips
-    d, dr = depth.cpu(), g["out.depths_upsampled"]
-    rel = (d - dr).abs() / dr.abs()
-    assert float(rel.median()) <= 1e-5
-    assert float((rel > 1e-4).float().mean()) <= 2 * lim, float(rel.max())
-    assert conf.shape == g["out.confidence_upsampled"].shape
+    assert float(drel.median()) <= 1e-5
+    assert float((drel > 1e-4).float().mean()) <= 2 * lim, float(drel.max())
+    assert conf.shape == cr.shape and c_lo.shape == c_lo_ref.shape
+    assert m["conf_lo_median"] <= 1e-4 and m["conf_up_median"] <= 1e-4 and conf_bad <= 2 * lim
 
 
 def _rates(a, b):
@@ -139,7 +154,8 @@ def test_cfg1_against_reference_outputs(tag):
 
     # (3) same platform, benign weights, same convolution back-end (MIOpen): every pixel
     if tag == "seed0":
-        eng_m = InferenceEngine(model.weights(), 4, backend="miopen")
+        from miopen_engine import MiopenEngine
+        eng_m = MiopenEngine(model.weights(), 4)
         with torch.no_grad():
             d_m, _ = eng_m.run(imgs["level_0"], {l: pm[f"level_{l}"] for l in (1, 2, 3)}, dmin, dmax)
         bad_m, _, max_m = _rates(d_m, o_gpu["depths_upsampled"])
@@ -191,6 +207,28 @@ def test_rejects_cpu_tensors_and_bad_sizes():
               s["depth_min"].to(DEV), s["depth_max"].to(DEV))
 
 
+def test_nan_projection_raises_like_the_reference_and_clears():
+    """module.py:83,87: a singular reference camera trips the (deferred) NaN assert; the next good sample runs"""
+    from itermvs_amd import synthetic
+    model = make_model("seed0", 1)
+    s = synthetic.make_sample(batch=1, num_views=3, height=64, width=96, seed=0)
+    imgs, pm, dmin, dmax = to_dev(s)
+    bad = {k: v.clone() for k, v in pm.items()}
+    for k in bad:
+        bad[k][:, 0] = 0.0
+    with pytest.raises(AssertionError, match="nan in proj"):
+        model(imgs, bad, dmin, dmax)
+    out = model(imgs, pm, dmin, dmax)                        # the flag was cleared by the failed check
+    assert bool(torch.isfinite(out["depths_upsampled"]).all())
+    graphed = make_model("seed0", 1)
+    graphed.use_graphs = True                                # graph mode: never stalls, the check is explicit
+    graphed(imgs, pm, dmin, dmax)
+    graphed(imgs, bad, dmin, dmax)
+    with pytest.raises(AssertionError, match="nan in proj"):
+        graphed.check_projection_finite()
+    graphed.check_projection_finite()
+
+
 def test_graph_replay_equals_eager():
     """hipGraph segments + eager corr_iter launches reproduce the eager engine bit for bit, for changing inputs."""
     from itermvs_amd import synthetic
@@ -224,8 +262,9 @@ def test_full_size_configs_cross_backend(cfg):
     s = synthetic.make_sample(batch=1, num_views=views, height=h, width=w, seed=3)
     imgs, pm, dmin, dmax = to_dev(s)
     projs = {l: pm[f"level_{l}"] for l in (1, 2, 3)}
-    hip = InferenceEngine(model.weights(), iters, backend="hip")
-    mio = InferenceEngine(model.weights(), iters, backend="miopen")
+    from miopen_engine import MiopenEngine
+    hip = InferenceEngine(model.weights(), iters)
+    mio = MiopenEngine(model.weights(), iters)
     t_hip, t_mio = {}, {}
     with torch.no_grad():
         d1, c1 = hip.run(imgs["level_0"], projs, dmin, dmax, trace=t_hip)

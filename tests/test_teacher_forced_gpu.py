@@ -1,0 +1,175 @@
+"""Chaos-free full-size parity: every HIP stage of the engine is fed the CPU oracle's OWN inputs for that stage
+(teacher forcing), so a deviation never feeds back through the arg-max / GRU and the tolerances can be the kernels'
+real ones instead of a platform-floor ratio.
+
+For the init stage and each of the GRU iterations (models/itermvs.py:270-324) the oracle's trace provides the stage
+inputs; the engine's stage methods (itermvs_amd/engine.py: stage_init / stage_score0 / stage_hidden0 / stage_head /
+stage_corr / stage_corrnets / stage_gru / confidence / convex up-sampling) run on them and are compared with the
+oracle's stage outputs:
+
+    aggregated correlations (CorrNet inputs)   <= 5e-5 * scale
+    CorrNet scores, hidden states, confidence  <= 1e-4 * scale
+    arg-max bins                               IDENTICAL wherever the oracle's top-2 logit gap > 1e-4 * max(1, |top logit|)
+                                               (>= 99 % of the pixels in every case)
+    normalised depth                           <= 1e-4 there
+    up-sampled depth / confidence              <= 1e-5 relative / 1e-6
+
+scale = max(1, max |oracle tensor|).  Cases: BASELINE cfg 1 with the published DTU weights (photo-consistent scene and
+noise images) and the cfg-3 shape (5 views, 1600x1152) with the seeded weights.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_weights
+from oracle import itermvs_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HID = 32
+
+
+def cu(t):
+    return t.to(DEV)
+
+
+def rel_err(got, want):
+    """max |got - want| / max(1, max |want|)"""
+    want = want.detach().cpu().float()
+    return float((got.detach().cpu().float() - want).abs().max()) / max(1.0, float(want.abs().max()))
+
+
+FAILS = []
+
+
+def need(cond, msg):
+    """deferred assert: every stage is measured before the test fails, the report lists all deviations"""
+    if not cond:
+        FAILS.append(msg)
+
+
+def check_head(eng, ws, w_cpu, hidden_o, best_o, nd_o, tag):
+    """depth head + regression on the oracle's hidden state, fused launch and layer-by-layer form"""
+    logits_o = O.depth_head_logits(w_cpu, hidden_o)
+    top2 = torch.topk(logits_o, 2, dim=1).values
+    # the oracle's own arg-max is not a near-tie: top-2 gap > 1e-4 relative to the winning logit (>= 1e-4 absolute)
+    decided = (top2[:, :1] - top2[:, 1:2]) > 1e-4 * top2[:, :1].abs().clamp(min=1.0)
+    need(float(decided.float().mean()) >= 0.99, f"{tag}: only {float(decided.float().mean()):.4f} decided pixels")
+    out = {}
+    for form in ("fused", "layers"):
+        ws["hidden"].copy_(cu(hidden_o))
+        logits, best = eng.stage_head(ws, want_logits=(form == "layers"), want_best=True)
+        best = best.cpu()
+        nd = ws["hx"][:, HID:HID + 1].cpu()
+        need(torch.equal(ws["hx2"][:, HID:HID + 1].cpu(), nd), f"{tag}/{form}: hx2 depth channel differs")   # both GRU input buffers receive it
+        flips = (best != best_o) & decided
+        need(int(flips.sum()) == 0, f"{tag}/{form}: {int(flips.sum())} arg-max flips at decided pixels")
+        err = float(((nd - nd_o).abs() * decided).max())
+        need(err <= 1e-4, f"{tag}/{form}: normalised depth off by {err:.2e}")
+        if logits is not None:
+            need(rel_err(logits, logits_o) <= 1e-4, f"{tag}: logits {rel_err(logits, logits_o):.2e}")
+        out[form] = (float((best != best_o).float().mean()), err)
+    return out, float(decided.float().mean())
+
+
+CASES = [("dtu", "scene", 5, 512, 640, 4), ("dtu", "noise", 5, 512, 640, 4), ("seed0", "noise", 5, 1152, 1600, 4)]
+
+
+@pytest.mark.parametrize("wtag,kind,views,height,width,iters", CASES, ids=["cfg1-dtu-scene", "cfg1-dtu-noise", "cfg3-seed0-noise"])
+def test_every_stage_on_the_oracles_inputs(wtag, kind, views, height, width, iters):
+    from itermvs_amd import ops, synthetic
+    from itermvs_amd.engine import InferenceEngine
+    torch.set_num_threads(min(32, max(8, torch.get_num_threads())))
+    w_cpu = load_weights(wtag)
+    s = (synthetic.make_scene_sample(num_views=views, height=height, width=width, seed=0) if kind == "scene"
+         else synthetic.make_sample(batch=1, num_views=views, height=height, width=width, seed=0))
+    t = {}
+    with torch.no_grad():
+        out_o = O.pipeline_forward(w_cpu, s["imgs"], s["proj_matrices"], s["depth_min"], s["depth_max"], iters, trace=t)
+    eng = InferenceEngine({k: cu(v) for k, v in w_cpu.items()}, iters)
+    b, v = 1, views
+    sv = v - 1
+    h, wd = height // 4, width // 4
+    ws = eng._workspace(b, h, wd)
+    hx, hx2 = ws["hx"], ws["hx2"]
+    report = {}
+    FAILS.clear()
+
+    def lim(name, value, bound):
+        report[name] = value
+        need(value <= bound, f"{name} = {value:.2e} > {bound:.0e}")
+
+    # FeatureNet on the same images (the only stage whose input is not an oracle intermediate)
+    with torch.no_grad():
+        feats = eng.feature_net(cu(s["imgs"]["level_0"]).reshape(b * v, 3, height, width))
+    for l in (1, 2, 3):
+        lim(f"feat{l}", rel_err(feats[l], t["feats"][l]), 2e-5)
+
+    # stage inputs from the oracle: features, reference-faithful fp32 projections (module.py:77-90), depth range
+    cl = {l: cu(t["feats"][l]).contiguous(memory_format=torch.channels_last) for l in (1, 2, 3)}
+    pv = {l: cl[l].view(b, v, *cl[l].shape[1:]) for l in (1, 2, 3)}
+    src = {l: [pv[l][:, i] for i in range(1, v)] for l in (1, 2, 3)}
+    ref = {l: pv[l][:, 0] for l in (1, 2, 3)}
+    pm = [s["proj_matrices"][f"level_{l}"].float() for l in (1, 2, 3)]
+    p12 = torch.stack([torch.stack([O.compose_projection(pm[i][:, k], pm[i][:, 0])[:, :3, :4].reshape(-1, 12)
+                                    for k in range(1, v)], 1) for i in range(3)]).contiguous()      # [3,B,S,12]
+    proj = cu(p12)
+    inv_min, inv_max = cu(1.0 / s["depth_min"].float()), cu(1.0 / s["depth_max"].float())
+    with torch.no_grad():
+        ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
+
+        # ---- initialisation (itermvs.py:270-276) ----
+        tr = {}
+        view_w = eng.stage_init(ws, src[3], ref[3], proj[2], inv_min, inv_max, trace=tr)
+        lim("init.agg", rel_err(tr["init_agg"], t["init_agg"].permute(0, 2, 1, 3, 4)), 5e-5)
+        lim("init.view_w", rel_err(view_w, t["view_weights"]), 1e-4)
+        score0 = eng.stage_score0(cu(t["init_agg"].permute(0, 2, 1, 3, 4).contiguous()))
+        lim("init.score", rel_err(score0, t["init_score"]), 1e-4)
+        eng.stage_hidden0(ws, cu(t["init_score"]))
+        lim("hidden0", rel_err(ws["hidden"], t["hidden0"]), 1e-4)
+        need(torch.equal(hx[:, :HID], ws["hidden"]), "hidden0: the two copies differ")
+        report["head0"], report["decided0"] = check_head(eng, ws, w_cpu, t["hidden0"], t["best0"], t["nd0"], "init")
+
+        # ---- iterations (itermvs.py:288-324) ----
+        hidden_in = t["hidden0"]
+        view_w_o = cu(t["view_weights"])
+        for it, ti in enumerate(t["iters"]):
+            hx[:, :HID].copy_(cu(hidden_in))
+            hx[:, HID:HID + 1].copy_(cu(ti["nd_in"]))
+            hx2[:, HID:HID + 1].copy_(cu(ti["nd_in"]))
+            aggs = eng.stage_corr(ws, src, ref_q, proj, view_w_o, inv_min, inv_max)
+            for i, a in enumerate(aggs):
+                want = ti["aggs"][i].permute(0, 2, 1, 3, 4)
+                lim(f"it{it}.agg{i + 1}", rel_err(a, want), 5e-5)
+                ws["agg"][i].copy_(cu(want))
+            eng.stage_corrnets(ws)
+            lim(f"it{it}.score", rel_err(hx[:, HID + 1:], ti["score"]), 1e-4)
+            need(torch.equal(hx2[:, HID + 1:], hx[:, HID + 1:]), f"it{it}: score copies differ")
+            hx[:, HID + 1:].copy_(cu(ti["score"]))
+            hx2[:, HID + 1:].copy_(cu(ti["score"]))
+            eng.stage_gru(ws)
+            lim(f"it{it}.hidden", rel_err(ws["hidden"], ti["hidden"]), 1e-4)
+            need(torch.equal(hx[:, :HID], ws["hidden"]), f"it{it}: hidden copies differ")
+            if ti["conf"] is not None:
+                ws["hidden"].copy_(cu(ti["hidden"]))
+                conf = eng.confidence(ws["hidden"], ws["conf_mid"], ws["conf"])
+                lim("conf", rel_err(conf, ti["conf"]), 1e-4)
+            report[f"it{it}.head"], _ = check_head(eng, ws, w_cpu, ti["hidden"], ti["best"], ti["nd"], f"iter {it}")
+            hidden_in = ti["hidden"]
+
+        # ---- final up-sampling (itermvs.py:262-264, 321-324) on the oracle's depth, logits and confidence ----
+        last = t["iters"][-1]
+        u = "iter_mvs.upsample."
+        ref2 = t["feats"][2].view(b, v, *t["feats"][2].shape[1:])[:, 0]
+        up_logits_o = F.conv2d(F.relu(F.conv2d(ref2, w_cpu[u + "0.weight"], padding=1)), w_cpu[u + "2.weight"])
+        up_logits = eng.upsample_logits(cu(ref2).contiguous(), ws)
+        lim("up_logits", rel_err(up_logits, up_logits_o), 1e-4)
+        hx[:, HID:HID + 1].copy_(cu(last["nd"]))
+        depth_up = ops.convex_upsample(cu(up_logits_o), hx, inv_min, inv_max, nd_channel=HID)
+        d, d_o = depth_up.cpu(), out_o["depths_upsampled"]
+        lim("depth_up", float(((d - d_o).abs() / d_o).max()), 1e-5)
+        conf_up = ops.bilinear_up(cu(last["conf"]), 4)
+        lim("conf_up", float((conf_up.cpu() - out_o["confidence_upsampled"]).abs().max()), 1e-6)
+    print(f"teacher-forced {wtag}/{kind} {width}x{height}: " + ", ".join(
+        f"{k}={v:.1e}" if isinstance(v, float) else f"{k}={v}" for k, v in report.items()))
+    assert not FAILS, "; ".join(FAILS)
