@@ -28,6 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+PMC_SUMMARY = "r02_pmc_kernels.json"   # written by tools/pmc_kernels.sh on the GPU box, committed per round
 
 
 def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int):
@@ -82,6 +83,68 @@ def cpu_baseline(args, target_seconds: float = 15.0):
             "s_per_depth_map": dt / n}
 
 
+def transfers_leg(args, dev, samples, world):
+    """depth-maps/s with PCIe in the loop: H2D of the sample (imgs level_0, cameras, depth range) and D2H of the two output
+    maps, overlapped with compute through two graph runners' static buffers (double buffering) and three HIP streams."""
+    import torch
+    from itermvs_amd import shard, synthetic
+    from itermvs_amd.engine import GraphedRunner, InferenceEngine
+    from itermvs_amd.net import Pipeline
+    m = Pipeline(iteration=args.iters, test=True)
+    m.load_state_dict(synthetic.random_state_dict(0))
+    m = m.to(dev).eval()
+    eng = InferenceEngine(m.weights(), args.iters)
+    imgs0, projs0, dmin0, dmax0 = samples[0]
+    pj = {l: projs0[f"level_{l}"].float() for l in (1, 2, 3)}
+    runners = [GraphedRunner(eng, imgs0["level_0"].float(), pj, dmin0.float(), dmax0.float()) for _ in range(2)]
+    host_in = []
+    for imgs, projs, dmin, dmax in samples:
+        host_in.append((imgs["level_0"].float().cpu().pin_memory(),
+                        torch.stack([projs[f"level_{l}"].float() for l in (1, 2, 3)]).cpu().pin_memory(),
+                        dmin.float().cpu().pin_memory(), dmax.float().cpu().pin_memory()))
+    host_out = [tuple(torch.empty(o.shape, dtype=o.dtype).pin_memory() for o in r.out) for r in runners]
+    s_in, s_cmp, s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
+    ev_in = [torch.cuda.Event() for _ in range(2)]
+    ev_done = [torch.cuda.Event() for _ in range(2)]
+    ev_out = [torch.cuda.Event() for _ in range(2)]
+    started = [False, False]
+
+    def step(i: int) -> None:
+        k = i % 2
+        r = runners[k]
+        h_img, h_proj, h_min, h_max = host_in[i % len(host_in)]
+        with torch.cuda.stream(s_in):
+            if started[k]:
+                s_in.wait_event(ev_done[k])                 # replay i-2 has consumed these static inputs
+            r.imgs.copy_(h_img, non_blocking=True)
+            r.proj_stack.copy_(h_proj, non_blocking=True)
+            r.depth_min.copy_(h_min, non_blocking=True)
+            r.depth_max.copy_(h_max, non_blocking=True)
+            ev_in[k].record(s_in)
+        with torch.cuda.stream(s_cmp):
+            s_cmp.wait_event(ev_in[k])
+            if started[k]:
+                s_cmp.wait_event(ev_out[k])                 # outputs of replay i-2 are on the host
+            r(r.imgs, r.projs, r.depth_min, r.depth_max)    # static inputs: no staging copies, one graph launch
+            ev_done[k].record(s_cmp)
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(ev_done[k])
+            for h, d in zip(host_out[k], r.out):
+                h.copy_(d, non_blocking=True)
+            ev_out[k].record(s_out)
+        started[k] = True
+
+    elapsed = shard.timed_steps(step, args.steps, max(args.warmup, 4))
+    eng.check_projection_finite()
+    h2d = sum(t.numel() * t.element_size() for t in host_in[0])
+    d2h = sum(t.numel() * t.element_size() for t in host_out[0])
+    return {"value": world * args.steps * args.batch / elapsed, "unit": "depth-maps/s", "ms_per_step": elapsed / args.steps * 1e3,
+            "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h,
+            "note": "pinned host inputs -> H2D on a copy stream into the static inputs of two alternating hipGraph runners, "
+                    "compute stream, D2H of depth + confidence into pinned host buffers on a third stream; "
+                    "same steps / barrier / max-over-ranks timing as `value`"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,12 +156,18 @@ def main() -> None:
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--batch", type=int, default=1, help="reference views per step and GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-transfers", action="store_true", help="skip the host-buffers-in / host-buffers-out leg")
+    ap.add_argument("--minimal", action="store_true",
+                    help="only the timed region (no CPU baseline, pipelined / transfer legs, conv roofline pass): profiling runs")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent reference views in flight per GPU (one HIP stream + engine workspace each)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying hipGraph segments")
     ap.add_argument("--pipeline-streams", type=int, default=4,
                     help="extra measurement: throughput with this many reference views in flight (0/1 = skip)")
     args = ap.parse_args()
+    if args.minimal:
+        args.no_cpu_baseline = args.no_transfers = True
+        args.pipeline_streams = 0
 
     import torch
     from itermvs_amd import ops, shard, synthetic
@@ -157,8 +226,9 @@ def main() -> None:
     # HIP-event pairs around the fused kernels' launches (on their launch stream).  Graph mode: external
     # event-record nodes captured with the launches (enabled BEFORE the capture below); eager mode: plain records.
     per_step = args.iters + 1
-    # (graph mode: only the corr_iter launches carry event nodes -- each node costs ~5 us of graph time)
-    ops.profile_enable((args.steps + args.warmup) * per_step + 8 * per_step, mask=0x1 if ab == 2 else 0x3)
+    # (graph mode: an event-record node costs ~5 us of graph time, so runner A carries them around corr_init and the even
+    # GRU iterations' corr_iter, runner B around the odd iterations' corr_iter)
+    ops.profile_enable((args.steps + args.warmup) * per_step + 8 * per_step, mask=0x3)
     for k in range(n_models):                          # set-up, not a step: capture every runner's hipGraph
         with torch.cuda.stream(streams[k]):
             if ab == 2:
@@ -167,6 +237,7 @@ def main() -> None:
                 from itermvs_amd.engine import InferenceEngine
                 models[k]._engine = InferenceEngine(models[k].weights(), models[k].iteration)
                 models[k]._engine.profile_iterations = set(range(k % 2, args.iters, 2))
+                models[k]._engine.profile_init = (k % 2 == 0)
             models[k](*samples[0])
     torch.cuda.synchronize()
     ops.profile_collect(max_samples=4096)              # drop the set-up launches' samples
@@ -189,21 +260,26 @@ def main() -> None:
     if t_iter:
         avg_ms = sum(t_iter) / len(t_iter)
         achieved = b_iter / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "itermvs_corr_iter (corr_iter_kernel<32>)", "achieved": achieved,
+        kernel_name = ops.corr_iter_kernel_name()
+        roofline = {"bound": "hbm", "kernel": f"itermvs_corr_iter ({kernel_name})", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": b_iter, "avg_launch_ms": avg_ms, "launches_timed": len(t_iter),
                     "timing": ("external hipEvent record nodes around the launch inside the replayed hipGraph, every replay of "
                                "the timed region read; the two alternating runners carry the nodes on even / odd GRU iterations" if ab == 2 else "hipEvent pairs on the launch stream inside the timed region")}
-        pmc_file = os.path.join(ROOT, "profiles", "r01_corr_iter_pmc.json")
-        if os.path.exists(pmc_file):      # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
+        # HBM bytes per launch: rocprofv3 --pmc passes of THIS command (tools/pmc_kernels.sh -> tools/pmc_summary.py ->
+        # profiles/<round>_pmc_kernels.json); taken only if the summary names the kernel that ran here and the same workload
+        pmc_file = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+        if os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
-            if pmc.get("workload") == [args.views, args.height, args.width, args.batch]:
-                roofline["traffic"] = pmc["traffic_bytes_per_launch"]
-                roofline["traffic_source"] = pmc["source"]
+            entry = pmc.get("kernels", {}).get(kernel_name)
+            if entry and pmc.get("workload") == [args.views, args.height, args.width, args.batch] and "traffic_bytes_per_launch" in entry:
+                roofline["traffic"] = entry["traffic_bytes_per_launch"]
+                roofline["traffic_source"] = f"profiles/{PMC_SUMMARY}: " + pmc["source"]
         if t_init:
             init_ms = sum(t_init) / len(t_init)
-            roofline["corr_init"] = {"avg_launch_ms": init_ms, "algorithmic_bytes_per_launch": b_init,
-                                     "achieved": b_init / (init_ms * 1e-3) / 1e9}
+            roofline["corr_init"] = {"kernel": "itermvs_corr_init (corr_init_kernel<32>)", "avg_launch_ms": init_ms,
+                                     "launches_timed": len(t_init), "algorithmic_bytes_per_launch": b_init,
+                                     "achieved": b_init / (init_ms * 1e-3) / 1e9, "frac": b_init / (init_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     # extra: independent reference views pipelined on several HIP streams of the same GPU (each stream replays
     # its own hipGraph segments).  Reported separately: with concurrent streams the HIP-event bracket of a
@@ -234,11 +310,18 @@ def main() -> None:
                      "steps": psteps, "ms_per_step": pel / psteps * 1e3}
         del pm
 
+    # the SURVEY section 8(d) form of the metric: host buffers in, host buffers out (eval.py:130-137).  Pinned host
+    # samples are copied into the static inputs of two alternating graph runners on a copy stream while the previous depth
+    # map computes; both outputs go back to pinned host memory on a third stream.  Reported beside `value`, never as it.
+    with_transfers = None
+    if args.streams == 1 and not args.eager and not args.no_transfers:
+        with_transfers = transfers_leg(args, dev, samples, world)
+
     # second roofline: the matrix-core convolutions (FeatureNet, CorrNet, ConvGRU, heads) -- timed with
     # HIP-event pairs around every itermvs_conv2d launch in a short EXTRA pass after the timed region
     # (event pairs around ~100 launches per step would perturb the throughput measurement)
     conv_roofline = None
-    if rank == 0:
+    if rank == 0 and not args.minimal:
         n_extra = 3
         ops.profile_enable(n_extra * 160 + 8, mask=0x4)
         ops.CONV_FLOP_COUNTER.update(enabled=True, flops=0.0, launches=0)
@@ -281,6 +364,7 @@ def main() -> None:
             "roofline": roofline,
             "roofline_conv": conv_roofline,
             "pipelined": pipelined,
+            "with_transfers": with_transfers,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)

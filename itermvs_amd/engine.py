@@ -81,6 +81,7 @@ class InferenceEngine:
         # read and cleared by check_projection_finite()
         self.nan_flag = torch.zeros((1,), device=dev, dtype=torch.int32)
         self.profile_iterations = None   # set of iteration indices whose corr_iter launch carries timing events (None = all)
+        self.profile_init = True         # whether the corr_init launch carries timing events (bench.py)
         self.pk: Dict[str, object] = {}
         self._pack_weights()
 
@@ -214,7 +215,7 @@ class InferenceEngine:
         b, _, h3, w3 = ref3.shape
         s = len(src3)
         w = self.w
-        corr_v = ops.corr_init(src3, ref3, proj3, inv_min, inv_max, INIT_SAMPLES)                 # [B,S,32,8,h3,w3]
+        corr_v = ops.corr_init(src3, ref3, proj3, inv_min, inv_max, INIT_SAMPLES, timed=self.profile_init)   # [B,S,32,8,h3,w3]
         pv = "iter_mvs.evaluation.pixel_view_weight."
         x = self._conv(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), pv + "conv.0.conv.", act="relu")
         vw = ops.pvw_tail(x, w[pv + "conv.1.weight"], w[pv + "conv.1.bias"], INIT_SAMPLES)        # 1x1 + softmax + max

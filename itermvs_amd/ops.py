@@ -187,8 +187,15 @@ def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, vie
     return outs
 
 
+def corr_iter_kernel_name() -> str:
+    """name of the device kernel itermvs_corr_iter launches by default (rocprofv3's Kernel_Name contains it)"""
+    form = os.environ.get("ITERMVS_CORR_ITER_IMPL", "views")[:1]
+    return {"l": "corr_iter_kernel", "n": "corr_iter_vw_kernel<true"}.get(form, "corr_iter_vw_kernel<false")
+
+
 def corr_init(src3: Sequence[Tensor], ref3: Tensor, proj: Tensor, inv_min: Tensor, inv_max: Tensor,
-              num_samples: int = 32, depth: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+              num_samples: int = 32, depth: Optional[Tensor] = None, out: Optional[Tensor] = None,
+              timed: bool = True) -> Tensor:
     """itermvs.py:48-51 (+ :11-19): per-view group correlation, [B,S,N,8,H,W]."""
     b, _, h, w = ref3.shape
     s = len(src3)
@@ -206,7 +213,12 @@ def corr_init(src3: Sequence[Tensor], ref3: Tensor, proj: Tensor, inv_min: Tenso
     if out is None:
         out = torch.empty((b, s, p.N, 8, h, w), device=ref3.device, dtype=torch.float32)
     p.out = out.data_ptr()
-    check(_lib.load().itermvs_corr_init(C.byref(p), _stream()), "itermvs_corr_init")
+    lib = _lib.load()
+    if not timed:               # no timing events around this launch: mask bit 1 off for the call
+        lib.itermvs_profile_set_mask(_PROFILE_MASK[0] & ~2)
+    check(lib.itermvs_corr_init(C.byref(p), _stream()), "itermvs_corr_init")
+    if not timed:
+        lib.itermvs_profile_set_mask(_PROFILE_MASK[0])
     return out
 
 

@@ -48,6 +48,47 @@ def test_compose_proj_matches_fp64_and_reference():
                 assert float(((got - ref32).abs() / ref32.abs().clamp(min=1.0)).max()) < 1e-4
 
 
+def test_compose_proj_tap_indices_against_reference_projection():
+    """Bilinear tap indices floor(ix), floor(iy) with the DEVICE projection (fp64 inverse, rounded once) vs the
+    reference's fp32 ``src @ inverse(ref)`` (module.py:77-90; LAPACK on the CPU, MAGMA / cuSOLVER on a GPU -- the reference
+    itself has no single bit pattern here), through the same fp32 coordinate arithmetic (the oracle's restatement of
+    module.py:89-115), for every level and source view of the cfg-1 geometry and of the golden fixtures.
+    The two roundings of the same matrix move the sampling position by < 3e-4 px (a few ulps of a 320-px coordinate); a
+    tap index can therefore differ only where the position sits within that distance of an integer, i.e. where the tap
+    that changes carries a weight < 3e-4 and the interpolated value is continuous (measured: 2e-5 of the coordinates).  Asserted: position shift, flip rate, and that every flip is of that kind."""
+    from itermvs_amd import synthetic
+    samples = [synthetic.make_sample(1, 5, 512, 640, seed=0), synthetic.make_scene_sample(5, 512, 640, seed=1),
+               synthetic.make_sample(2, 11, 96, 160, seed=5)]
+    gen = torch.Generator().manual_seed(3)
+    worst_shift, flips, total = 0.0, 0, 0
+    for sm in samples:
+        for l in (1, 2, 3):
+            mats = sm["proj_matrices"][f"level_{l}"].float()
+            b, v = mats.shape[:2]
+            hh, ww = sm["imgs"]["level_0"].shape[-2:]
+            h1, w1 = hh >> l, ww >> l
+            h, w = hh // 4, ww // 4
+            dev12 = ops().compose_proj(cu(mats)).cpu()                                   # [B,V-1,12]
+            depth = 425.0 + 510.0 * torch.rand((b, 4, h, w), generator=gen)
+            for k in range(1, v):
+                ref44 = O.compose_projection(mats[:, k], mats[:, 0])
+                dev44 = torch.cat([dev12[:, k - 1].view(b, 3, 4), torch.tensor([0.0, 0, 0, 1]).expand(b, 1, 4)], 1)
+                ix_r, iy_r, _ = O.warp_source_coords(ref44, depth, h1, w1)
+                ix_d, iy_d, _ = O.warp_source_coords(dev44, depth, h1, w1)
+                inside = (ix_r > -1) & (ix_r < w1) & (iy_r > -1) & (iy_r < h1)
+                for a_r, a_d in ((ix_r, ix_d), (iy_r, iy_d)):
+                    worst_shift = max(worst_shift, float(((a_r - a_d).abs() * inside).max()))
+                    fl = (torch.floor(a_r) != torch.floor(a_d)) & inside
+                    flips += int(fl.sum())
+                    total += int(inside.sum())
+                    # a flipped index sits at an integer boundary of BOTH positions
+                    near = torch.minimum((a_r - torch.round(a_r)).abs(), (a_d - torch.round(a_d)).abs())
+                    assert float((near * fl).max()) < 3e-4
+    print(f"compose_proj tap indices: worst position shift {worst_shift:.2e} px, {flips} of {total} coordinates "
+          f"change their floor ({flips / total:.2e})")
+    assert worst_shift < 3e-4 and flips / total < 2e-4
+
+
 def test_compose_proj_nan_flag():
     mats = torch.eye(4).repeat(1, 3, 1, 1).clone()
     mats[0, 0] = 0.0                                      # singular reference -> inf/nan

@@ -1,29 +1,62 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE ...) of `bench.py` for one kernel into
-profiles/<name>.json.   usage: pmc_summary.py <dir with one sub-dir per pass> <kernel substring> <out.json>
+"""Summarise rocprofv3 --pmc passes of `bench.py --eager --minimal` (tools/pmc_kernels.sh) per kernel into one JSON:
+    usage: pmc_summary.py <dir with one sub-dir per pass> <out.json>
 
-HBM traffic per launch = FETCH_SIZE * 2 + WRITE_SIZE (KiB): on gfx950 FETCH_SIZE reports exactly half of
-the bytes of 16-byte-per-lane reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE was checked against the
-kernel's known 6.55 MB of output per launch (6400 KiB measured)."""
+Per kernel (template arguments kept, namespaces / argument lists dropped): the mean of every collected counter per
+launch and a few derived figures.  HBM traffic per launch = FETCH_SIZE * 2 + WRITE_SIZE (KiB): on gfx950 FETCH_SIZE
+reports exactly half of the bytes of 16-byte-per-lane reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE was checked
+against corr_iter's known 6.55 MB of output per launch (6400 KiB measured).  TCP_TCC_READ_REQ counts 128-byte lines
+(TCC_MISS x 128 B reproduces the corrected FETCH_SIZE of corr_iter)."""
 import collections
 import csv
 import glob
 import json
+import re
 import sys
 
-root, needle, out = sys.argv[1:4]
-vals = collections.defaultdict(list)
+root, out = sys.argv[1:3]
+KEEP = ("corr_iter", "corr_init", "conv_tile_kernel", "deconv_tile_kernel", "conv_mfma", "conv_direct_kernel", "head_fused",
+        "pvw_tail", "view_aggregate", "ref_quarter", "convex_upsample")
+
+
+def short(name: str) -> str:
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("itermvs::", "")
+    return re.sub(r"\(.*$", "", name)
+
+
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
+grid = {}
 for f in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if needle in r["Kernel_Name"]:
-            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
-mean = {k: sum(v) / len(v) for k, v in vals.items()}
-res = {"kernel": needle, "launches_sampled": {k: len(v) for k, v in vals.items()}, "counters_mean_per_launch": mean}
-if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
-    res["traffic_bytes_per_launch"] = (mean["FETCH_SIZE"] * 2 + mean["WRITE_SIZE"]) * 1024
-    res["fetch_bytes_corrected"] = mean["FETCH_SIZE"] * 2 * 1024
-    res["write_bytes"] = mean["WRITE_SIZE"] * 1024
-res["workload"] = [5, 512, 640, 1]
-res["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --steps 3 --warmup 2 --eager`, FETCH_SIZE x2 per MI355X_MICROARCH.md"
+        k = short(r["Kernel_Name"])
+        if any(s in k for s in KEEP):
+            vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            grid[k] = (int(r["Grid_Size"]), int(r["Workgroup_Size"]), int(r["VGPR_Count"]), int(r["LDS_Block_Size"]))
+kernels = {}
+for k, cs in sorted(vals.items()):
+    m = {c: sum(v) / len(v) for c, v in cs.items()}
+    e = {"launches_sampled": max(len(v) for v in cs.values()), "grid_threads": grid[k][0], "workgroup": grid[k][1],
+         "vgpr_arch": grid[k][2], "lds_bytes": grid[k][3], "counters_mean_per_launch": m}
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        e["traffic_bytes_per_launch"] = (m["FETCH_SIZE"] * 2 + m["WRITE_SIZE"]) * 1024
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in m and "TCP_TCC_READ_REQ_sum" in m:
+        e["l1_hit_rate"] = 1.0 - m["TCP_TCC_READ_REQ_sum"] / max(m["TCP_TOTAL_CACHE_ACCESSES_sum"], 1.0)
+        e["l1_to_l2_bytes"] = m["TCP_TCC_READ_REQ_sum"] * 128
+    if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
+        e["l2_hit_rate"] = m["TCC_HIT_sum"] / max(m["TCC_HIT_sum"] + m["TCC_MISS_sum"], 1.0)
+    if "SQ_WAVES" in m and "SQ_INSTS_VALU" in m:
+        e["valu_insts_per_wave"] = m["SQ_INSTS_VALU"] / max(m["SQ_WAVES"], 1.0)
+    if "SQ_ACTIVE_INST_ANY" in m and "SQ_WAVE_CYCLES" in m:      # both in quad-cycles summed over waves
+        e["wave_time_issuing"] = m["SQ_ACTIVE_INST_ANY"] / max(m["SQ_WAVE_CYCLES"], 1.0)
+        e["wave_time_waiting"] = m.get("SQ_WAIT_ANY", 0.0) / max(m["SQ_WAVE_CYCLES"], 1.0)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CYCLES" in m and m["SQ_BUSY_CYCLES"] > 0:
+        # MFMA-busy cycles summed over the 1024 SIMDs / (busy cycles of the SQs x SIMDs per SQ): see profiles/README.md
+        e["mfma_busy_cycles_per_simd"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0
+    kernels[k] = e
+res = {"workload": [5, 512, 640, 1],
+       "source": "rocprofv3 --pmc (one pass per counter set, tools/pmc_kernels.sh) on `python bench.py --steps 3 --warmup 2 --eager --minimal`; FETCH_SIZE x2 per MI355X_MICROARCH.md",
+       "kernels": kernels}
 json.dump(res, open(out, "w"), indent=1)
-print(json.dumps(res, indent=1))
+for k, e in kernels.items():
+    print(k, {x: (round(v, 4) if isinstance(v, float) else v) for x, v in e.items() if x != "counters_mean_per_launch"})
