@@ -120,12 +120,11 @@ int itermvs_ref_quarter(const itermvs_fmap* ref_l1, const itermvs_fmap* ref_l2,
 typedef struct itermvs_corr_iter_params {
     int32_t B, S, H, W;                        /* sample grid = level-2 size              */
     int32_t N[3];                              /* hypotheses per level (reference: 4,4,2) */
-    int32_t impl;                              /* kernel form: 0 = default.  impl % 10: 1 = source views walked inside the lane,
-                                                  2 = views across waves (default; all hypotheses' taps in flight, footprints
-                                                  shared by DPP quad broadcasts, views reduced in order through LDS),
-                                                  3..7 = measurement variants of 2 (non-temporal loads, in-flight depth);
-                                                  impl / 10 = 0 / 1 / 2: 32x1 / 16x2 / 8x4 pixel tiles of form 2.
-                                                  All forms give the same results (tests/test_kernels_gpu.py). */
+    int32_t impl;                              /* kernel form: 0 = default.  impl % 10: 1 = source views walked inside the lane
+                                                  (default), 2 = views across waves (all hypotheses' taps in flight, footprints
+                                                  shared by DPP quad broadcasts, views reduced in order through LDS), 3 = 2 held
+                                                  to 128 registers; impl / 10 = 0 / 1 / 2: 32x1 / 16x2 / 8x4 pixel tiles of
+                                                  forms 2 / 3.  All forms give the same results (tests/test_kernels_gpu.py). */
     itermvs_level_src src[3];                  /* [level-1]; channels-last (sc == 1)      */
     const float* ref_q;                        /* [B,H,W,C1+C2+C3] from itermvs_ref_quarter */
     const float* proj;                         /* [3,B,S,12] from itermvs_compose_proj    */

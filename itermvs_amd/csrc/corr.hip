@@ -14,178 +14,13 @@
 //   carries the view-weighted accumulators in registers.
 //   Results are transposed through LDS so the [B,N,8,H,W] planes CorrNet / PixelViewWeight
 //   consume are written as full rows of TILE pixels.
-#include <stdlib.h>
-
-#include "common.hpp"
+#include "corr_common.hpp"
 
 namespace itermvs {
-
-constexpr int kThreads = 256;
-
-template <int CPG>
-struct Chunk {
-    // lane j of a (pixel, hypothesis) group owns the float4 at channel 4*j of every 16-channel block:
-    //   C=16: 4 lanes x 1 float4            (two correlation groups of 2 per lane)
-    //   C=32: 8 lanes x 1 float4            (one group of 4 per lane)
-    //   C=48: 4 lanes x 3 float4 (stride 16 channels): every load instruction of the group covers one
-    //         contiguous 64-byte run (one L1 access) -- a "6 floats per lane" layout costs 9 accesses
-    //         per tap instead of 3 and made the L1 tag rate the bound of the whole kernel.  The lane's
-    //         12 channels straddle the 6-channel correlation groups; partial sums are re-grouped with
-    //         four quad-local DPP moves (see blend_corr).
-    static constexpr int VEC = (CPG == 6) ? 12 : 4;  // floats per lane
-    static constexpr int LPT = (CPG == 4) ? 8 : 4;   // lanes per tap
-    static constexpr int NG = (CPG == 4) ? 1 : 2;    // correlation groups finalised per lane
-};
-
-// channel of element c of lane j's chunk
-template <int VEC>
-__device__ __forceinline__ int chunk_channel(int j, int c) {
-    return 16 * (c / 4) + 4 * j + (c % 4);
-}
-
-template <int VEC>
-__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[VEC]) {
-#pragma unroll
-    for (int i = 0; i < VEC / 4; ++i) {
-        const float4 t = *reinterpret_cast<const float4*>(p + 16 * i);
-        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
-    }
-}
-
-// v_mov_b32 dpp quad_perm: lane l of each quad reads lane ((CTRL >> 2*l) & 3) of the same quad
-template <int CTRL>
-__device__ __forceinline__ float quad_perm(float x) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
-}
-#define ITERMVS_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
-
-// Everything about one bilinear footprint that is identical for the chunk lanes of a
-// (pixel, hypothesis): 32-bit element offsets of the two rows / two columns and the four weights
-// (already zero for out-of-range taps).  Computed by ONE lane and broadcast with shuffles.
-struct Footprint {
-    uint32_t r0, r1, c0, c1;
-    float nw, ne, sw, se;
-};
-
-__device__ __forceinline__ Footprint make_footprint(float ix, float iy, int W1, int H1, uint32_t sy, uint32_t sx) {
-    const Taps t = make_taps(ix, iy, W1, H1);
-    Footprint f;
-    f.r0 = (uint32_t)t.y0 * sy; f.r1 = (uint32_t)t.y1 * sy;
-    f.c0 = (uint32_t)t.x0 * sx; f.c1 = (uint32_t)t.x1 * sx;
-    f.nw = t.nw; f.ne = t.ne; f.sw = t.sw; f.se = t.se;
-    return f;
-}
-
-__device__ __forceinline__ Footprint shfl_footprint(const Footprint& f, int src_lane) {
-    Footprint o;
-    o.r0 = (uint32_t)__shfl((int)f.r0, src_lane, 64); o.r1 = (uint32_t)__shfl((int)f.r1, src_lane, 64);
-    o.c0 = (uint32_t)__shfl((int)f.c0, src_lane, 64); o.c1 = (uint32_t)__shfl((int)f.c1, src_lane, 64);
-    o.nw = __shfl(f.nw, src_lane, 64); o.ne = __shfl(f.ne, src_lane, 64);
-    o.sw = __shfl(f.sw, src_lane, 64); o.se = __shfl(f.se, src_lane, 64);
-    return o;
-}
-
-// group correlation of one lane's chunk for one view: bilinear blend of the four taps, product
-// with the reference chunk, mean over the channels of each group (itermvs.py:50-51).
-// `fb` is wave-uniform (SGPR base), tap offsets are 32-bit element offsets (saddr + voffset loads).
-template <int VEC>
-struct TapData {
-    float v00[VEC], v01[VEC], v10[VEC], v11[VEC];
-};
-
-// `fb` is wave-uniform (SGPR base), tap offsets are 32-bit element offsets (saddr + voffset loads).
-template <int VEC>
-__device__ __forceinline__ void load_taps(const float* __restrict__ fb, uint32_t joff, const Footprint& tp, TapData<VEC>& t) {
-    const uint32_t r0 = tp.r0 + joff, r1 = tp.r1 + joff;
-    load_vec<VEC>(fb + (r0 + tp.c0), t.v00);
-    load_vec<VEC>(fb + (r0 + tp.c1), t.v01);
-    load_vec<VEC>(fb + (r1 + tp.c0), t.v10);
-    load_vec<VEC>(fb + (r1 + tp.c1), t.v11);
-}
-
-// group correlation of one lane's chunk for one view: bilinear blend of the four taps, product
-// with the reference chunk, mean over the channels of each group (itermvs.py:50-51).
-template <int CPG>
-__device__ __forceinline__ void blend_corr(const TapData<Chunk<CPG>::VEC>& t, const Footprint& tp,
-                                           const float (&refv)[Chunk<CPG>::VEC], float (&corr)[Chunk<CPG>::NG]) {
-    constexpr int VEC = Chunk<CPG>::VEC;
-    float w[VEC];
-#pragma unroll
-    for (int c = 0; c < VEC; ++c)
-        w[c] = fmaf(tp.se, t.v11[c], fmaf(tp.sw, t.v10[c], fmaf(tp.ne, t.v01[c], tp.nw * t.v00[c])));
-    if constexpr (CPG == 2) {
-        corr[0] = fmaf(w[1], refv[1], w[0] * refv[0]) * 0.5f;
-        corr[1] = fmaf(w[3], refv[3], w[2] * refv[2]) * 0.5f;
-    } else if constexpr (CPG == 4) {
-        corr[0] = fmaf(w[3], refv[3], fmaf(w[2], refv[2], fmaf(w[1], refv[1], w[0] * refv[0]))) * 0.25f;
-    } else {
-        // lane j (= lane & 3) holds channels 16i + 4j + k (i = 0..2, k = 0..3); group g = channels
-        // 6g .. 6g+5.  lo_i / hi_i = products of the lower / upper channel pair of block i:
-        //   g0 = s0[j0] + lo0[j1]   g1 = hi0[j1] + s0[j2]      (s_i = lo_i + hi_i)
-        //   g2 = s0[j3] + lo1[j0]   g3 = hi1[j0] + s1[j1]
-        //   g4 = s1[j2] + lo1[j3]   g5 = hi1[j3] + s2[j0]
-        //   g6 = s2[j1] + lo2[j2]   g7 = hi2[j2] + s2[j3]
-        // lane d finalises groups 2d and 2d+1; each source lane selects what it owes and one
-        // quad_perm per term delivers it.
-        float lo[3], hi[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            lo[i] = fmaf(w[4 * i + 1], refv[4 * i + 1], w[4 * i] * refv[4 * i]);
-            hi[i] = fmaf(w[4 * i + 3], refv[4 * i + 3], w[4 * i + 2] * refv[4 * i + 2]);
-        }
-        const float s0 = lo[0] + hi[0], s1 = lo[1] + hi[1], s2 = lo[2] + hi[2];
-        const int j = threadIdx.x & 3;
-        const float ta = (j == 0 || j == 3) ? s0 : (j == 2 ? s1 : s2);
-        const float tb = (j == 1) ? lo[0] : (j == 2 ? lo[2] : lo[1]);
-        const float tc = (j == 1) ? hi[0] : (j == 2 ? hi[2] : hi[1]);
-        const float tdd = (j == 2) ? s0 : (j == 1 ? s1 : s2);
-        const float g_first = quad_perm<ITERMVS_QP(0, 3, 2, 1)>(ta) + quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tb);
-        const float g_second = quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tc) + quad_perm<ITERMVS_QP(2, 1, 0, 3)>(tdd);
-        corr[0] = g_first / 6.0f;
-        corr[1] = g_second / 6.0f;
-    }
-}
-
-template <int CPG>
-__device__ __forceinline__ void chunk_corr(const float* __restrict__ fb, uint32_t joff, const Footprint& tp,
-                                           const float (&refv)[Chunk<CPG>::VEC], float (&corr)[Chunk<CPG>::NG]) {
-    TapData<Chunk<CPG>::VEC> t;
-    load_taps<Chunk<CPG>::VEC>(fb, joff, tp, t);
-    blend_corr<CPG>(t, tp, refv, corr);
-}
-
-// XCD-aware tile order: block k is observed to run on XCD k % 8 (a speed assumption only), so give
-// each XCD a contiguous band of pixel tiles; neighbouring tiles then share one L2 instead of having
-// every L2 fetch its own copy of the same source lines.  grid.x is a multiple of 8.
-__device__ __forceinline__ int xcd_tile(int tiles) {
-    const int per_xcd = (tiles + 7) / 8;
-    return (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-}
 
 // ---------------------------------------------------------------------------------------------
 // iteration branch
 // ---------------------------------------------------------------------------------------------
-struct IterLevel {
-    const float* src[ITERMVS_MAX_SRC];
-    int64_t sb, sy, sx;
-    const float* depth;  // explicit hypotheses or nullptr
-    float* out;
-    float offs[ITERMVS_MAX_HYP];
-    int C, H1, W1, N, coff;
-};
-
-struct IterArgs {
-    IterLevel lv[3];
-    const float* ref_q;
-    const float* proj;
-    const float* view_w;
-    const float* nd;
-    int64_t nd_sb;
-    const float* inv_min;
-    const float* inv_max;
-    int B, S, H, W, CQ;
-};
-
 template <int CPG, int TILE>
 __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLevel& L, int lvl, float* __restrict__ lds) {
     using K = Chunk<CPG>;
@@ -295,45 +130,6 @@ __global__ void __launch_bounds__(kThreads) corr_iter_kernel(const IterArgs a) {
 //     bit for bit -- and writes the [B,N,8,H,W] planes.
 // S > 4 runs in chunks of 4 views with the accumulators carried in registers.
 // ---------------------------------------------------------------------------------------------
-constexpr int kVwTile = 32;   // pixels per block: TW x (32 / TW)
-constexpr int kVwViews = 4;   // views per chunk (= waves per block)
-
-__device__ __forceinline__ float quad_bcast(float x, int u) {   // u is a constant after unrolling
-    switch (u) {
-        case 0: return quad_perm<ITERMVS_QP(0, 0, 0, 0)>(x);
-        case 1: return quad_perm<ITERMVS_QP(1, 1, 1, 1)>(x);
-        case 2: return quad_perm<ITERMVS_QP(2, 2, 2, 2)>(x);
-        default: return quad_perm<ITERMVS_QP(3, 3, 3, 3)>(x);
-    }
-}
-__device__ __forceinline__ uint32_t quad_bcast(uint32_t x, int u) {
-    return (uint32_t)__float_as_int(quad_bcast(__int_as_float((int)x), u));
-}
-
-template <int VEC, bool NT>
-__device__ __forceinline__ void load_vec_opt(const float* __restrict__ p, float (&v)[VEC]) {
-#pragma unroll
-    for (int i = 0; i < VEC / 4; ++i) {
-        typedef float vec4f __attribute__((ext_vector_type(4)));
-        const vec4f* q = reinterpret_cast<const vec4f*>(p + 16 * i);
-        vec4f t;
-        if constexpr (NT) t = __builtin_nontemporal_load(q);
-        else t = *q;
-        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
-    }
-}
-
-// Every level uses 4 lanes (one quad) per (pixel, view): lane j owns the float4 at channel 4j of every 16-channel block
-// (C=16: 1 block, C=32: 2, C=48: 3), so each load instruction of the quad covers one contiguous 64-byte run and one tap
-// address serves VEC/4 loads.  Two correlation groups are finalised per lane.
-template <int CPG>
-struct VwChunk {
-    static constexpr int VEC = 2 * CPG;   // floats per lane: 4 / 8 / 12
-    static constexpr int NG = 2;
-    // correlation group of result q of lane j
-    static __device__ __forceinline__ int group(int j, int q) { return CPG == 4 ? j + 4 * q : 2 * j + q; }
-};
-
 template <int CPG>
 __device__ __forceinline__ void blend_corr_vw(const TapData<2 * CPG>& t, const Footprint& tp, const float (&refv)[2 * CPG],
                                               float (&corr)[2]) {
@@ -368,7 +164,7 @@ __device__ __forceinline__ void blend_corr_vw(const TapData<2 * CPG>& t, const F
     }
 }
 
-template <int CPG, int NB, bool NT>
+template <int CPG, int NB>
 __device__ __forceinline__ void corr_iter_vw_level(const IterArgs& a, const IterLevel& L, int lvl, float* __restrict__ lds,
                                                    int tw_log2) {
     using K = VwChunk<CPG>;
@@ -443,10 +239,10 @@ __device__ __forceinline__ void corr_iter_vw_level(const IterArgs& a, const Iter
                             Footprint wt[NB];
 #pragma unroll
                             for (int u = 0; u < NB; ++u) {
-                                load_vec_opt<K::VEC, NT>(fb + (quad_bcast(o00, lb + u) + joff), td[u].v00);
-                                load_vec_opt<K::VEC, NT>(fb + (quad_bcast(o01, lb + u) + joff), td[u].v01);
-                                load_vec_opt<K::VEC, NT>(fb + (quad_bcast(o10, lb + u) + joff), td[u].v10);
-                                load_vec_opt<K::VEC, NT>(fb + (quad_bcast(o11, lb + u) + joff), td[u].v11);
+                                load_vec<K::VEC>(fb + (quad_bcast(o00, lb + u) + joff), td[u].v00);
+                                load_vec<K::VEC>(fb + (quad_bcast(o01, lb + u) + joff), td[u].v01);
+                                load_vec<K::VEC>(fb + (quad_bcast(o10, lb + u) + joff), td[u].v10);
+                                load_vec<K::VEC>(fb + (quad_bcast(o11, lb + u) + joff), td[u].v11);
                                 wt[u].nw = quad_bcast(f.nw, lb + u); wt[u].ne = quad_bcast(f.ne, lb + u);
                                 wt[u].sw = quad_bcast(f.sw, lb + u); wt[u].se = quad_bcast(f.se, lb + u);
                             }
@@ -501,15 +297,15 @@ __device__ __forceinline__ void corr_iter_vw_level(const IterArgs& a, const Iter
     }
 }
 
-template <bool NT, int NBA, int NBB, int NBC, int WAVES>
+template <int NBA, int NBB, int NBC, int WAVES>
 __global__ void __launch_bounds__(kThreads, WAVES) corr_iter_vw_kernel(const IterArgs a, const int tw_log2) {
     extern __shared__ float lds[];   // see corr_iter_vw_level; sized by the launch for the level with most hypotheses
     const int lvl = blockIdx.y;
     const IterLevel& L = a.lv[lvl];
     switch (L.C) {
-        case 16: corr_iter_vw_level<2, NBA, NT>(a, L, lvl, lds, tw_log2); break;
-        case 32: corr_iter_vw_level<4, NBB, NT>(a, L, lvl, lds, tw_log2); break;
-        default: corr_iter_vw_level<6, NBC, NT>(a, L, lvl, lds, tw_log2); break;
+        case 16: corr_iter_vw_level<2, NBA>(a, L, lvl, lds, tw_log2); break;
+        case 32: corr_iter_vw_level<4, NBB>(a, L, lvl, lds, tw_log2); break;
+        default: corr_iter_vw_level<6, NBC>(a, L, lvl, lds, tw_log2); break;
     }
 }
 
@@ -719,32 +515,10 @@ extern "C" int itermvs_pvw_tail(const float* x, const float* w, const float* bia
 static int default_impl() {
     static const int v = [] {
         const char* e = getenv("ITERMVS_CORR_ITER_IMPL");
-        if (e && e[0] == 'l') return 1;
-        if (e && e[0] == 'n') return 3;
-        return 2;
+        const int n = e ? atoi(e) : 0;
+        return n > 0 ? n : 1;
     }();
     return v;
-}
-static int default_narrow() {
-    static const int v = [] {
-        const char* e = getenv("ITERMVS_CORR_TILE_W");
-        const int w = e ? atoi(e) : 32;
-        return w == 8 ? 2 : w == 16 ? 1 : 0;
-    }();
-    return v;
-}
-
-static int check_level(const itermvs_level_src& s, int S) {
-    ITERMVS_RETURN_IF(s.C != 16 && s.C != 32 && s.C != 48, ITERMVS_ERR_CHANNELS);
-    ITERMVS_RETURN_IF(s.H < 1 || s.W < 1, ITERMVS_ERR_DIMS);
-    ITERMVS_RETURN_IF(s.sc != 1, ITERMVS_ERR_LAYOUT);
-    ITERMVS_RETURN_IF((s.sx % 4) || (s.sy % 4) || (s.sb % 4), ITERMVS_ERR_ALIGN);
-    ITERMVS_RETURN_IF(s.sx <= 0 || s.sy <= 0 || (int64_t)s.H * s.sy >= (int64_t)1 << 31, ITERMVS_ERR_DIMS);  // 32-bit tap offsets
-    for (int v = 0; v < S; ++v) {
-        ITERMVS_RETURN_IF(!s.view[v], ITERMVS_ERR_NULL);
-        ITERMVS_RETURN_IF(((uintptr_t)s.view[v]) % 16, ITERMVS_ERR_ALIGN);
-    }
-    return ITERMVS_OK;
 }
 
 extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream) {
@@ -754,7 +528,7 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
     ITERMVS_RETURN_IF(!p->ref_q || !p->proj || !p->view_w || !p->inv_depth_min || !p->inv_depth_max, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(((uintptr_t)p->ref_q) % 16, ITERMVS_ERR_ALIGN);
     for (int l = 0; l < 3; ++l) {
-        const int rc = check_level(p->src[l], p->S);
+        const int rc = itermvs_check_level(p->src[l], p->S);
         if (rc) return rc;
         ITERMVS_RETURN_IF(p->N[l] < 1 || p->N[l] > ITERMVS_MAX_HYP, ITERMVS_ERR_DIMS);
         ITERMVS_RETURN_IF(!p->out[l], ITERMVS_ERR_NULL);
@@ -776,16 +550,18 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
     a.ref_q = p->ref_q; a.proj = p->proj; a.view_w = p->view_w; a.nd = p->norm_depth; a.nd_sb = p->norm_depth_sb;
     a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max;
     a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.CQ = coff;
-    // impl % 10: 0 = default (ITERMVS_CORR_ITER_IMPL=lane|views|nt overrides), 1 = views walked in the lane, 2 = views across
-    // waves with (4, 2, 1) hypotheses' taps in flight on the (C=16, 32, 48) levels, 3 = 2 with non-temporal tap loads,
-    // 4 / 5 / 6 = (2,1,1) / (4,4,2) / (2,2,1) in flight, 7 = 2 held to 128 registers (experiments: registers vs occupancy); impl / 10 = log2 narrowing of the 32-pixel tile of forms 2 / 3
-    // (0: 32x1 strips, 1: 16x2, 2: 8x4; experiment, ITERMVS_CORR_TILE_W sets the default)
+    // impl % 10: 0 = default (ITERMVS_CORR_ITER_IMPL=<number> overrides), 1 = views walked in the lane (default), 2 = views
+    // across waves with (4, 2, 1) hypotheses' taps in flight on the (C=16, 32, 48) levels, 3 = 2 held to 128 registers
+    // (4 waves per SIMD); impl / 10 = log2 narrowing of the 32-pixel tile of forms 2 / 3 (0: 32x1 strips, 1: 16x2, 2: 8x4).
+    // Measured on MI355X (profiles/r02): both forms sit at the same 24-34 us per launch at cfg 1 -- the launch is bound by
+    // the rate at which a CU's vector L1 gets its misses served (1.2-1.6 M 128-byte requests per launch, ~4800 per CU),
+    // the second form issues 14 % fewer vector instructions but misses the L1 31 % more often.
     int variant = p->impl % 10, narrow = p->impl / 10;
     if (variant == 0) {
-        variant = default_impl();
-        narrow = default_narrow();
+        variant = default_impl() % 10;
+        narrow = default_impl() / 10;
     }
-    ITERMVS_RETURN_IF(variant < 1 || variant > 7 || narrow < 0 || narrow > 2, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(variant < 1 || variant > 3 || narrow < 0 || narrow > 2, ITERMVS_ERR_DIMS);
     itermvs_profile_begin(1, (hipStream_t)stream);
     if (variant == 1) {
         constexpr int TILE = 32;
@@ -799,16 +575,10 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
         const int nmax = max(p->N[0], max(p->N[1], p->N[2]));
         const size_t shmem = (size_t)((kVwViews + (p->S > kVwViews ? 1 : 0)) * nmax * ITERMVS_GROUPS + (p->S > kVwViews ? ITERMVS_GROUPS : 0)) *
                              (kVwTile + 1) * sizeof(float);
-#define VW_LAUNCH(...) hipLaunchKernelGGL((corr_iter_vw_kernel<__VA_ARGS__>), grid, dim3(kThreads), shmem, (hipStream_t)stream, a, tw_log2)
-        switch (variant) {
-            case 3: VW_LAUNCH(true, 4, 2, 1, 3); break;
-            case 4: VW_LAUNCH(false, 2, 1, 1, 3); break;
-            case 5: VW_LAUNCH(false, 4, 4, 2, 2); break;
-            case 6: VW_LAUNCH(false, 2, 2, 1, 3); break;
-            case 7: VW_LAUNCH(false, 4, 2, 1, 4); break;
-            default: VW_LAUNCH(false, 4, 2, 1, 3); break;
-        }
-#undef VW_LAUNCH
+        if (variant == 3)
+            hipLaunchKernelGGL((corr_iter_vw_kernel<4, 2, 1, 4>), grid, dim3(kThreads), shmem, (hipStream_t)stream, a, tw_log2);
+        else
+            hipLaunchKernelGGL((corr_iter_vw_kernel<4, 2, 1, 3>), grid, dim3(kThreads), shmem, (hipStream_t)stream, a, tw_log2);
     }
     itermvs_profile_end(1, (hipStream_t)stream);
     return itermvs_launch_status();
@@ -819,7 +589,7 @@ extern "C" int itermvs_corr_init(const itermvs_corr_init_params* p, void* stream
     ITERMVS_RETURN_IF(p->B < 1 || p->H < 1 || p->W < 1 || p->N < 2, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(p->S < 1 || p->S > ITERMVS_MAX_SRC, ITERMVS_ERR_VIEWS);
     ITERMVS_RETURN_IF(!p->ref.data || !p->proj || !p->inv_depth_min || !p->inv_depth_max || !p->out, ITERMVS_ERR_NULL);
-    const int rc = check_level(p->src, p->S);
+    const int rc = itermvs_check_level(p->src, p->S);
     if (rc) return rc;
     ITERMVS_RETURN_IF(p->ref.C != p->src.C || p->ref.H != p->H || p->ref.W != p->W, ITERMVS_ERR_DIMS);
     InitArgs a;

@@ -1,0 +1,213 @@
+// Shared device helpers of the fused warp + correlation kernels (corr.hip forward, corr_bwd.hip gradient).
+#pragma once
+#include <stdlib.h>
+
+#include "common.hpp"
+
+namespace itermvs {
+
+constexpr int kThreads = 256;
+
+template <int CPG>
+struct Chunk {
+    // lane j of a (pixel, hypothesis) group owns the float4 at channel 4*j of every 16-channel block:
+    //   C=16: 4 lanes x 1 float4            (two correlation groups of 2 per lane)
+    //   C=32: 8 lanes x 1 float4            (one group of 4 per lane)
+    //   C=48: 4 lanes x 3 float4 (stride 16 channels): every load instruction of the group covers one
+    //         contiguous 64-byte run (one L1 access) -- a "6 floats per lane" layout costs 9 accesses
+    //         per tap instead of 3 and made the L1 tag rate the bound of the whole kernel.  The lane's
+    //         12 channels straddle the 6-channel correlation groups; partial sums are re-grouped with
+    //         four quad-local DPP moves (see blend_corr).
+    static constexpr int VEC = (CPG == 6) ? 12 : 4;  // floats per lane
+    static constexpr int LPT = (CPG == 4) ? 8 : 4;   // lanes per tap
+    static constexpr int NG = (CPG == 4) ? 1 : 2;    // correlation groups finalised per lane
+};
+
+// channel of element c of lane j's chunk
+template <int VEC>
+__device__ __forceinline__ int chunk_channel(int j, int c) {
+    return 16 * (c / 4) + 4 * j + (c % 4);
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC / 4; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(p + 16 * i);
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+}
+
+// v_mov_b32 dpp quad_perm: lane l of each quad reads lane ((CTRL >> 2*l) & 3) of the same quad
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+#define ITERMVS_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+
+// Everything about one bilinear footprint that is identical for the chunk lanes of a
+// (pixel, hypothesis): 32-bit element offsets of the two rows / two columns and the four weights
+// (already zero for out-of-range taps).  Computed by ONE lane and broadcast with shuffles.
+struct Footprint {
+    uint32_t r0, r1, c0, c1;
+    float nw, ne, sw, se;
+};
+
+__device__ __forceinline__ Footprint make_footprint(float ix, float iy, int W1, int H1, uint32_t sy, uint32_t sx) {
+    const Taps t = make_taps(ix, iy, W1, H1);
+    Footprint f;
+    f.r0 = (uint32_t)t.y0 * sy; f.r1 = (uint32_t)t.y1 * sy;
+    f.c0 = (uint32_t)t.x0 * sx; f.c1 = (uint32_t)t.x1 * sx;
+    f.nw = t.nw; f.ne = t.ne; f.sw = t.sw; f.se = t.se;
+    return f;
+}
+
+__device__ __forceinline__ Footprint shfl_footprint(const Footprint& f, int src_lane) {
+    Footprint o;
+    o.r0 = (uint32_t)__shfl((int)f.r0, src_lane, 64); o.r1 = (uint32_t)__shfl((int)f.r1, src_lane, 64);
+    o.c0 = (uint32_t)__shfl((int)f.c0, src_lane, 64); o.c1 = (uint32_t)__shfl((int)f.c1, src_lane, 64);
+    o.nw = __shfl(f.nw, src_lane, 64); o.ne = __shfl(f.ne, src_lane, 64);
+    o.sw = __shfl(f.sw, src_lane, 64); o.se = __shfl(f.se, src_lane, 64);
+    return o;
+}
+
+// group correlation of one lane's chunk for one view: bilinear blend of the four taps, product
+// with the reference chunk, mean over the channels of each group (itermvs.py:50-51).
+// `fb` is wave-uniform (SGPR base), tap offsets are 32-bit element offsets (saddr + voffset loads).
+template <int VEC>
+struct TapData {
+    float v00[VEC], v01[VEC], v10[VEC], v11[VEC];
+};
+
+// `fb` is wave-uniform (SGPR base), tap offsets are 32-bit element offsets (saddr + voffset loads).
+template <int VEC>
+__device__ __forceinline__ void load_taps(const float* __restrict__ fb, uint32_t joff, const Footprint& tp, TapData<VEC>& t) {
+    const uint32_t r0 = tp.r0 + joff, r1 = tp.r1 + joff;
+    load_vec<VEC>(fb + (r0 + tp.c0), t.v00);
+    load_vec<VEC>(fb + (r0 + tp.c1), t.v01);
+    load_vec<VEC>(fb + (r1 + tp.c0), t.v10);
+    load_vec<VEC>(fb + (r1 + tp.c1), t.v11);
+}
+
+// group correlation of one lane's chunk for one view: bilinear blend of the four taps, product
+// with the reference chunk, mean over the channels of each group (itermvs.py:50-51).
+template <int CPG>
+__device__ __forceinline__ void blend_corr(const TapData<Chunk<CPG>::VEC>& t, const Footprint& tp,
+                                           const float (&refv)[Chunk<CPG>::VEC], float (&corr)[Chunk<CPG>::NG]) {
+    constexpr int VEC = Chunk<CPG>::VEC;
+    float w[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c)
+        w[c] = fmaf(tp.se, t.v11[c], fmaf(tp.sw, t.v10[c], fmaf(tp.ne, t.v01[c], tp.nw * t.v00[c])));
+    if constexpr (CPG == 2) {
+        corr[0] = fmaf(w[1], refv[1], w[0] * refv[0]) * 0.5f;
+        corr[1] = fmaf(w[3], refv[3], w[2] * refv[2]) * 0.5f;
+    } else if constexpr (CPG == 4) {
+        corr[0] = fmaf(w[3], refv[3], fmaf(w[2], refv[2], fmaf(w[1], refv[1], w[0] * refv[0]))) * 0.25f;
+    } else {
+        // lane j (= lane & 3) holds channels 16i + 4j + k (i = 0..2, k = 0..3); group g = channels
+        // 6g .. 6g+5.  lo_i / hi_i = products of the lower / upper channel pair of block i:
+        //   g0 = s0[j0] + lo0[j1]   g1 = hi0[j1] + s0[j2]      (s_i = lo_i + hi_i)
+        //   g2 = s0[j3] + lo1[j0]   g3 = hi1[j0] + s1[j1]
+        //   g4 = s1[j2] + lo1[j3]   g5 = hi1[j3] + s2[j0]
+        //   g6 = s2[j1] + lo2[j2]   g7 = hi2[j2] + s2[j3]
+        // lane d finalises groups 2d and 2d+1; each source lane selects what it owes and one
+        // quad_perm per term delivers it.
+        float lo[3], hi[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            lo[i] = fmaf(w[4 * i + 1], refv[4 * i + 1], w[4 * i] * refv[4 * i]);
+            hi[i] = fmaf(w[4 * i + 3], refv[4 * i + 3], w[4 * i + 2] * refv[4 * i + 2]);
+        }
+        const float s0 = lo[0] + hi[0], s1 = lo[1] + hi[1], s2 = lo[2] + hi[2];
+        const int j = threadIdx.x & 3;
+        const float ta = (j == 0 || j == 3) ? s0 : (j == 2 ? s1 : s2);
+        const float tb = (j == 1) ? lo[0] : (j == 2 ? lo[2] : lo[1]);
+        const float tc = (j == 1) ? hi[0] : (j == 2 ? hi[2] : hi[1]);
+        const float tdd = (j == 2) ? s0 : (j == 1 ? s1 : s2);
+        const float g_first = quad_perm<ITERMVS_QP(0, 3, 2, 1)>(ta) + quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tb);
+        const float g_second = quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tc) + quad_perm<ITERMVS_QP(2, 1, 0, 3)>(tdd);
+        corr[0] = g_first / 6.0f;
+        corr[1] = g_second / 6.0f;
+    }
+}
+
+template <int CPG>
+__device__ __forceinline__ void chunk_corr(const float* __restrict__ fb, uint32_t joff, const Footprint& tp,
+                                           const float (&refv)[Chunk<CPG>::VEC], float (&corr)[Chunk<CPG>::NG]) {
+    TapData<Chunk<CPG>::VEC> t;
+    load_taps<Chunk<CPG>::VEC>(fb, joff, tp, t);
+    blend_corr<CPG>(t, tp, refv, corr);
+}
+
+// XCD-aware tile order: block k is observed to run on XCD k % 8 (a speed assumption only), so give
+// each XCD a contiguous band of pixel tiles; neighbouring tiles then share one L2 instead of having
+// every L2 fetch its own copy of the same source lines.  grid.x is a multiple of 8.
+__device__ __forceinline__ int xcd_tile(int tiles) {
+    const int per_xcd = (tiles + 7) / 8;
+    return (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+}
+
+struct IterLevel {
+    const float* src[ITERMVS_MAX_SRC];
+    int64_t sb, sy, sx;
+    const float* depth;  // explicit hypotheses or nullptr
+    float* out;
+    float offs[ITERMVS_MAX_HYP];
+    int C, H1, W1, N, coff;
+};
+
+struct IterArgs {
+    IterLevel lv[3];
+    const float* ref_q;
+    const float* proj;
+    const float* view_w;
+    const float* nd;
+    int64_t nd_sb;
+    const float* inv_min;
+    const float* inv_max;
+    int B, S, H, W, CQ;
+};
+
+constexpr int kVwTile = 32;   // pixels per block: TW x (32 / TW)
+constexpr int kVwViews = 4;   // views per chunk (= waves per block)
+
+__device__ __forceinline__ float quad_bcast(float x, int u) {   // u is a constant after unrolling
+    switch (u) {
+        case 0: return quad_perm<ITERMVS_QP(0, 0, 0, 0)>(x);
+        case 1: return quad_perm<ITERMVS_QP(1, 1, 1, 1)>(x);
+        case 2: return quad_perm<ITERMVS_QP(2, 2, 2, 2)>(x);
+        default: return quad_perm<ITERMVS_QP(3, 3, 3, 3)>(x);
+    }
+}
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t x, int u) {
+    return (uint32_t)__float_as_int(quad_bcast(__int_as_float((int)x), u));
+}
+
+// Every level uses 4 lanes (one quad) per (pixel, view): lane j owns the float4 at channel 4j of every 16-channel block
+// (C=16: 1 block, C=32: 2, C=48: 3), so each load instruction of the quad covers one contiguous 64-byte run and one tap
+// address serves VEC/4 loads.  Two correlation groups are finalised per lane.
+template <int CPG>
+struct VwChunk {
+    static constexpr int VEC = 2 * CPG;   // floats per lane: 4 / 8 / 12
+    static constexpr int NG = 2;
+    // correlation group of result q of lane j
+    static __device__ __forceinline__ int group(int j, int q) { return CPG == 4 ? j + 4 * q : 2 * j + q; }
+};
+
+}  // namespace itermvs
+
+// argument checks shared by the forward and backward entry points
+static inline int itermvs_check_level(const itermvs_level_src& s, int S) {
+    ITERMVS_RETURN_IF(s.C != 16 && s.C != 32 && s.C != 48, ITERMVS_ERR_CHANNELS);
+    ITERMVS_RETURN_IF(s.H < 1 || s.W < 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(s.sc != 1, ITERMVS_ERR_LAYOUT);
+    ITERMVS_RETURN_IF((s.sx % 4) || (s.sy % 4) || (s.sb % 4), ITERMVS_ERR_ALIGN);
+    ITERMVS_RETURN_IF(s.sx <= 0 || s.sy <= 0 || (int64_t)s.H * s.sy >= (int64_t)1 << 31, ITERMVS_ERR_DIMS);  // 32-bit tap offsets
+    for (int v = 0; v < S; ++v) {
+        ITERMVS_RETURN_IF(!s.view[v], ITERMVS_ERR_NULL);
+        ITERMVS_RETURN_IF(((uintptr_t)s.view[v]) % 16, ITERMVS_ERR_ALIGN);
+    }
+    return ITERMVS_OK;
+}
+

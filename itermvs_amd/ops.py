@@ -189,8 +189,8 @@ def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, vie
 
 def corr_iter_kernel_name() -> str:
     """name of the device kernel itermvs_corr_iter launches by default (rocprofv3's Kernel_Name contains it)"""
-    form = os.environ.get("ITERMVS_CORR_ITER_IMPL", "views")[:1]
-    return {"l": "corr_iter_kernel", "n": "corr_iter_vw_kernel<true"}.get(form, "corr_iter_vw_kernel<false")
+    form = os.environ.get("ITERMVS_CORR_ITER_IMPL", "1")
+    return "corr_iter_kernel" if (int(form) if form.isdigit() else 1) % 10 == 1 else "corr_iter_vw_kernel"
 
 
 def corr_init(src3: Sequence[Tensor], ref3: Tensor, proj: Tensor, inv_min: Tensor, inv_max: Tensor,

@@ -221,7 +221,7 @@ def test_pvw_tail_fused(shape):
 
 @pytest.mark.parametrize("tag", ["seed0", "dtu"])
 @pytest.mark.parametrize("mode", ["explicit", "generated"])
-@pytest.mark.parametrize("impl", [1, 2, 24])
+@pytest.mark.parametrize("impl", [1, 2, 23])
 def test_corr_iter(tag, mode, impl):
     g, src, ref, p12, inv_min, inv_max = _small(tag)
     ref_q = ops().ref_quarter(ref[1], ref[2], ref[3])
@@ -241,8 +241,7 @@ def test_corr_iter(tag, mode, impl):
 
 
 def test_corr_iter_forms_agree():
-    """the two kernel forms of itermvs_corr_iter (views walked in the lane / views across waves, every tile shape and
-    in-flight depth) evaluate the same arithmetic in the same order: C=16 and C=32 levels bit for bit, the C=48 level
+    """the two kernel forms of itermvs_corr_iter (views walked in the lane / views across waves, every tile shape) evaluate the same arithmetic in the same order: C=16 and C=32 levels bit for bit, the C=48 level
     (whose group mean uses the reciprocal-corrected division in the second form) to one rounding"""
     g, src, ref, p12, inv_min, inv_max = _small("dtu")
     ref_q = ops().ref_quarter(ref[1], ref[2], ref[3])
@@ -250,7 +249,7 @@ def test_corr_iter_forms_agree():
     from itermvs_amd.engine import sample_offsets
     nd = cu(g["iter0.nd_in"])
     base = ops().corr_iter(src, ref_q, p12, vw, inv_min, inv_max, norm_depth=nd, offsets=sample_offsets(), impl=1)
-    for impl in (2, 3, 4, 5, 6, 7, 12, 22, 17):
+    for impl in (2, 3, 12, 22, 13, 23):
         got = ops().corr_iter(src, ref_q, p12, vw, inv_min, inv_max, norm_depth=nd, offsets=sample_offsets(), impl=impl)
         assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]), impl
         assert maxdiff(got[2], base[2]) <= 2e-7 * max(1.0, float(base[2].abs().max())), impl
@@ -445,7 +444,7 @@ def test_bilinear_up():
     assert maxdiff(ops().bilinear_up(cu(x), 2, act="tanh"), torch.tanh(F.interpolate(x, scale_factor=2, mode="bilinear"))) <= 1e-6
 
 
-@pytest.mark.parametrize("impl", [1, 2, 7, 14, 23, 25])
+@pytest.mark.parametrize("impl", [1, 2, 3, 12, 23])
 def test_ragged_sizes_and_many_views(impl):
     """pixel count not a multiple of the tile, non-integer map/grid ratios, S = 10 source views
     (the pair.txt maximum), B = 2."""

@@ -101,7 +101,7 @@ def test_every_stage_on_the_oracles_inputs(wtag, kind, views, height, width, ite
 
     # FeatureNet on the same images (the only stage whose input is not an oracle intermediate)
     with torch.no_grad():
-        feats = eng.feature_net(cu(s["imgs"]["level_0"]).reshape(b * v, 3, height, width))
+        feats = eng.feature_net(cu(s["imgs"]["level_0"]).reshape(b * v, 3, height, width).contiguous())
     for l in (1, 2, 3):
         lim(f"feat{l}", rel_err(feats[l], t["feats"][l]), 2e-5)
 
