@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ITERMVS_ABI_VERSION 4
+#define ITERMVS_ABI_VERSION 5
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -158,6 +158,27 @@ typedef struct itermvs_corr_init_params {
 } itermvs_corr_init_params;
 
 int itermvs_corr_init(const itermvs_corr_init_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gradients of the two fused correlation entry points for training (train.py:194-243; the training branches of
+ * models/itermvs.py:59-61, 111-113).  The sampling grid carries no gradient (models/module.py:77 builds it under
+ * torch.no_grad), the view weights of the iteration branch are detached (models/itermvs.py:295); so the gradient flows to
+ * the source features (scatter-add of the four taps, fp32 hardware atomics) and to the reference features (gather; the
+ * warped values are recomputed, no [B,C,N,H,W] volume is ever stored).
+ *
+ * itermvs_corr_iter_backward: `p` = the forward's parameter block (its `out` pointers are ignored);
+ *   grad_out[l]   [B,N_l,8,H,W]  dL/d out_l
+ *   grad_src[l]   host array of S device pointers: dL/d src_l[s], addressed with the strides of p->src[l]
+ *                 (channels-last), ZERO-FILLED by the caller, accumulated into;
+ *   grad_ref_q    [B,H,W,C1+C2+C3] dL/d ref_q, written completely.
+ * itermvs_corr_init_backward: `p` = the forward's parameter block (p->ref must be channels-last here, N <= 32);
+ *   grad_out      [B,S,N,8,H,W]  dL/d out;   grad_src: S device pointers as above (zero-filled);
+ *   grad_ref      dL/d ref, addressed with the strides of p->ref, written completely.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_corr_iter_backward(const itermvs_corr_iter_params* p, const float* const grad_out[3],
+                               float* const* const grad_src[3], float* grad_ref_q, void* stream);
+int itermvs_corr_init_backward(const itermvs_corr_init_params* p, const float* grad_out, float* const* grad_src,
+                               float* grad_ref, void* stream);
 
 /* itermvs_view_aggregate -- models/itermvs.py:59-69
  *   out[b,n,g,p] = sum_s corr[b,s,n,g,p] * w[b,s,p] / (1e-5 + sum_s w[b,s,p])

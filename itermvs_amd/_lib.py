@@ -13,7 +13,7 @@ from typing import Optional
 MAX_SRC = 16
 MAX_HYP = 8
 GROUPS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitermvs_hip.so")
@@ -79,6 +79,9 @@ PROTOTYPES = {
     "itermvs_ref_quarter": (C.c_int, [C.POINTER(FMap)] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "itermvs_corr_iter": (C.c_int, [C.POINTER(CorrIterParams), C.c_void_p]),
     "itermvs_corr_init": (C.c_int, [C.POINTER(CorrInitParams), C.c_void_p]),
+    "itermvs_corr_iter_backward": (C.c_int, [C.POINTER(CorrIterParams), C.POINTER(C.c_void_p * 3),
+                                             C.POINTER(C.POINTER(C.c_void_p) * 3), C.c_void_p, C.c_void_p]),
+    "itermvs_corr_init_backward": (C.c_int, [C.POINTER(CorrInitParams), C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
     "itermvs_view_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_void_p, C.c_void_p]),
     "itermvs_pvw_tail": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

@@ -187,6 +187,130 @@ def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, vie
     return outs
 
 
+def _corr_iter_params(src, ref_q, proj, view_w, inv_min, inv_max, norm_depth, offsets, outs, impl=0):
+    """parameter block of itermvs_corr_iter for hypotheses generated from ``norm_depth`` + ``offsets``; returns (block, keep-alive)"""
+    b, h, w, _ = ref_q.shape
+    p = CorrIterParams()
+    p.B, p.S, p.H, p.W = b, len(src[1]), h, w
+    p.impl = impl
+    for i, l in enumerate((1, 2, 3)):
+        p.src[i] = level_src(src[l], f"src level {l}")
+        p.depth[i] = None
+        p.N[i] = len(offsets[l])
+        for k, o in enumerate(offsets[l]):
+            p.offsets[i][k] = o
+        p.out[i] = outs[i].data_ptr() if outs is not None else None
+    nd = norm_depth if (norm_depth.stride(3) == 1 and norm_depth.stride(2) == w) else norm_depth.contiguous()
+    p.norm_depth, p.norm_depth_sb = nd.data_ptr(), nd.stride(0)
+    p.ref_q, p.proj, p.view_w = ref_q.data_ptr(), proj.data_ptr(), view_w.data_ptr()
+    p.inv_depth_min, p.inv_depth_max = inv_min.data_ptr(), inv_max.data_ptr()
+    return p, nd
+
+
+def _views(feat: Tensor, b: int, v: int):
+    """[B*V,C,H,W] dense channels-last pyramid level -> (reference view [B,C,H,W], list of the V-1 source views), all views"""
+    pv = feat.view(b, v, *feat.shape[1:])
+    return pv[:, 0], [pv[:, i] for i in range(1, v)]
+
+
+def _need_cl(t: Tensor, name: str) -> Tensor:
+    _dev(t, name)
+    if not t.is_contiguous(memory_format=torch.channels_last):
+        raise RuntimeError(f"{name}: expected a dense channels-last [B*V,C,H,W] tensor")
+    return t
+
+
+class _CorrIterFn(torch.autograd.Function):
+    """itermvs.py:84-120 as one differentiable op: forward = itermvs_corr_iter, backward = itermvs_corr_iter_backward.
+    Inputs: ref_q [B,H,W,96], proj, view_w (detached by the caller, itermvs.py:295), inverse depth range, normalised
+    depth (no gradient, module.py:77), and the three channels-last pyramid levels [B*V,C_l,H_l,W_l] whose views 1..V-1 are
+    the sources.  The gradient w.r.t. each level is one dense tensor the kernel scatter-adds into (view 0 stays zero)."""
+
+    @staticmethod
+    def forward(ctx, ref_q, proj, view_w, inv_min, inv_max, norm_depth, offsets, b, v, f1, f2, f3):
+        src = {l: _views(f, b, v)[1] for l, f in ((1, f1), (2, f2), (3, f3))}
+        _, h, w, _ = ref_q.shape
+        outs = [torch.empty((b, len(offsets[l]), 8, h, w), device=ref_q.device, dtype=torch.float32) for l in (1, 2, 3)]
+        p, nd = _corr_iter_params(src, ref_q, proj, view_w, inv_min, inv_max, norm_depth, offsets, outs)
+        check(_lib.load().itermvs_corr_iter(C.byref(p), _stream()), "itermvs_corr_iter")
+        ctx.save_for_backward(ref_q, proj, view_w, inv_min, inv_max, nd, f1, f2, f3)
+        ctx.meta = (offsets, b, v)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        ref_q, proj, view_w, inv_min, inv_max, nd, f1, f2, f3 = ctx.saved_tensors
+        offsets, b, v = ctx.meta
+        feats = (f1, f2, f3)
+        src = {l: _views(f, b, v)[1] for l, f in zip((1, 2, 3), feats)}
+        p, nd = _corr_iter_params(src, ref_q, proj, view_w, inv_min, inv_max, nd, offsets, None)
+        gouts = [g.contiguous() for g in gouts]
+        gfeat = [torch.zeros_like(f) for f in feats]              # dense channels-last like the features
+        gref = torch.empty_like(ref_q)
+        go = (C.c_void_p * 3)(*[g.data_ptr() for g in gouts])
+        lv = [(C.c_void_p * (v - 1))(*[t.data_ptr() for t in _views(gf, b, v)[1]]) for gf in gfeat]
+        gs = (C.POINTER(C.c_void_p) * 3)(*[C.cast(a, C.POINTER(C.c_void_p)) for a in lv])
+        check(_lib.load().itermvs_corr_iter_backward(C.byref(p), C.byref(go), C.byref(gs), gref.data_ptr(), _stream()),
+              "itermvs_corr_iter_backward")
+        return (gref, None, None, None, None, None, None, None, None) + tuple(gfeat)
+
+
+def corr_iter_train(feats: Dict[int, Tensor], b: int, v: int, ref_q: Tensor, proj: Tensor, view_w: Tensor, inv_min: Tensor,
+                    inv_max: Tensor, norm_depth: Tensor, offsets: Dict[int, Sequence[float]]) -> Tuple[Tensor, ...]:
+    """differentiable itermvs_corr_iter: ``feats[l]`` = dense channels-last [B*V,C_l,H_l,W_l] (gradient to the source views)
+    and ``ref_q`` [B,H,W,96] (gradient) -> three [B,N_l,8,H,W] tensors"""
+    f = [_need_cl(feats[l], f"feature level {l}") for l in (1, 2, 3)]
+    return _CorrIterFn.apply(_dev(ref_q, "ref_q").contiguous(), _dev(proj, "proj").contiguous(), _dev(view_w, "view_w").contiguous(),
+                             inv_min, inv_max, norm_depth.detach(), {l: tuple(offsets[l]) for l in (1, 2, 3)}, b, v, *f)
+
+
+def _corr_init_params(src3, ref3, proj, inv_min, inv_max, n, out):
+    b, _, h, w = ref3.shape
+    p = CorrInitParams()
+    p.B, p.S, p.H, p.W, p.N = b, len(src3), h, w, n
+    p.src = level_src(src3, "src level 3")
+    p.ref = fmap(ref3, "ref3")
+    p.proj = proj.data_ptr()
+    p.depth = None
+    p.inv_depth_min, p.inv_depth_max = inv_min.data_ptr(), inv_max.data_ptr()
+    p.out = out.data_ptr() if out is not None else None
+    return p
+
+
+class _CorrInitFn(torch.autograd.Function):
+    """itermvs.py:48-51 (+ :11-19) as one differentiable op on the level-3 features [B*V,48,H,W] (channels-last):
+    per-view group correlation [B,S,N,8,H,W]; gradient = one dense tensor (reference view gathered, sources scattered)"""
+
+    @staticmethod
+    def forward(ctx, f3, proj, inv_min, inv_max, n, b, v):
+        ref3, src3 = _views(f3, b, v)
+        out = torch.empty((b, v - 1, n, 8) + tuple(f3.shape[2:]), device=f3.device, dtype=torch.float32)
+        p = _corr_init_params(src3, ref3, proj, inv_min, inv_max, n, out)
+        check(_lib.load().itermvs_corr_init(C.byref(p), _stream()), "itermvs_corr_init")
+        ctx.save_for_backward(f3, proj, inv_min, inv_max)
+        ctx.meta = (n, b, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        f3, proj, inv_min, inv_max = ctx.saved_tensors
+        n, b, v = ctx.meta
+        ref3, src3 = _views(f3, b, v)
+        p = _corr_init_params(src3, ref3, proj, inv_min, inv_max, n, None)
+        gout = gout.contiguous()
+        gf = torch.zeros_like(f3)
+        gref, gsrc = _views(gf, b, v)
+        ptrs = (C.c_void_p * (v - 1))(*[t.data_ptr() for t in gsrc])
+        check(_lib.load().itermvs_corr_init_backward(C.byref(p), gout.data_ptr(), ptrs, gref.data_ptr(), _stream()),
+              "itermvs_corr_init_backward")
+        return gf, None, None, None, None, None, None
+
+
+def corr_init_train(f3: Tensor, b: int, v: int, proj: Tensor, inv_min: Tensor, inv_max: Tensor, num_samples: int = 32) -> Tensor:
+    """differentiable itermvs_corr_init on the dense channels-last level-3 features [B*V,48,H,W]: -> [B,S,N,8,H,W]"""
+    return _CorrInitFn.apply(_need_cl(f3, "feature level 3"), _dev(proj, "proj").contiguous(), inv_min, inv_max, num_samples, b, v)
+
+
 def corr_iter_kernel_name() -> str:
     """name of the device kernel itermvs_corr_iter launches by default (rocprofv3's Kernel_Name contains it)"""
     form = os.environ.get("ITERMVS_CORR_ITER_IMPL", "1")

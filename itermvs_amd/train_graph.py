@@ -1,13 +1,17 @@
 """Differentiable (training) form of the pipeline and ``full_loss`` -- models/net.py:36-51,
 78-190 and the ``not self.test`` branches of models/itermvs.py:253-329.
 
-Training needs gradients w.r.t. the feature maps and every weight, so this path keeps the
-reference's tensor-level structure and runs it on PyTorch-ROCm autograd, with the homography
-warp -- the only non-dense operator on the path -- provided by the hand-written HIP kernels
-(``itermvs_warp`` forward, ``itermvs_warp_backward`` scatter-add) wrapped in a
-``torch.autograd.Function`` (ops.warp), and the camera composition by ``itermvs_compose_proj``.
-Like the reference (module.py:77) no gradient flows to depth hypotheses or cameras.
-Everything runs on the GPU; CPU tensors are rejected upstream (net.py counterpart).
+Training needs gradients w.r.t. the feature maps and every weight, so the dense layers keep the
+reference's tensor-level structure on PyTorch-ROCm autograd.  The matching part -- homography warp,
+bilinear gather, group-wise correlation and (iteration branch) the view-weighted mean, i.e. each
+``Evaluation`` call up to its CorrNet -- is ONE ``torch.autograd.Function`` per call backed by the fused
+HIP kernels: forward ``itermvs_corr_init`` / ``itermvs_corr_iter`` (the inference kernels), backward
+``itermvs_corr_init_backward`` / ``itermvs_corr_iter_backward`` (warped values recomputed, gradient
+scatter-added into the source features with fp32 atomics, gathered into the reference features).  No
+``[B,C,N,H,W]`` warped volume and no per-view cost volume of the iteration branch exists in training
+either.  Like the reference (module.py:77, itermvs.py:295) no gradient flows to depth hypotheses,
+cameras or (iteration branch) view weights.  Everything runs on the GPU; CPU tensors are rejected
+upstream (net.py counterpart).
 """
 from __future__ import annotations
 
@@ -72,23 +76,19 @@ class _Net:
         o1 = F.conv2d(mid, w[p + "output1.weight"], w[p + "output1.bias"], padding=1)
         return {1: o1, 2: o2, 3: o3}
 
-    # -- Evaluation pieces (itermvs.py:333-381) -------------------------------------------------
-    @staticmethod
-    def _fold_n(x):                                    # [B,G,N,H,W] -> [B*N,G,H,W]
-        b, g, n, h, w = x.shape
-        return x.permute(0, 2, 1, 3, 4).reshape(b * n, g, h, w)
-
+    # -- Evaluation pieces (itermvs.py:333-381); correlations arrive as [B,N,G,H,W], the layout the fused kernels
+    #    write and the reference reaches with its permute (itermvs.py:343-345, 367-369) --------------------------
     def view_weight(self, corr):
         w, p = self.w, "iter_mvs.evaluation.pixel_view_weight."
-        b, _, n, h, wd = corr.shape
-        x = F.relu(F.conv2d(self._fold_n(corr), w[p + "conv.0.conv.weight"], padding=1))
+        b, n, g, h, wd = corr.shape
+        x = F.relu(F.conv2d(corr.reshape(b * n, g, h, wd), w[p + "conv.0.conv.weight"], padding=1))
         x = F.conv2d(x, w[p + "conv.1.weight"], w[p + "conv.1.bias"]).view(b, n, h, wd)
         return torch.softmax(x, dim=1).max(dim=1, keepdim=True)[0]
 
     def corr_net(self, corr, level):
         w, p = self.w, f"iter_mvs.evaluation.corr_conv1.{level - 1}."
-        b, _, n, h, wd = corr.shape
-        c0 = F.relu(F.conv2d(self._fold_n(corr), w[p + "conv0.conv.weight"], padding=1))
+        b, n, g, h, wd = corr.shape
+        c0 = F.relu(F.conv2d(corr.reshape(b * n, g, h, wd), w[p + "conv0.conv.weight"], padding=1))
         c1 = F.relu(F.conv2d(c0, w[p + "conv1.conv.weight"], stride=2, padding=1))
         c2 = F.relu(F.conv2d(c1, w[p + "conv2.conv.weight"], stride=2, padding=1))
         u1 = c1 + F.conv_transpose2d(c2, w[p + "conv3.weight"], stride=2, padding=1, output_padding=1)
@@ -144,11 +144,6 @@ def _convex_upsample(nd: Tensor, weight: Tensor) -> Tensor:
     return up.permute(0, 1, 4, 2, 5, 3).reshape(b, 1, 4 * h, 4 * w)
 
 
-def _group_corr(warped: Tensor, ref: Tensor) -> Tensor:      # itermvs.py:50-51
-    b, c, n, h, w = warped.shape
-    return (warped.view(b, G, c // G, n, h, w) * ref.view(b, G, c // G, 1, h, w)).mean(dim=2)
-
-
 def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor], depth_min: Tensor,
                   depth_max: Tensor, iteration: int, bn_training: bool = True):
     """``Pipeline(test=False).forward``: returns the reference's training dict (net.py:115-120)."""
@@ -156,24 +151,26 @@ def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor
     b, v, _, hh, ww = imgs.shape
     s = v - 1
     feats = net.features(imgs.reshape(b * v, 3, hh, ww))
-    pv = {l: f.view(b, v, *f.shape[1:]) for l, f in feats.items()}
+    # channels-last copies of the pyramid: what the fused correlation kernels gather from (autograd sees a layout change)
+    cl = {l: f.contiguous(memory_format=torch.channels_last) for l, f in feats.items()}
+    ref = {l: cl[l].view(b, v, *cl[l].shape[1:])[:, 0] for l in (1, 2, 3)}
     nan_flag = torch.zeros((1,), device=imgs.device, dtype=torch.int32)
     with torch.no_grad():
         proj = ops.compose_proj(torch.stack([projs[1], projs[2], projs[3]]).reshape(3 * b, v, 4, 4), nan_flag).view(3, b, s, 12)
     h, wd = feats[2].shape[2:]
-    inv_min = (1.0 / depth_min).view(b, 1, 1, 1)
-    inv_max = (1.0 / depth_max).view(b, 1, 1, 1)
+    inv_min_b, inv_max_b = (1.0 / depth_min).contiguous(), (1.0 / depth_max).contiguous()
+    inv_min, inv_max = inv_min_b.view(b, 1, 1, 1), inv_max_b.view(b, 1, 1, 1)
 
     u = "iter_mvs.upsample."
-    up_w = F.conv2d(F.relu(F.conv2d(pv[2][:, 0], w[u + "0.weight"], padding=1)), w[u + "2.weight"])
+    up_w = F.conv2d(F.relu(F.conv2d(ref[2], w[u + "0.weight"], padding=1)), w[u + "2.weight"])
     up_w = torch.softmax(up_w.view(b, 1, 9, 4, 4, h, wd), dim=2)
 
     # ---- initialisation: itermvs.py:36-82 ------------------------------------------------------
     k = torch.arange(INIT_SAMPLES, device=imgs.device, dtype=torch.float32).view(1, -1, 1, 1)
-    samples = 1.0 / (inv_max + (k.expand(b, INIT_SAMPLES, h // 2, wd // 2) / (INIT_SAMPLES - 1)) * (inv_min - inv_max))
+    corr_views = ops.corr_init_train(cl[3], b, v, proj[2], inv_min_b, inv_max_b, INIT_SAMPLES)      # [B,S,N,8,h3,w3]
     acc, wsum, vws = 0, 1e-5, []
     for i in range(s):
-        corr = _group_corr(ops.warp(pv[3][:, i + 1], proj[2][:, i], samples), pv[3][:, 0])
+        corr = corr_views[:, i]                                                                 # [B,N,8,h3,w3]
         vw = net.view_weight(corr)
         vws.append(F.interpolate(vw, scale_factor=2, mode="bilinear"))
         acc = acc + corr * vw.unsqueeze(1)
@@ -192,23 +189,17 @@ def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor
     depths_up: List[Tensor] = []
     conf_up = None
     nd = nd.detach()
-    ref_q = {1: F.interpolate(pv[1][:, 0], scale_factor=0.5, mode="bilinear"), 2: pv[2][:, 0],
-             3: F.interpolate(pv[3][:, 0], scale_factor=2, mode="bilinear")}            # itermvs.py:95-98
-    offs = {l: torch.tensor(o, device=imgs.device).view(1, -1, 1, 1) for l, o in sample_offsets().items()}
+    # itermvs.py:95-98: reference features on the 1/4 grid, packed [B,H,W,96] like itermvs_ref_quarter does at inference
+    ref_q = torch.cat([F.interpolate(ref[1], scale_factor=0.5, mode="bilinear"), ref[2],
+                       F.interpolate(ref[3], scale_factor=2, mode="bilinear")], 1).permute(0, 2, 3, 1).contiguous()
+    offsets = sample_offsets()
     view_w_const = view_w.detach()                                                       # itermvs.py:295
 
     # ---- iterations: itermvs.py:288-314 ----------------------------------------------------------
     for it in range(iteration):
-        scores = []
-        for l in (1, 2, 3):
-            d = _unnorm(torch.clamp(nd + offs[l], 0, 1), inv_min, inv_max)
-            acc, wsum = 0, 1e-5
-            for i in range(s):
-                corr = _group_corr(ops.warp(pv[l][:, i + 1], proj[l - 1][:, i], d), ref_q[l])
-                vw = view_w_const[:, i].view(b, 1, 1, h, wd)
-                acc = acc + corr * vw
-                wsum = wsum + vw
-            scores.append(net.corr_net(acc / wsum, l))
+        # hypotheses clamp(nd + offsets) -> depth (itermvs.py:290-293) are built inside the kernel, as at inference
+        aggs = ops.corr_iter_train(cl, b, v, ref_q, proj, view_w_const, inv_min_b, inv_max_b, nd, offsets)
+        scores = [net.corr_net(aggs[i], l) for i, l in enumerate((1, 2, 3))]
         hidden = net.gru(hidden, torch.cat([nd] + scores, 1))
         conf0 = net.conf_logit(hidden)
         prob = net.probability(hidden)

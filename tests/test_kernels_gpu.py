@@ -257,6 +257,84 @@ def test_corr_iter_forms_agree():
         ops().corr_iter(src, ref_q, p12, vw, inv_min, inv_max, norm_depth=nd, offsets=sample_offsets(), impl=9)
 
 
+def _bwd_case(b, v, h, w, seed):
+    """random pyramid + cameras + depth for the gradient tests: CPU leaves (requires_grad) and the shared geometry"""
+    gen = torch.Generator().manual_seed(seed)
+    from itermvs_amd import synthetic
+    sm = synthetic.make_sample(b, v, 4 * h, 4 * w, seed=seed)      # (4h, 4w must be multiples of 32)
+    sizes = {1: (2 * h, 2 * w), 2: (h, w), 3: (h // 2, w // 2)}
+    chans = {1: 16, 2: 32, 3: 48}
+    feats = {l: torch.randn((b * v, chans[l]) + sizes[l], generator=gen).requires_grad_(True) for l in (1, 2, 3)}
+    projs = torch.stack([sm["proj_matrices"][f"level_{l}"] for l in (1, 2, 3)])
+    p12 = torch.stack([torch.stack([proj12_cpu(projs[i][:, s], projs[i][:, 0]) for s in range(1, v)], 1) for i in range(3)])
+    inv_min, inv_max = torch.full((b,), 1 / 425.0), torch.full((b,), 1 / 935.0)
+    return gen, feats, sizes, chans, p12, inv_min, inv_max
+
+
+def _oracle_corr(feat, ref, p12_l, depth, b, v, size):
+    """per-view group correlations [B,G,N,h,w] of one level with the oracle's differentiable pieces"""
+    pv = feat.view(b, v, *feat.shape[1:])
+    out = []
+    for s in range(1, v):
+        m = torch.cat([p12_l[:, s - 1].view(b, 3, 4), torch.zeros(b, 1, 4)], 1)
+        with torch.no_grad():
+            ix, iy, _ = O.warp_source_coords(m, depth, size[0], size[1])
+        out.append(O.group_correlation(O.bilinear_gather(pv[:, s], ix, iy), ref))
+    return out
+
+
+@pytest.mark.parametrize("b,v", [(1, 3), (2, 6)])
+def test_corr_iter_backward_matches_autograd(b, v):
+    """itermvs_corr_iter_backward (scatter-add to the source features, gather to ref_q) vs torch autograd through the
+    oracle's warp + group correlation + view-weighted mean (itermvs.py:84-120), hypotheses built from nd + offsets"""
+    from itermvs_amd.engine import sample_offsets
+    h, w = 24, 40
+    gen, feats, sizes, chans, p12, inv_min, inv_max = _bwd_case(b, v, h, w, 7)
+    ref_q = torch.randn((b, h, w, 96), generator=gen).requires_grad_(True)
+    vw = torch.rand((b, v - 1, h, w), generator=gen)
+    nd = torch.rand((b, 1, h, w), generator=gen)
+    samples = O.iteration_depth_samples(nd, inv_min.view(b, 1, 1, 1), inv_max.view(b, 1, 1, 1))
+    gw = {l: torch.randn((b, n, 8, h, w), generator=gen) for l, n in ((1, 4), (2, 4), (3, 2))}
+    off = {1: 0, 2: 16, 3: 48}
+    loss = 0
+    for i, l in enumerate((1, 2, 3)):
+        refl = ref_q[..., off[l]:off[l] + chans[l]].permute(0, 3, 1, 2)
+        acc, wsum = 0, 1e-5
+        for s, corr in enumerate(_oracle_corr(feats[l], refl, p12[i], samples[l], b, v, sizes[l])):
+            wv = vw[:, s].view(b, 1, 1, h, w)
+            acc, wsum = acc + corr * wv, wsum + wv
+        loss = loss + ((acc / wsum).permute(0, 2, 1, 3, 4) * gw[l]).sum()
+    loss.backward()
+    # HIP
+    fg = {l: cu(feats[l].detach()).contiguous(memory_format=torch.channels_last).requires_grad_(True) for l in (1, 2, 3)}
+    rq = cu(ref_q.detach()).requires_grad_(True)
+    outs = ops().corr_iter_train(fg, b, v, rq, cu(p12), cu(vw), cu(inv_min), cu(inv_max), cu(nd), sample_offsets())
+    sum((o * cu(gw[l])).sum() for o, l in zip(outs, (1, 2, 3))).backward()
+    for l in (1, 2, 3):
+        g_ref = feats[l].grad
+        assert maxdiff(fg[l].grad, g_ref) <= 1e-4 * max(1.0, float(g_ref.abs().max())), l
+        assert float(fg[l].grad.view(b, v, -1)[:, 0].abs().max()) == 0.0            # the reference view of the pyramid gets none here
+    assert maxdiff(rq.grad, ref_q.grad) <= 1e-4 * max(1.0, float(ref_q.grad.abs().max()))
+
+
+@pytest.mark.parametrize("b,v", [(1, 3), (2, 5)])
+def test_corr_init_backward_matches_autograd(b, v):
+    """itermvs_corr_init_backward vs autograd through the oracle (itermvs.py:48-51), 32 hypotheses uniform in inverse depth"""
+    h, w = 24, 40
+    gen, feats, sizes, chans, p12, inv_min, inv_max = _bwd_case(b, v, h, w, 9)
+    f3 = feats[3]
+    h3, w3 = sizes[3]
+    depth = O.initial_depth_samples(inv_min.view(b, 1, 1, 1), inv_max.view(b, 1, 1, 1), h3, w3)
+    gw = torch.randn((b, v - 1, 32, 8, h3, w3), generator=gen)
+    ref = f3.view(b, v, *f3.shape[1:])[:, 0]
+    corrs = _oracle_corr(f3, ref, p12[2], depth, b, v, sizes[3])
+    sum((c.permute(0, 2, 1, 3, 4) * gw[:, s]).sum() for s, c in enumerate(corrs)).backward()
+    fg = cu(f3.detach()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = ops().corr_init_train(fg, b, v, cu(p12[2]), cu(inv_min), cu(inv_max), 32)
+    (out * cu(gw)).sum().backward()
+    assert maxdiff(fg.grad, f3.grad) <= 1e-4 * max(1.0, float(f3.grad.abs().max()))
+
+
 @pytest.mark.parametrize("tag", ["seed0", "dtu"])
 def test_prob_regress_bit_exact_indices(tag):
     g = golden(f"e2e_small_{tag}.npz")
