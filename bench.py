@@ -31,13 +31,13 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s
 PMC_SUMMARY = "r02_pmc_kernels.json"   # written by tools/pmc_kernels.sh on the GPU box, committed per round
 
 
-def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int):
-    """DESIGN.md 'Algorithmic bytes': every required tensor moved once, fp32.
+def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int, e: int = 4):
+    """DESIGN.md 'Algorithmic bytes': every required tensor moved once; ``e`` = bytes per stored feature element (4, or 2
+    with --feature-dtype bf16 / fp16), everything else fp32.
     Returns (bytes per corr_iter launch, bytes per corr_init launch, bytes per depth map)."""
     p1, p2, p3 = (h // 2) * (w // 2), (h // 4) * (w // 4), (h // 8) * (w // 8)
-    e = 4
     it = batch * (s * (16 * p1 + 32 * p2 + 48 * p3) * e     # source pyramids, each view once
-                  + 96 * p2 * e                             # packed reference features at 1/4 res
+                  + 96 * p2 * 4                             # packed reference features at 1/4 res (kept fp32)
                   + p2 * 4                                  # normalised depth (hypotheses built in-kernel)
                   + s * p2 * 4                              # view weights
                   + 80 * p2 * 4)                            # [B,10,8,H/4,W/4] aggregated correlations out
@@ -93,7 +93,7 @@ def transfers_leg(args, dev, samples, world):
     m = Pipeline(iteration=args.iters, test=True)
     m.load_state_dict(synthetic.random_state_dict(0))
     m = m.to(dev).eval()
-    eng = InferenceEngine(m.weights(), args.iters)
+    eng = InferenceEngine(m.weights(), args.iters, args.feature_dtype)
     imgs0, projs0, dmin0, dmax0 = samples[0]
     pj = {l: projs0[f"level_{l}"].float() for l in (1, 2, 3)}
     runners = [GraphedRunner(eng, imgs0["level_0"].float(), pj, dmin0.float(), dmax0.float()) for _ in range(2)]
@@ -155,6 +155,8 @@ def main() -> None:
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--batch", type=int, default=1, help="reference views per step and GPU")
+    ap.add_argument("--feature-dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
+                    help="storage type of the feature pyramids (BASELINE cfg 4 bf16 / cfg 5 fp16); arithmetic stays fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-transfers", action="store_true", help="skip the host-buffers-in / host-buffers-out leg")
     ap.add_argument("--minimal", action="store_true",
@@ -188,6 +190,7 @@ def main() -> None:
         m = Pipeline(iteration=args.iters, test=True)
         m.load_state_dict(synthetic.random_state_dict(0))
         m.use_graphs = not args.eager
+        m.feature_dtype = args.feature_dtype
         models.append(m.to(dev).eval())
         streams.append(torch.cuda.Stream(device=dev) if args.streams > 1 else torch.cuda.current_stream(dev))
     model = models[0]
@@ -235,7 +238,7 @@ def main() -> None:
                 # an event-record node costs ~5 us of graph time: runner A carries them on iterations 0, 2, ...,
                 # runner B on 1, 3, ... -- every iteration position is sampled in every second replay
                 from itermvs_amd.engine import InferenceEngine
-                models[k]._engine = InferenceEngine(models[k].weights(), models[k].iteration)
+                models[k]._engine = InferenceEngine(models[k].weights(), models[k].iteration, args.feature_dtype)
                 models[k]._engine.profile_iterations = set(range(k % 2, args.iters, 2))
                 models[k]._engine.profile_init = (k % 2 == 0)
             models[k](*samples[0])
@@ -253,7 +256,8 @@ def main() -> None:
     value = maps / elapsed
 
     s_views = args.views - 1
-    b_iter, b_init, b_map = algorithmic_bytes(s_views, args.height, args.width, args.batch, args.iters)
+    b_iter, b_init, b_map = algorithmic_bytes(s_views, args.height, args.width, args.batch, args.iters,
+                                               4 if args.feature_dtype == "fp32" else 2)
     t_iter = [ms for kind, ms in prof if kind == 1]
     t_init = [ms for kind, ms in prof if kind == 2]
     roofline = None
@@ -293,6 +297,7 @@ def main() -> None:
             m = Pipeline(iteration=args.iters, test=True)
             m.load_state_dict(synthetic.random_state_dict(0))
             m.use_graphs = True
+            m.feature_dtype = args.feature_dtype
             pm.append(m.to(dev).eval())
             pstreams.append(torch.cuda.Stream(device=dev))
         for k in range(ns):
@@ -326,6 +331,7 @@ def main() -> None:
         ops.profile_enable(n_extra * 160 + 8, mask=0x4)
         ops.CONV_FLOP_COUNTER.update(enabled=True, flops=0.0, launches=0)
         eager_model = Pipeline(iteration=args.iters, test=True)
+        eager_model.feature_dtype = args.feature_dtype
         eager_model.load_state_dict(synthetic.random_state_dict(0))
         eager_model = eager_model.to(dev).eval()
         eager_model(*samples[0])                       # warm-up (not timed: profiling collects below)
@@ -352,12 +358,13 @@ def main() -> None:
             "metric": "depth-maps/sec (ref-views/s) at 5-view 640x512, 4 iters",
             "value": value, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.feature_dtype == "fp32" else f"f32 arithmetic, {args.feature_dtype} feature storage",
+            "data": "synthetic",
             "config": {"workload": f"BASELINE cfg 2 (= cfg 1 on 1xMI355X): 1 ref + {s_views} src views, "
                                    f"{args.width}x{args.height}, {args.iters} GRU iterations, test mode, "
                                    f"random-init weights, {args.batch} ref view(s) per step and GPU",
                        "views": args.views, "height": args.height, "width": args.width, "iterations": args.iters,
-                       "batch_per_gpu": args.batch, "streams_per_gpu": args.streams,
+                       "batch_per_gpu": args.batch, "streams_per_gpu": args.streams, "feature_dtype": args.feature_dtype,
                        "launch": "eager" if args.eager else "one hipGraph per depth map",
                        "parallelism": f"ref-view sharding x{world}, no collective",
                        "algorithmic_MB_per_depth_map": b_map / 1e6},

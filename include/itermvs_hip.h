@@ -42,8 +42,18 @@ typedef enum itermvs_status {
     ITERMVS_ERR_VIEWS = -4,       /* S < 1 or S > ITERMVS_MAX_SRC                 */
     ITERMVS_ERR_ALIGN = -5,       /* pointer / stride not aligned for vector path */
     ITERMVS_ERR_LAYOUT = -6,      /* fused kernels need channels-last features    */
-    ITERMVS_ERR_LAUNCH = -7       /* hipLaunchKernel failed (see hipGetLastError) */
+    ITERMVS_ERR_LAUNCH = -7,      /* hipLaunchKernel failed (see hipGetLastError) */
+    ITERMVS_ERR_DTYPE = -8        /* feature storage type not supported by this entry point */
 } itermvs_status;
+
+/* Storage type of FEATURE maps (the pyramids the correlation kernels gather from).  Arithmetic is always fp32: 16-bit
+ * storage halves the gathered bytes (BASELINE cfg 4 "bf16", cfg 5 "fp16"); coordinates, depths, view weights, correlations
+ * and every other tensor stay fp32. */
+typedef enum itermvs_dtype {
+    ITERMVS_F32 = 0,
+    ITERMVS_F16 = 1,              /* IEEE binary16 */
+    ITERMVS_BF16 = 2              /* bfloat16      */
+} itermvs_dtype;
 
 /* library / ABI identification */
 int itermvs_version(void);
@@ -52,19 +62,20 @@ const char* itermvs_error_string(int status);
 /* A 4-D feature map addressed with ELEMENT strides, so NCHW and channels-last (NHWC) views
  * of torch tensors are both accepted.  The fused kernels require sc == 1 (channels-last). */
 typedef struct itermvs_fmap {
-    const float* data;
+    const void* data;         /* elements of `dtype` */
     int64_t sb, sc, sy, sx;   /* strides of batch, channel, row, column (elements) */
     int32_t C, H, W;
-    int32_t _pad;
+    int32_t dtype;            /* itermvs_dtype; 16-bit storage is accepted by the fused correlation entry points and
+                                 itermvs_ref_quarter, everything else takes ITERMVS_F32 */
 } itermvs_fmap;
 
 /* The S source-view feature maps of one pyramid level: per-view base pointers sharing one
  * set of element strides (views of a [B,V,...] tensor or separately allocated maps). */
 typedef struct itermvs_level_src {
-    const float* view[ITERMVS_MAX_SRC];
+    const void* view[ITERMVS_MAX_SRC];   /* elements of `dtype` */
     int64_t sb, sc, sy, sx;
     int32_t C, H, W;
-    int32_t _pad;
+    int32_t dtype;                       /* itermvs_dtype (all levels of one call share it) */
 } itermvs_level_src;
 
 /* ------------------------------------------------------------------------------------------
@@ -299,7 +310,8 @@ int itermvs_bilinear_up2(const float* x, int32_t B, int32_t C, int32_t H, int32_
  *   in the epilogue (matrix-core formats only, Hout and Wout even).
  * `out_layout` 0: `out` is [Cout,H,W] planes per batch item (batch stride out_sn); 1: `out` is a dense
  *   channels-last [N,H,W,Cout] tensor (the layout the correlation kernels read; act 0, no `add`,
- *   Cout % 4 == 0, matrix-core formats only).
+ *   Cout % 4 == 0, matrix-core formats only); 2 / 3: the same in fp16 / bf16 storage (round to nearest even of the
+ *   fp32 result; `out` points to 16-bit elements, out_sn counts them).
  * `out2` (optional) receives a second, contiguous [N,Cout,H,W] copy of the result.
  * `split_cout` > 0 (matrix-core formats, multiple of 16): output channels [split_cout, Cout) form a SECOND
  *   result with its own activation `act_b` and destination `out_b` (planes, batch stride out_b_sn, channel

@@ -13,6 +13,7 @@ from typing import Optional
 MAX_SRC = 16
 MAX_HYP = 8
 GROUPS = 8
+F32, F16, BF16 = 0, 1, 2      # itermvs_dtype: storage type of feature maps
 ABI_VERSION = 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -24,13 +25,13 @@ c_float_p = C.POINTER(C.c_float)
 class FMap(C.Structure):
     """itermvs_fmap"""
     _fields_ = [("data", C.c_void_p), ("sb", C.c_int64), ("sc", C.c_int64), ("sy", C.c_int64),
-                ("sx", C.c_int64), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("_pad", C.c_int32)]
+                ("sx", C.c_int64), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
 
 
 class LevelSrc(C.Structure):
     """itermvs_level_src"""
     _fields_ = [("view", C.c_void_p * MAX_SRC), ("sb", C.c_int64), ("sc", C.c_int64), ("sy", C.c_int64),
-                ("sx", C.c_int64), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("_pad", C.c_int32)]
+                ("sx", C.c_int64), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
 
 
 class CorrIterParams(C.Structure):

@@ -17,6 +17,7 @@ extern "C" const char* itermvs_error_string(int status) {
         case ITERMVS_ERR_ALIGN: return "pointer or stride not aligned for the vector path (16 bytes)";
         case ITERMVS_ERR_LAYOUT: return "fused kernels need channels-last feature maps (channel stride 1)";
         case ITERMVS_ERR_LAUNCH: return "HIP kernel launch failed";
+        case ITERMVS_ERR_DTYPE: return "feature storage type not supported by this entry point";
         default: return "unknown itermvs status";
     }
 }

@@ -147,14 +147,14 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     ITERMVS_RETURN_IF(p->act == 5 && !p->aux2, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->act >= 2 && p->add, ITERMVS_ERR_DIMS);   // residual add only with none / relu
     ITERMVS_RETURN_IF(p->add_mode < 0 || p->add_mode > 1, ITERMVS_ERR_DIMS);
-    ITERMVS_RETURN_IF(p->out_layout < 0 || p->out_layout > 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(p->out_layout < 0 || p->out_layout > 3, ITERMVS_ERR_DIMS);
     if (p->split_cout != 0) {
         ITERMVS_RETURN_IF(p->weight_format != 2 || p->transposed || p->out_layout != 0 || p->add || p->out2, ITERMVS_ERR_DIMS);
         ITERMVS_RETURN_IF(p->split_cout < 16 || p->split_cout >= p->Cout || (p->split_cout & 15), ITERMVS_ERR_DIMS);
         ITERMVS_RETURN_IF(!p->out_b || p->act_b < 0 || p->act_b > 4 || p->act > 4, ITERMVS_ERR_DIMS);
         ITERMVS_RETURN_IF(p->act_b == 4 && !p->aux1, ITERMVS_ERR_NULL);
     }
-    ITERMVS_RETURN_IF(p->out_layout == 1 && (p->weight_format == 0 || p->transposed || p->act != 0 || p->add || (p->Cout & 3)),
+    ITERMVS_RETURN_IF(p->out_layout >= 1 && (p->weight_format == 0 || p->transposed || p->act != 0 || p->add || (p->Cout & 3)),
                       ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(p->add_mode == 1 && (!p->add || p->weight_format == 0 || p->transposed || p->act != 0), ITERMVS_ERR_DIMS);
     ConvArgs a;

@@ -38,9 +38,22 @@ struct EpilogueArgs {
     const float* aux1;
     const float* aux2;
     int Cout, P, act;
-    int out_nhwc;               // `out` is channels-last [P][Cout] (per batch item) instead of [Cout][P]
+    int out_nhwc;               // != 0: `out` is channels-last [P][Cout] (per batch item) instead of [Cout][P];
+                                // 1 fp32, 2 fp16, 3 bf16 storage (itermvs_conv_params.out_layout)
     int add_mode, Hout, Wout;   // add_mode 1: `add` is the half-resolution tensor, up-sampled x2 (bilinear) here
 };
+
+// `out` advanced by `elems` ELEMENTS of the output's storage type
+__device__ __forceinline__ float* epi_out_base(float* out, int64_t elems, int out_nhwc) {
+    return out_nhwc >= 2 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(out) + elems) : out + elems;
+}
+// fp32 -> 16-bit storage, round to nearest even (what torch's .half() / .bfloat16() do)
+__device__ __forceinline__ uint32_t epi_to_f16(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v); }
+__device__ __forceinline__ uint32_t epi_to_bf16(float v) {
+    const uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -177,11 +190,29 @@ __device__ __forceinline__ void conv_epilogue_nhwc(const EpilogueArgs& e, const 
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         if (pix_off[nb] == kEpiOob) continue;
-        float* __restrict__ row = e.out + (size_t)(pix_off[nb] >> 2) * (size_t)e.Cout;
+        if (e.out_nhwc == 1) {
+            float* __restrict__ row = e.out + (size_t)(pix_off[nb] >> 2) * (size_t)e.Cout;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const int co = m0 + mb * 16 + q * 4;
-            if (co < e.Cout) *reinterpret_cast<f32x4*>(row + co) = acc[mb][nb];
+            for (int mb = 0; mb < MB; ++mb) {
+                const int co = m0 + mb * 16 + q * 4;
+                if (co < e.Cout) *reinterpret_cast<f32x4*>(row + co) = acc[mb][nb];
+            }
+        } else {   // 16-bit storage: the lane's four channels are 8 contiguous bytes
+            uint16_t* __restrict__ row = reinterpret_cast<uint16_t*>(e.out) + (size_t)(pix_off[nb] >> 2) * (size_t)e.Cout;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int co = m0 + mb * 16 + q * 4;
+                const f32x4 v = acc[mb][nb];
+                uint2 pk;
+                if (e.out_nhwc == 2) {
+                    pk.x = epi_to_f16(v[0]) | (epi_to_f16(v[1]) << 16);
+                    pk.y = epi_to_f16(v[2]) | (epi_to_f16(v[3]) << 16);
+                } else {
+                    pk.x = epi_to_bf16(v[0]) | (epi_to_bf16(v[1]) << 16);
+                    pk.y = epi_to_bf16(v[2]) | (epi_to_bf16(v[3]) << 16);
+                }
+                if (co < e.Cout) *reinterpret_cast<uint2*>(row + co) = pk;
+            }
         }
     }
     if (e.out2) {

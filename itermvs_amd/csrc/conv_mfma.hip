@@ -40,7 +40,7 @@ struct MfmaArgs {
 
 __device__ __forceinline__ EpilogueArgs make_epilogue(const MfmaArgs& a, int n, int P) {
     EpilogueArgs e;
-    e.out = a.out + (int64_t)n * a.out_sn;
+    e.out = epi_out_base(a.out, (int64_t)n * a.out_sn, a.out_nhwc);
     e.out2 = a.out2 ? a.out2 + (int64_t)n * a.Cout * P : nullptr;
     e.add = a.add ? a.add + (int64_t)n * a.add_sn : nullptr;
     e.aux1 = a.aux1 ? a.aux1 + (int64_t)n * a.aux1_sn : nullptr;

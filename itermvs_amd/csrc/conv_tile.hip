@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
             px[nb] = ox;
         }
         EpilogueArgs e;
-        e.out = a.out + (int64_t)cur.n * a.out_sn;
+        e.out = epi_out_base(a.out, (int64_t)cur.n * a.out_sn, a.out_nhwc);
         e.out2 = a.out2 ? a.out2 + (int64_t)cur.n * a.Cout * P : nullptr;
         e.add = a.add ? a.add + (int64_t)cur.n * a.add_sn : nullptr;
         e.aux1 = a.aux1 ? a.aux1 + (int64_t)cur.n * a.aux1_sn : nullptr;

@@ -21,7 +21,7 @@ namespace itermvs {
 // ---------------------------------------------------------------------------------------------
 // iteration branch
 // ---------------------------------------------------------------------------------------------
-template <int CPG, int TILE>
+template <int CPG, int TILE, int FT>
 __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLevel& L, int lvl, float* __restrict__ lds) {
     using K = Chunk<CPG>;
     constexpr int LS = TILE + 1;  // padded LDS row: the transposed writes hit distinct banks
@@ -84,7 +84,7 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
             for (int k = 0; k < nb; ++k) {
                 const Footprint tp = shfl_footprint(mine, gbase + k);
                 float corr[K::NG];
-                chunk_corr<CPG>(L.src[s0 + k] + (int64_t)b * L.sb, joff, tp, refv, corr);
+                chunk_corr<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), joff, tp, refv, corr);
                 const float wv = a.view_w[((size_t)b * a.S + s0 + k) * P + p];
 #pragma unroll
                 for (int q = 0; q < K::NG; ++q) acc[q] = acc[q] + corr[q] * wv;  // itermvs.py:115
@@ -102,15 +102,15 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
     }
 }
 
-template <int TILE>
+template <int TILE, int FT>
 __global__ void __launch_bounds__(kThreads) corr_iter_kernel(const IterArgs a) {
     __shared__ float lds[ITERMVS_MAX_HYP * ITERMVS_GROUPS * (TILE + 1)];
     const int lvl = blockIdx.y;
     const IterLevel& L = a.lv[lvl];
     switch (L.C) {
-        case 16: corr_iter_level<2, TILE>(a, L, lvl, lds); break;
-        case 32: corr_iter_level<4, TILE>(a, L, lvl, lds); break;
-        default: corr_iter_level<6, TILE>(a, L, lvl, lds); break;
+        case 16: corr_iter_level<2, TILE, FT>(a, L, lvl, lds); break;
+        case 32: corr_iter_level<4, TILE, FT>(a, L, lvl, lds); break;
+        default: corr_iter_level<6, TILE, FT>(a, L, lvl, lds); break;
     }
 }
 
@@ -325,7 +325,7 @@ struct InitArgs {
     int B, S, H, W, N, C, H1, W1, NB;  // NB = hypotheses per block
 };
 
-template <int CPG, int TILE>
+template <int CPG, int TILE, int FT>
 __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restrict__ lds) {
     using K = Chunk<CPG>;
     constexpr int LS = TILE + 1;
@@ -345,7 +345,7 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
     const WarpRcp rc = make_rcp(g);
     const float inv_min = a.inv_min[b], inv_max = a.inv_max[b];
     const float* m = a.proj + ((size_t)b * a.S + s) * 12;
-    const float* fsrc = a.src[s] + (int64_t)b * a.sb;
+    const float* fsrc = feat_base<FT>(a.src[s], (int64_t)b * a.sb);
     const uint32_t sy = (uint32_t)a.sy, sx = (uint32_t)a.sx;
     const int lane = threadIdx.x & 63;
 
@@ -361,7 +361,7 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
         float refv[K::VEC];
 #pragma unroll
         for (int c = 0; c < K::VEC; ++c)
-            refv[c] = a.ref.data[b * a.ref.sb + chunk_channel<K::VEC>(j, c) * a.ref.sc + y * a.ref.sy + x * a.ref.sx];
+            refv[c] = ld_feat<FT>((const float*)a.ref.data, b * a.ref.sb + chunk_channel<K::VEC>(j, c) * a.ref.sc + y * a.ref.sy + x * a.ref.sx);
         // lane j projects hypothesis grp*LPT + j once; the group then walks its LPT hypotheses and
         // every lane reads the footprint of hypothesis k from lane k (wavefront shuffles)
         const int nl_mine = grp * K::LPT + j;
@@ -386,7 +386,7 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
         for (int k = 0; k < cnt; ++k) {
             const Footprint tp = shfl_footprint(mine, gbase + k);
             float corr[K::NG];
-            chunk_corr<CPG>(fsrc, joff, tp, refv, corr);
+            chunk_corr<CPG, FT>(fsrc, joff, tp, refv, corr);
             const int nl = grp * K::LPT + k;
 #pragma unroll
             for (int q = 0; q < K::NG; ++q) lds[(nl * ITERMVS_GROUPS + j * K::NG + q) * LS + px] = corr[q];
@@ -403,13 +403,13 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
 
 constexpr int kInitNB = 8;  // hypotheses per block
 
-template <int TILE>
+template <int TILE, int FT>
 __global__ void __launch_bounds__(kThreads) corr_init_kernel(const InitArgs a) {
     __shared__ float lds[kInitNB * ITERMVS_GROUPS * (TILE + 1)];
     switch (a.C) {
-        case 16: corr_init_body<2, TILE>(a, lds); break;
-        case 32: corr_init_body<4, TILE>(a, lds); break;
-        default: corr_init_body<6, TILE>(a, lds); break;
+        case 16: corr_init_body<2, TILE, FT>(a, lds); break;
+        case 32: corr_init_body<4, TILE, FT>(a, lds); break;
+        default: corr_init_body<6, TILE, FT>(a, lds); break;
     }
 }
 
@@ -538,7 +538,7 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
     int coff = 0;
     for (int l = 0; l < 3; ++l) {
         IterLevel& L = a.lv[l];
-        for (int v = 0; v < ITERMVS_MAX_SRC; ++v) L.src[v] = p->src[l].view[v < p->S ? v : 0];
+        for (int v = 0; v < ITERMVS_MAX_SRC; ++v) L.src[v] = (const float*)p->src[l].view[v < p->S ? v : 0];
         L.sb = p->src[l].sb; L.sy = p->src[l].sy; L.sx = p->src[l].sx;
         L.depth = p->depth[l];
         L.out = p->out[l];
@@ -562,12 +562,19 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
         narrow = default_impl() / 10;
     }
     ITERMVS_RETURN_IF(variant < 1 || variant > 3 || narrow < 0 || narrow > 2, ITERMVS_ERR_DIMS);
+    const int dtype = p->src[0].dtype;
+    ITERMVS_RETURN_IF(p->src[1].dtype != dtype || p->src[2].dtype != dtype, ITERMVS_ERR_DTYPE);
+    if (dtype != ITERMVS_F32) variant = 1;   // 16-bit feature storage: the in-lane form
     itermvs_profile_begin(1, (hipStream_t)stream);
     if (variant == 1) {
         constexpr int TILE = 32;
         const int P = p->H * p->W;
         const dim3 grid((((P + TILE - 1) / TILE + 7) / 8) * 8, 3, p->B);
-        hipLaunchKernelGGL((corr_iter_kernel<TILE>), grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+        switch (dtype) {
+            case ITERMVS_F16: hipLaunchKernelGGL((corr_iter_kernel<TILE, ITERMVS_F16>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
+            case ITERMVS_BF16: hipLaunchKernelGGL((corr_iter_kernel<TILE, ITERMVS_BF16>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
+            default: hipLaunchKernelGGL((corr_iter_kernel<TILE, ITERMVS_F32>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
+        }
     } else {
         const int tw_log2 = 5 - narrow, tw = 1 << tw_log2, th = kVwTile / tw;
         const int tiles = ((p->W + tw - 1) / tw) * ((p->H + th - 1) / th);
@@ -593,7 +600,7 @@ extern "C" int itermvs_corr_init(const itermvs_corr_init_params* p, void* stream
     if (rc) return rc;
     ITERMVS_RETURN_IF(p->ref.C != p->src.C || p->ref.H != p->H || p->ref.W != p->W, ITERMVS_ERR_DIMS);
     InitArgs a;
-    for (int v = 0; v < ITERMVS_MAX_SRC; ++v) a.src[v] = p->src.view[v < p->S ? v : 0];
+    for (int v = 0; v < ITERMVS_MAX_SRC; ++v) a.src[v] = (const float*)p->src.view[v < p->S ? v : 0];
     a.sb = p->src.sb; a.sy = p->src.sy; a.sx = p->src.sx;
     a.ref = p->ref; a.proj = p->proj; a.depth = p->depth;
     a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max; a.out = p->out;
@@ -603,8 +610,13 @@ extern "C" int itermvs_corr_init(const itermvs_corr_init_params* p, void* stream
     const int P = p->H * p->W;
     const int nblocks = (p->N + kInitNB - 1) / kInitNB;
     itermvs_profile_begin(2, (hipStream_t)stream);
-    hipLaunchKernelGGL(corr_init_kernel<TILE>, dim3((((P + TILE - 1) / TILE + 7) / 8) * 8, p->S * nblocks, p->B), dim3(kThreads), 0,
-                       (hipStream_t)stream, a);
+    const dim3 grid((((P + TILE - 1) / TILE + 7) / 8) * 8, p->S * nblocks, p->B);
+    ITERMVS_RETURN_IF(p->ref.dtype != p->src.dtype, ITERMVS_ERR_DTYPE);
+    switch (p->src.dtype) {
+        case ITERMVS_F16: hipLaunchKernelGGL((corr_init_kernel<TILE, ITERMVS_F16>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
+        case ITERMVS_BF16: hipLaunchKernelGGL((corr_init_kernel<TILE, ITERMVS_BF16>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
+        default: hipLaunchKernelGGL((corr_init_kernel<TILE, ITERMVS_F32>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
+    }
     itermvs_profile_end(2, (hipStream_t)stream);
     return itermvs_launch_status();
 }

@@ -49,7 +49,7 @@ struct BwdArgs {
 constexpr int kBwdLdsE = 4 * ITERMVS_MAX_HYP * ITERMVS_GROUPS * (kVwTile + 1);   // staged E: vch * N * 8 rows
 constexpr int kBwdLdsFloats = kBwdLdsE + kVwTile * 49 + kVwTile;                   // + dL/dref [px][C+1] + wsum [px]
 
-template <int CPG>
+template <int CPG, int FT>
 __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel& L, float* __restrict__ lds) {
     using K = VwChunk<CPG>;
     constexpr int TILE = kVwTile, LS = TILE + 1, C = 8 * CPG, CS = C + 1;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
 #pragma unroll 1
         for (int r = wave; r < sbc * hbn * 2; r += kThreads / 64) {
             const int pb = r & 1, hbi = (r >> 1) % hbn, v = (r >> 1) / hbn;   // wave-uniform
-            const float* fb = L.src[s0 + v] + (int64_t)b * L.sb;
+            const float* fb = feat_base<FT>(L.src[s0 + v], (int64_t)b * L.sb);
             float* gb = L.gsrc[s0 + v] + (int64_t)b * L.sb;
             const float* m = proj + (s0 + v) * 12;
             const int px = pb * 16 + (lane >> 2);
@@ -112,7 +112,10 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
             if (p < P) {   // whole quads drop out together
                 const int y = p / a.W, x = p - y * a.W;
                 float refv[K::VEC];
-                load_vec<K::VEC>(L.ref + (int64_t)b * L.rsb + (int64_t)y * L.rsy + (int64_t)x * L.rsx + j * 4, refv);
+                // the reference features: the fp32 ref_q pack (iteration) or the level-3 features themselves (initialisation)
+                const int64_t roff = (int64_t)b * L.rsb + (int64_t)y * L.rsy + (int64_t)x * L.rsx + j * 4;
+                if (a.init) load_feat<K::VEC, FT>(feat_base<FT>(L.ref, roff), 0u, refv);
+                else load_vec<K::VEC>(L.ref + roff, refv);
                 float rx, ry, rz;
                 ray_dir(m, (float)x * g.xr, (float)y * g.yr, rx, ry, rz);
                 const int hb = hbi * 4;
@@ -145,10 +148,10 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
                         const uint32_t q10 = quad_bcast(o10, u) + joff, q11 = quad_bcast(o11, u) + joff;
                         const float nw = quad_bcast(f.nw, u), ne = quad_bcast(f.ne, u), sw = quad_bcast(f.sw, u), se = quad_bcast(f.se, u);
                         TapData<K::VEC> t;
-                        load_vec<K::VEC>(fb + q00, t.v00);
-                        load_vec<K::VEC>(fb + q01, t.v01);
-                        load_vec<K::VEC>(fb + q10, t.v10);
-                        load_vec<K::VEC>(fb + q11, t.v11);
+                        load_feat<K::VEC, FT>(fb, q00, t.v00);
+                        load_feat<K::VEC, FT>(fb, q01, t.v01);
+                        load_feat<K::VEC, FT>(fb, q10, t.v10);
+                        load_feat<K::VEC, FT>(fb, q11, t.v11);
                         const float* __restrict__ er = e_lds + (v * rows + (hb + u) * ITERMVS_GROUPS) * LS + px;
 #pragma unroll
                         for (int c = 0; c < K::VEC; ++c) {
@@ -183,13 +186,14 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
     }
 }
 
+template <int FT>
 __global__ void __launch_bounds__(kThreads) corr_bwd_kernel(const BwdArgs a) {
     __shared__ float lds[kBwdLdsFloats];
     const BwdLevel& L = a.lv[blockIdx.y];
     switch (L.C) {
-        case 16: corr_bwd_level<2>(a, L, lds); break;
-        case 32: corr_bwd_level<4>(a, L, lds); break;
-        default: corr_bwd_level<6>(a, L, lds); break;
+        case 16: corr_bwd_level<2, FT>(a, L, lds); break;
+        case 32: corr_bwd_level<4, FT>(a, L, lds); break;
+        default: corr_bwd_level<6, FT>(a, L, lds); break;
     }
 }
 
@@ -197,11 +201,21 @@ __global__ void __launch_bounds__(kThreads) corr_bwd_kernel(const BwdArgs a) {
 
 using namespace itermvs;
 
+static int launch_bwd(const BwdArgs& a, int dtype, dim3 grid, hipStream_t stream) {
+    switch (dtype) {
+        case ITERMVS_F32: hipLaunchKernelGGL(corr_bwd_kernel<ITERMVS_F32>, grid, dim3(kThreads), 0, stream, a); break;
+        case ITERMVS_F16: hipLaunchKernelGGL(corr_bwd_kernel<ITERMVS_F16>, grid, dim3(kThreads), 0, stream, a); break;
+        case ITERMVS_BF16: hipLaunchKernelGGL(corr_bwd_kernel<ITERMVS_BF16>, grid, dim3(kThreads), 0, stream, a); break;
+        default: return ITERMVS_ERR_DTYPE;
+    }
+    return itermvs_launch_status();
+}
+
 static int fill_level(BwdLevel& L, const itermvs_level_src& s, float* const* gsrc, int S) {
     const int rc = itermvs_check_level(s, S);
     if (rc) return rc;
     for (int v = 0; v < ITERMVS_MAX_SRC; ++v) {
-        L.src[v] = s.view[v < S ? v : 0];
+        L.src[v] = (const float*)s.view[v < S ? v : 0];
         L.gsrc[v] = gsrc[v < S ? v : 0];
         ITERMVS_RETURN_IF(!L.gsrc[v], ITERMVS_ERR_NULL);
     }
@@ -240,9 +254,8 @@ extern "C" int itermvs_corr_iter_backward(const itermvs_corr_iter_params* p, con
     a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max;
     a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.init = 0; a.vch = 4;
     const int P = p->H * p->W;
-    hipLaunchKernelGGL(corr_bwd_kernel, dim3((((P + kVwTile - 1) / kVwTile + 7) / 8) * 8, 3, p->B), dim3(kThreads), 0,
-                       (hipStream_t)stream, a);
-    return itermvs_launch_status();
+    ITERMVS_RETURN_IF(p->src[1].dtype != p->src[0].dtype || p->src[2].dtype != p->src[0].dtype, ITERMVS_ERR_DTYPE);
+    return launch_bwd(a, p->src[0].dtype, dim3((((P + kVwTile - 1) / kVwTile + 7) / 8) * 8, 3, p->B), (hipStream_t)stream);
 }
 
 extern "C" int itermvs_corr_init_backward(const itermvs_corr_init_params* p, const float* grad_out, float* const* grad_src,
@@ -259,7 +272,7 @@ extern "C" int itermvs_corr_init_backward(const itermvs_corr_init_params* p, con
     if (rc) return rc;
     L.depth = p->depth;
     L.gout = grad_out;
-    L.ref = p->ref.data;
+    L.ref = (const float*)p->ref.data;
     L.gref = grad_ref;                      // addressed with the strides of `ref`
     L.rsb = p->ref.sb; L.rsy = p->ref.sy; L.rsx = p->ref.sx;
     L.proj = p->proj;
@@ -271,7 +284,6 @@ extern "C" int itermvs_corr_init_backward(const itermvs_corr_init_params* p, con
     a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.init = 1;
     a.vch = p->N <= 8 ? 4 : (p->N <= 16 ? 2 : 1);
     const int P = p->H * p->W;
-    hipLaunchKernelGGL(corr_bwd_kernel, dim3((((P + kVwTile - 1) / kVwTile + 7) / 8) * 8, 1, p->B), dim3(kThreads), 0,
-                       (hipStream_t)stream, a);
-    return itermvs_launch_status();
+    ITERMVS_RETURN_IF(p->ref.dtype != p->src.dtype, ITERMVS_ERR_DTYPE);
+    return launch_bwd(a, p->src.dtype, dim3((((P + kVwTile - 1) / kVwTile + 7) / 8) * 8, 1, p->B), (hipStream_t)stream);
 }

@@ -38,6 +38,44 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)
     }
 }
 
+// Feature storage types (itermvs_dtype): fp32, or 16-bit storage with fp32 arithmetic.  Pointers to feature maps travel as
+// `const float*` through the argument structs; FT says how to read them.  Offsets and strides are always in ELEMENTS.
+template <int FT>
+__device__ __forceinline__ const float* feat_base(const float* p, int64_t elem_off) {
+    if constexpr (FT == ITERMVS_F32) return p + elem_off;
+    else return reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(p) + elem_off);
+}
+template <int FT>
+__device__ __forceinline__ float cvt16(uint32_t bits) {   // low 16 bits -> float
+    if constexpr (FT == ITERMVS_BF16) return __uint_as_float(bits << 16);
+    else return (float)__builtin_bit_cast(_Float16, (uint16_t)bits);
+}
+template <int FT>
+__device__ __forceinline__ float ld_feat(const float* p, int64_t idx) {
+    if constexpr (FT == ITERMVS_F32) return p[idx];
+    else return cvt16<FT>(reinterpret_cast<const uint16_t*>(p)[idx]);
+}
+// lane chunk: VEC/4 runs of 4 consecutive channels, 16 channels apart (16 bytes each in fp32, 8 bytes in 16-bit storage)
+template <int VEC, int FT>
+__device__ __forceinline__ void load_feat(const float* __restrict__ base, uint32_t off, float (&v)[VEC]) {
+    if constexpr (FT == ITERMVS_F32) {
+        load_vec<VEC>(base + off, v);
+    } else {
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + off;
+#pragma unroll
+        for (int i = 0; i < VEC / 4; ++i) {
+            const uint2 t = *reinterpret_cast<const uint2*>(p + 16 * i);
+            if constexpr (FT == ITERMVS_BF16) {
+                v[4 * i] = __uint_as_float(t.x << 16); v[4 * i + 1] = __uint_as_float(t.x & 0xffff0000u);
+                v[4 * i + 2] = __uint_as_float(t.y << 16); v[4 * i + 3] = __uint_as_float(t.y & 0xffff0000u);
+            } else {
+                v[4 * i] = cvt16<FT>(t.x); v[4 * i + 1] = cvt16<FT>(t.x >> 16);
+                v[4 * i + 2] = cvt16<FT>(t.y); v[4 * i + 3] = cvt16<FT>(t.y >> 16);
+            }
+        }
+    }
+}
+
 // v_mov_b32 dpp quad_perm: lane l of each quad reads lane ((CTRL >> 2*l) & 3) of the same quad
 template <int CTRL>
 __device__ __forceinline__ float quad_perm(float x) {
@@ -80,13 +118,13 @@ struct TapData {
 };
 
 // `fb` is wave-uniform (SGPR base), tap offsets are 32-bit element offsets (saddr + voffset loads).
-template <int VEC>
+template <int VEC, int FT>
 __device__ __forceinline__ void load_taps(const float* __restrict__ fb, uint32_t joff, const Footprint& tp, TapData<VEC>& t) {
     const uint32_t r0 = tp.r0 + joff, r1 = tp.r1 + joff;
-    load_vec<VEC>(fb + (r0 + tp.c0), t.v00);
-    load_vec<VEC>(fb + (r0 + tp.c1), t.v01);
-    load_vec<VEC>(fb + (r1 + tp.c0), t.v10);
-    load_vec<VEC>(fb + (r1 + tp.c1), t.v11);
+    load_feat<VEC, FT>(fb, r0 + tp.c0, t.v00);
+    load_feat<VEC, FT>(fb, r0 + tp.c1, t.v01);
+    load_feat<VEC, FT>(fb, r1 + tp.c0, t.v10);
+    load_feat<VEC, FT>(fb, r1 + tp.c1, t.v11);
 }
 
 // group correlation of one lane's chunk for one view: bilinear blend of the four taps, product
@@ -132,11 +170,11 @@ __device__ __forceinline__ void blend_corr(const TapData<Chunk<CPG>::VEC>& t, co
     }
 }
 
-template <int CPG>
+template <int CPG, int FT>
 __device__ __forceinline__ void chunk_corr(const float* __restrict__ fb, uint32_t joff, const Footprint& tp,
                                            const float (&refv)[Chunk<CPG>::VEC], float (&corr)[Chunk<CPG>::NG]) {
     TapData<Chunk<CPG>::VEC> t;
-    load_taps<Chunk<CPG>::VEC>(fb, joff, tp, t);
+    load_taps<Chunk<CPG>::VEC, FT>(fb, joff, tp, t);
     blend_corr<CPG>(t, tp, refv, corr);
 }
 
@@ -202,6 +240,7 @@ static inline int itermvs_check_level(const itermvs_level_src& s, int S) {
     ITERMVS_RETURN_IF(s.C != 16 && s.C != 32 && s.C != 48, ITERMVS_ERR_CHANNELS);
     ITERMVS_RETURN_IF(s.H < 1 || s.W < 1, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(s.sc != 1, ITERMVS_ERR_LAYOUT);
+    ITERMVS_RETURN_IF(s.dtype < ITERMVS_F32 || s.dtype > ITERMVS_BF16, ITERMVS_ERR_DTYPE);
     ITERMVS_RETURN_IF((s.sx % 4) || (s.sy % 4) || (s.sb % 4), ITERMVS_ERR_ALIGN);
     ITERMVS_RETURN_IF(s.sx <= 0 || s.sy <= 0 || (int64_t)s.H * s.sy >= (int64_t)1 << 31, ITERMVS_ERR_DIMS);  // 32-bit tap offsets
     for (int v = 0; v < S; ++v) {

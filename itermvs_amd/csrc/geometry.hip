@@ -1,5 +1,5 @@
 // Camera composition, the plain (un-fused) warp seam and reference-feature resampling.
-#include "common.hpp"
+#include "corr_common.hpp"
 
 namespace itermvs {
 
@@ -83,7 +83,7 @@ __global__ void warp_kernel(itermvs_fmap src, const float* __restrict__ proj, co
     project(g, m, rx, ry, rz, depth[t], ix, iy, &valid);
     if (mask) mask[t] = valid ? 1 : 0;
     const Taps tp = make_taps(ix, iy, src.W, src.H);
-    const float* base = src.data + (int64_t)b * src.sb;
+    const float* base = (const float*)src.data + (int64_t)b * src.sb;
     const int64_t o00 = tp.y0 * src.sy + tp.x0 * src.sx, o01 = tp.y0 * src.sy + tp.x1 * src.sx;
     const int64_t o10 = tp.y1 * src.sy + tp.x0 * src.sx, o11 = tp.y1 * src.sy + tp.x1 * src.sx;
     const int64_t plane = (int64_t)N * H * W;
@@ -129,8 +129,9 @@ __global__ void warp_backward_kernel(const float* __restrict__ gout, const float
 // ref_quarter: out[b, y, x, 0:C1 | C1:C1+C2 | C1+C2:] on the level-2 grid   (itermvs.py:95-98)
 // thread per (b, y, x, channel quad); writes float4 (C1, C2, C3 are multiples of 4).
 // ---------------------------------------------------------------------------------------------
+template <int FT>
 __device__ __forceinline__ float ld(const itermvs_fmap& f, int b, int c, int y, int x) {
-    return f.data[b * f.sb + c * f.sc + y * f.sy + x * f.sx];
+    return ld_feat<FT>((const float*)f.data, b * f.sb + c * f.sc + y * f.sy + x * f.sx);
 }
 
 // F.interpolate(scale_factor=2, bilinear, align_corners=False) source index / weight
@@ -144,6 +145,7 @@ __device__ __forceinline__ void up2_axis(int d, int n_in, int& i0, int& i1, floa
     l0 = 1.0f - l1;
 }
 
+template <int FT>
 __global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fmap r3, int B, float* __restrict__ out) {
     const int H = r2.H, W = r2.W;
     const int CQ = r1.C + r2.C + r3.C;
@@ -160,13 +162,13 @@ __global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fma
     if (c < r1.C) {
         // x0.5 bilinear == weights 0.5/0.5 on rows 2y,2y+1 and columns 2x,2x+1
         for (int k = 0; k < 4; ++k) {
-            const float top = ld(r1, b, c + k, 2 * y, 2 * x) * 0.5f + ld(r1, b, c + k, 2 * y, 2 * x + 1) * 0.5f;
-            const float bot = ld(r1, b, c + k, 2 * y + 1, 2 * x) * 0.5f + ld(r1, b, c + k, 2 * y + 1, 2 * x + 1) * 0.5f;
+            const float top = ld<FT>(r1, b, c + k, 2 * y, 2 * x) * 0.5f + ld<FT>(r1, b, c + k, 2 * y, 2 * x + 1) * 0.5f;
+            const float bot = ld<FT>(r1, b, c + k, 2 * y + 1, 2 * x) * 0.5f + ld<FT>(r1, b, c + k, 2 * y + 1, 2 * x + 1) * 0.5f;
             v[k] = top * 0.5f + bot * 0.5f;
         }
     } else if (c < r1.C + r2.C) {
         c -= r1.C;
-        for (int k = 0; k < 4; ++k) v[k] = ld(r2, b, c + k, y, x);
+        for (int k = 0; k < 4; ++k) v[k] = ld<FT>(r2, b, c + k, y, x);
     } else {
         c -= r1.C + r2.C;
         int y0, y1, x0, x1;
@@ -174,8 +176,8 @@ __global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fma
         up2_axis(y, r3.H, y0, y1, hy0, hy1);
         up2_axis(x, r3.W, x0, x1, hx0, hx1);
         for (int k = 0; k < 4; ++k) {
-            const float top = ld(r3, b, c + k, y0, x0) * hx0 + ld(r3, b, c + k, y0, x1) * hx1;
-            const float bot = ld(r3, b, c + k, y1, x0) * hx0 + ld(r3, b, c + k, y1, x1) * hx1;
+            const float top = ld<FT>(r3, b, c + k, y0, x0) * hx0 + ld<FT>(r3, b, c + k, y0, x1) * hx1;
+            const float bot = ld<FT>(r3, b, c + k, y1, x0) * hx0 + ld<FT>(r3, b, c + k, y1, x1) * hx1;
             v[k] = top * hy0 + bot * hy1;
         }
     }
@@ -202,6 +204,7 @@ extern "C" int itermvs_compose_proj(const float* mats, int32_t n_sets, int32_t V
 
 extern "C" int itermvs_warp(const itermvs_fmap* src, const float* proj, const float* depth, int32_t B, int32_t N,
                             int32_t H, int32_t W, float* out, uint8_t* mask, void* stream) {
+    ITERMVS_RETURN_IF(src && src->dtype != ITERMVS_F32, ITERMVS_ERR_DTYPE);
     ITERMVS_RETURN_IF(!src || !src->data || !proj || !depth || !out, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(B < 1 || N < 1 || H < 1 || W < 1 || src->C < 1 || src->H < 1 || src->W < 1, ITERMVS_ERR_DIMS);
     const int64_t total = (int64_t)B * N * H * W;
@@ -230,7 +233,13 @@ extern "C" int itermvs_ref_quarter(const itermvs_fmap* r1, const itermvs_fmap* r
     ITERMVS_RETURN_IF((r1->C % 4) || (r2->C % 4) || (r3->C % 4), ITERMVS_ERR_CHANNELS);
     ITERMVS_RETURN_IF(((uintptr_t)out) % 16, ITERMVS_ERR_ALIGN);
     const int64_t total = (int64_t)B * r2->H * r2->W * ((r1->C + r2->C + r3->C) / 4);
-    hipLaunchKernelGGL(ref_quarter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *r1,
-                       *r2, *r3, B, out);
+    ITERMVS_RETURN_IF(r1->dtype != r2->dtype || r1->dtype != r3->dtype, ITERMVS_ERR_DTYPE);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    switch (r1->dtype) {
+        case ITERMVS_F32: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F32>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out); break;
+        case ITERMVS_F16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out); break;
+        case ITERMVS_BF16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_BF16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out); break;
+        default: return ITERMVS_ERR_DTYPE;
+    }
     return itermvs_launch_status();
 }

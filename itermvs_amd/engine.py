@@ -58,7 +58,13 @@ def fold_batchnorm(w: Mapping[str, Tensor], prefix: str, eps: float = 1e-5) -> T
 class InferenceEngine:
     """Test-mode ``IterMVS.forward`` (itermvs.py:253-329) on hand-written HIP kernels."""
 
-    def __init__(self, weights: Mapping[str, Tensor], iteration: int):
+    def __init__(self, weights: Mapping[str, Tensor], iteration: int, feature_dtype: str = "fp32"):
+        """``feature_dtype``: storage type of the three feature pyramids the correlation kernels gather from -- "fp32"
+        (default, the reference's numerics), "bf16" or "fp16" (BASELINE cfg 4 / cfg 5: half the gathered bytes, fp32
+        arithmetic; the output convolutions of FeatureNet round their fp32 results to nearest even)."""
+        if feature_dtype not in ops.FEATURE_DTYPES:
+            raise ValueError(f"feature_dtype must be one of {sorted(ops.FEATURE_DTYPES)}, got {feature_dtype!r}")
+        self.feature_dtype = ops.FEATURE_DTYPES[feature_dtype]
         w = {k: v.detach() for k, v in weights.items()}
         dev = w["feature_net.conv1.conv.weight"].device
         if dev.type != "cuda":
@@ -135,7 +141,8 @@ class InferenceEngine:
         p = "feature_net."
         m, _, hh, ww = x.shape
         dev = x.device
-        cl = lambda c, s: torch.empty((m, c, hh // s, ww // s), device=dev, memory_format=torch.channels_last)
+        cl = lambda c, s: torch.empty((m, c, hh // s, ww // s), device=dev, dtype=self.feature_dtype,
+                                      memory_format=torch.channels_last)
         o1, o2, o3 = cl(16, 2), cl(32, 4), cl(48, 8)
         self.o2_planar = torch.empty((m, 32, hh // 4, ww // 4), device=dev)
         f0 = self._cbr(x, "conv1.", 1, "relu")

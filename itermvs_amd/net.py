@@ -81,6 +81,9 @@ class Pipeline(nn.Module):
         # after the launches are enqueued); the graph mode never stalls the host: call check_projection_finite() when the
         # outputs are fetched (eval.py does, per batch).  None = follow that default.
         self.check_nan = None
+        # storage type of the feature pyramids in test mode: "fp32" (reference numerics), "bf16" / "fp16" (BASELINE cfg 4 / 5:
+        # half the gathered bytes, fp32 arithmetic); set before the first forward (or call invalidate())
+        self.feature_dtype = "fp32"
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     # -- weights ----------------------------------------------------------------------------
@@ -128,7 +131,7 @@ class Pipeline(nn.Module):
         if self.test:
             from .engine import InferenceEngine
             if self._engine is None:
-                self._engine = InferenceEngine(self.weights(), self.iteration)
+                self._engine = InferenceEngine(self.weights(), self.iteration, self.feature_dtype)
             with torch.no_grad():
                 if self.use_graphs:
                     from .engine import GraphedRunner

@@ -30,29 +30,42 @@ def _dev(t: Tensor, name: str) -> Tensor:
     return t
 
 
+_FEATURE_DTYPES = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+FEATURE_DTYPES = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+def _feat(t: Tensor, name: str) -> int:
+    """a feature map (fp32, or fp16 / bf16 STORAGE -- the kernels compute in fp32) -> its itermvs_dtype"""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA/ROCm tensor - the IterMVS HIP engine has no CPU path")
+    if t.dtype not in _FEATURE_DTYPES:
+        raise RuntimeError(f"{name}: feature maps are float32, float16 or bfloat16, got {t.dtype}")
+    return _FEATURE_DTYPES[t.dtype]
+
+
 def _ptr(t: Optional[Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
 def fmap(t: Tensor, name: str = "fmap") -> FMap:
-    """Describe a [B,C,H,W] tensor (any strides) as an ``itermvs_fmap``."""
-    _dev(t, name)
+    """Describe a [B,C,H,W] tensor (any strides; fp32 or 16-bit feature storage) as an ``itermvs_fmap``."""
+    dt = _feat(t, name)
     if t.dim() != 4:
         raise RuntimeError(f"{name}: expected [B,C,H,W]")
     sb, sc, sy, sx = t.stride()
-    return FMap(t.data_ptr(), sb, sc, sy, sx, t.shape[1], t.shape[2], t.shape[3], 0)
+    return FMap(t.data_ptr(), sb, sc, sy, sx, t.shape[1], t.shape[2], t.shape[3], dt)
 
 
 def level_src(views: Sequence[Tensor], name: str = "src") -> LevelSrc:
     """S source-view maps [B,C,H1,W1] sharing shape and strides -> ``itermvs_level_src``."""
     if not 1 <= len(views) <= MAX_SRC:
         raise RuntimeError(f"{name}: need 1..{MAX_SRC} source views, got {len(views)}")
-    v0 = _dev(views[0], name)
+    v0 = views[0]
     ls = LevelSrc()
+    ls.dtype = _feat(v0, name)
     for i, v in enumerate(views):
-        _dev(v, name)
-        if v.shape != v0.shape or v.stride() != v0.stride():
-            raise RuntimeError(f"{name}: all source views must share shape and strides")
+        if _feat(v, name) != ls.dtype or v.shape != v0.shape or v.stride() != v0.stride():
+            raise RuntimeError(f"{name}: all source views must share dtype, shape and strides")
         ls.view[i] = v.data_ptr()
     ls.sb, ls.sc, ls.sy, ls.sx = v0.stride()
     ls.C, ls.H, ls.W = v0.shape[1], v0.shape[2], v0.shape[3]
@@ -214,7 +227,7 @@ def _views(feat: Tensor, b: int, v: int):
 
 
 def _need_cl(t: Tensor, name: str) -> Tensor:
-    _dev(t, name)
+    _feat(t, name)
     if not t.is_contiguous(memory_format=torch.channels_last):
         raise RuntimeError(f"{name}: expected a dense channels-last [B*V,C,H,W] tensor")
     return t
@@ -245,14 +258,15 @@ class _CorrIterFn(torch.autograd.Function):
         src = {l: _views(f, b, v)[1] for l, f in zip((1, 2, 3), feats)}
         p, nd = _corr_iter_params(src, ref_q, proj, view_w, inv_min, inv_max, nd, offsets, None)
         gouts = [g.contiguous() for g in gouts]
-        gfeat = [torch.zeros_like(f) for f in feats]              # dense channels-last like the features
+        # dense channels-last like the features, fp32 whatever their storage type (fp32 atomics)
+        gfeat = [torch.zeros_like(f, dtype=torch.float32) for f in feats]
         gref = torch.empty_like(ref_q)
         go = (C.c_void_p * 3)(*[g.data_ptr() for g in gouts])
         lv = [(C.c_void_p * (v - 1))(*[t.data_ptr() for t in _views(gf, b, v)[1]]) for gf in gfeat]
         gs = (C.POINTER(C.c_void_p) * 3)(*[C.cast(a, C.POINTER(C.c_void_p)) for a in lv])
         check(_lib.load().itermvs_corr_iter_backward(C.byref(p), C.byref(go), C.byref(gs), gref.data_ptr(), _stream()),
               "itermvs_corr_iter_backward")
-        return (gref, None, None, None, None, None, None, None, None) + tuple(gfeat)
+        return (gref, None, None, None, None, None, None, None, None) + tuple(g.to(f.dtype) for g, f in zip(gfeat, feats))
 
 
 def corr_iter_train(feats: Dict[int, Tensor], b: int, v: int, ref_q: Tensor, proj: Tensor, view_w: Tensor, inv_min: Tensor,
@@ -298,12 +312,12 @@ class _CorrInitFn(torch.autograd.Function):
         ref3, src3 = _views(f3, b, v)
         p = _corr_init_params(src3, ref3, proj, inv_min, inv_max, n, None)
         gout = gout.contiguous()
-        gf = torch.zeros_like(f3)
+        gf = torch.zeros_like(f3, dtype=torch.float32)
         gref, gsrc = _views(gf, b, v)
         ptrs = (C.c_void_p * (v - 1))(*[t.data_ptr() for t in gsrc])
         check(_lib.load().itermvs_corr_init_backward(C.byref(p), gout.data_ptr(), ptrs, gref.data_ptr(), _stream()),
               "itermvs_corr_init_backward")
-        return gf, None, None, None, None, None, None
+        return gf.to(f3.dtype), None, None, None, None, None, None
 
 
 def corr_init_train(f3: Tensor, b: int, v: int, proj: Tensor, inv_min: Tensor, inv_max: Tensor, num_samples: int = 32) -> Tensor:
@@ -648,12 +662,15 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     if out is None:
         out = torch.empty((n, cout, hout, wout), device=x.device, dtype=torch.float32,
                           memory_format=torch.channels_last if channels_last_out else torch.contiguous_format)
+    if not channels_last_out and out.dtype != torch.float32:
+        raise RuntimeError("conv2d: 16-bit storage exists for channels-last outputs only")
     p = ConvParams()
     p.inp, p.in_sn = _planes(x, "conv input")
     if channels_last_out:
         if not out.is_contiguous(memory_format=torch.channels_last):
             raise RuntimeError("conv2d: channels_last_out needs a dense channels-last `out`")
-        p.out, p.out_sn, p.out_layout = _dev(out, "conv output").data_ptr(), cout * hout * wout, 1
+        # out_layout 1 / 2 / 3 = fp32 / fp16 / bf16 storage of the feature map (rounded to nearest even from fp32)
+        p.out, p.out_sn, p.out_layout = out.data_ptr(), cout * hout * wout, 1 + _feat(out, "conv output")
     else:
         p.out, p.out_sn = _planes(out, "conv output")
     if out.shape != (n, cout, hout, wout):

@@ -201,3 +201,24 @@ def test_gru_fused_epilogues(fmt):
              out=hx[:, :32], out2=hidden)
     assert rel_err(hidden, want) <= 5e-6 and rel_err(hx[:, :32], want) <= 5e-6
     assert torch.equal(hx[:, 32:], x)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_channels_last_output_in_16bit_storage(dtype):
+    """FeatureNet's output convolutions can write the pyramid in fp16 / bf16 (out_layout 2 / 3): the fp32 result rounded to
+    nearest even, bit for bit what torch's cast gives on the fp32 channels-last output; NaN / inf survive"""
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn((3, 48, 20, 28), generator=gen).to(DEV)
+    x[0, 0, 0, 0] = 3.0e38
+    wt = torch.randn((32, 48, 3, 3), generator=gen).to(DEV) * 0.1
+    bias = torch.randn((32,), generator=gen).to(DEV)
+    pk = ops().MfmaWeight(wt)
+    o32 = torch.empty((3, 32, 20, 28), device=DEV, memory_format=torch.channels_last)
+    o16 = torch.empty((3, 32, 20, 28), device=DEV, dtype=dtype, memory_format=torch.channels_last)
+    planar = torch.empty((3, 32, 20, 28), device=DEV)
+    ops().conv2d(x, pk, bias, channels_last_out=True, out=o32)
+    ops().conv2d(x, pk, bias, channels_last_out=True, out=o16, out2=planar)
+    assert o16.dtype == dtype and torch.equal(o16, o32.to(dtype))
+    assert torch.equal(planar, o32.contiguous())                 # the planar copy stays fp32
+    with pytest.raises(RuntimeError):
+        ops().conv2d(x, pk, bias, out=torch.empty((3, 32, 20, 28), device=DEV, dtype=dtype))

@@ -257,6 +257,43 @@ def test_corr_iter_forms_agree():
         ops().corr_iter(src, ref_q, p12, vw, inv_min, inv_max, norm_depth=nd, offsets=sample_offsets(), impl=9)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_16bit_feature_storage_matches_oracle_on_the_rounded_features(dtype):
+    """BASELINE cfg 4 / cfg 5 feature storage: the correlation kernels read fp16 / bf16 pyramids and compute in fp32, so
+    on features that ARE representable in 16 bits they must agree with the fp32 oracle like the fp32 path does
+    (ref_quarter <= 1e-6, per-view and aggregated correlations <= 5e-5 * scale)."""
+    g, src, ref, p12, inv_min, inv_max = _small("dtu")
+    r16 = lambda t: t.to(dtype)                                   # round to nearest even, what the conv epilogue does
+    src16 = {l: [r16(t) for t in src[l]] for l in src}
+    ref16 = {l: r16(ref[l]) for l in ref}
+    srcr = {l: [t.float() for t in src16[l]] for l in src}        # the same values held in fp32
+    refr = {l: ref16[l].float() for l in ref}
+    rq16 = ops().ref_quarter(ref16[1], ref16[2], ref16[3])
+    rq32 = ops().ref_quarter(refr[1], refr[2], refr[3])
+    assert torch.equal(rq16, rq32)
+    vw = cu(g["init.view_weights"])
+    from itermvs_amd.engine import sample_offsets
+    nd = cu(g["iter0.nd_in"])
+    a16 = ops().corr_iter(src16, rq16, p12, vw, inv_min, inv_max, norm_depth=nd, offsets=sample_offsets())
+    a32 = ops().corr_iter(srcr, rq32, p12, vw, inv_min, inv_max, norm_depth=nd, offsets=sample_offsets(), impl=1)
+    for x, y in zip(a16, a32):
+        assert torch.equal(x, y)                                  # same arithmetic on the same values
+    c16 = ops().corr_init(src16[3], ref16[3], p12[2], inv_min, inv_max, 32)
+    c32 = ops().corr_init(srcr[3], refr[3], p12[2], inv_min, inv_max, 32)
+    assert torch.equal(c16, c32)
+    # and against the oracle (CPU, fp32) on those rounded features
+    b, v = g["feat.level3"].shape[:2]
+    f3 = torch.stack([refr[3].cpu()] + [t.cpu() for t in srcr[3]], 1)
+    depth = O.initial_depth_samples((1.0 / g["depth_min"]).view(b, 1, 1, 1), (1.0 / g["depth_max"]).view(b, 1, 1, 1), *f3.shape[-2:])
+    for sidx in range(v - 1):
+        m = torch.cat([p12[2][:, sidx].cpu().view(b, 3, 4), torch.zeros(b, 1, 4)], 1)
+        ix, iy, _ = O.warp_source_coords(m, depth, *f3.shape[-2:])
+        want = O.group_correlation(O.bilinear_gather(f3[:, sidx + 1], ix, iy), f3[:, 0]).permute(0, 2, 1, 3, 4)
+        assert maxdiff(c16[:, sidx], want) <= 5e-5 * max(1.0, float(want.abs().max()))
+    with pytest.raises(RuntimeError, match="float32|storage type"):      # the plain warp seam is fp32 only
+        ops().warp(src16[1][0], p12[0][:, 0], cu(g["iter0.samples.level1"]))
+
+
 def _bwd_case(b, v, h, w, seed):
     """random pyramid + cameras + depth for the gradient tests: CPU leaves (requires_grad) and the shared geometry"""
     gen = torch.Generator().manual_seed(seed)
@@ -283,13 +320,16 @@ def _oracle_corr(feat, ref, p12_l, depth, b, v, size):
     return out
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("b,v", [(1, 3), (2, 6)])
-def test_corr_iter_backward_matches_autograd(b, v):
+def test_corr_iter_backward_matches_autograd(b, v, dtype):
     """itermvs_corr_iter_backward (scatter-add to the source features, gather to ref_q) vs torch autograd through the
     oracle's warp + group correlation + view-weighted mean (itermvs.py:84-120), hypotheses built from nd + offsets"""
     from itermvs_amd.engine import sample_offsets
     h, w = 24, 40
     gen, feats, sizes, chans, p12, inv_min, inv_max = _bwd_case(b, v, h, w, 7)
+    if dtype != torch.float32:                # 16-bit feature storage: both sides see the rounded values
+        feats = {l: f.detach().to(dtype).float().requires_grad_(True) for l, f in feats.items()}
     ref_q = torch.randn((b, h, w, 96), generator=gen).requires_grad_(True)
     vw = torch.rand((b, v - 1, h, w), generator=gen)
     nd = torch.rand((b, 1, h, w), generator=gen)
@@ -306,14 +346,16 @@ def test_corr_iter_backward_matches_autograd(b, v):
         loss = loss + ((acc / wsum).permute(0, 2, 1, 3, 4) * gw[l]).sum()
     loss.backward()
     # HIP
-    fg = {l: cu(feats[l].detach()).contiguous(memory_format=torch.channels_last).requires_grad_(True) for l in (1, 2, 3)}
+    fg = {l: cu(feats[l].detach()).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True) for l in (1, 2, 3)}
     rq = cu(ref_q.detach()).requires_grad_(True)
     outs = ops().corr_iter_train(fg, b, v, rq, cu(p12), cu(vw), cu(inv_min), cu(inv_max), cu(nd), sample_offsets())
     sum((o * cu(gw[l])).sum() for o, l in zip(outs, (1, 2, 3))).backward()
+    tol = 1e-4 if dtype == torch.float32 else 1e-2       # the returned gradient is rounded to the storage type
     for l in (1, 2, 3):
         g_ref = feats[l].grad
-        assert maxdiff(fg[l].grad, g_ref) <= 1e-4 * max(1.0, float(g_ref.abs().max())), l
-        assert float(fg[l].grad.view(b, v, -1)[:, 0].abs().max()) == 0.0            # the reference view of the pyramid gets none here
+        assert fg[l].grad.dtype == dtype
+        assert maxdiff(fg[l].grad, g_ref) <= tol * max(1.0, float(g_ref.abs().max())), l
+        assert float(fg[l].grad.reshape(b, v, -1)[:, 0].abs().max()) == 0.0            # the reference view of the pyramid gets none here
     assert maxdiff(rq.grad, ref_q.grad) <= 1e-4 * max(1.0, float(ref_q.grad.abs().max()))
 
 

@@ -63,18 +63,20 @@ def test_small_pipeline_every_seam(tag):
     print(f"e2e_small {tag}: " + ", ".join(f"{k}={v:.1e}" for k, v in m.items()) +
           f", flips0={flips0:.4f}, flips_last={flips:.4f}, depth median {float(drel.median()):.1e}, "
           f"depth>1e-4 {float((drel > 1e-4).float().mean()):.4f}, conf>1e-3 {conf_bad:.4f}")
-    # un-forced run: each seam carries the deviations of the seams before it (FeatureNet 5e-5 -> correlation -> softmax)
+    # un-forced run: each seam carries the deviations of the seams before it.  Bounds = ~5x what the kernels measure on
+    # the MI355X (profiles/r02/r02b_parity_report.txt: features 1.4e-6, correlations 3.5e-6 / 5.2e-6, view weights 5.6e-6,
+    # scores 4.0e-6, hidden state 1.2e-5 (seed0) / 9.4e-5 (DTU weights, tanh of larger pre-activations))
     for l in (1, 2, 3):
-        assert m[f"feat{l}"] <= 5e-5
-    assert m["corr_view"] <= 2e-4 and m["init_agg"] <= 2e-4
-    assert m["view_w"] <= 1e-3 and m["init_score"] <= 1e-3 and m["hidden0"] <= 1e-3
+        assert m[f"feat{l}"] <= 1e-5
+    assert m["corr_view"] <= 2e-5 and m["init_agg"] <= 3e-5
+    assert m["view_w"] <= 5e-5 and m["init_score"] <= 3e-5 and m["hidden0"] <= (1e-4 if tag == "seed0" else 5e-4)
     lim = 0.02 if tag == "seed0" else 0.10
     assert flips0 <= lim, flips0
     assert flips <= 2 * lim, flips
     assert float(drel.median()) <= 1e-5
     assert float((drel > 1e-4).float().mean()) <= 2 * lim, float(drel.max())
     assert conf.shape == cr.shape and c_lo.shape == c_lo_ref.shape
-    assert m["conf_lo_median"] <= 1e-4 and m["conf_up_median"] <= 1e-4 and conf_bad <= 2 * lim
+    assert m["conf_lo_median"] <= 2e-5 and m["conf_up_median"] <= 2e-5 and conf_bad <= 2 * lim
 
 
 def _rates(a, b):
@@ -227,6 +229,32 @@ def test_nan_projection_raises_like_the_reference_and_clears():
     with pytest.raises(AssertionError, match="nan in proj"):
         graphed.check_projection_finite()
     graphed.check_projection_finite()
+
+
+@pytest.mark.parametrize("fdt", ["bf16", "fp16"])
+def test_16bit_feature_storage_end_to_end(fdt):
+    """BASELINE cfg 4 (bf16) / cfg 5 (fp16) feature storage at the cfg-1 shape, photo-consistent scene, DTU weights:
+    the stated tolerance against the fp32 engine.  Storage rounding perturbs the features by 2^-9 (bf16) / 2^-12 (fp16)
+    relative, the correlations by about as much, and a perturbation of that size flips arg-max bins on part of the
+    pixels (the chaos of DESIGN.md section 2); what must hold: same reconstruction quality, median deviation small."""
+    from itermvs_amd import synthetic
+    s = synthetic.make_scene_sample(num_views=5, height=512, width=640, seed=0)
+    ref_model = make_model("dtu", 4)
+    m16 = make_model("dtu", 4)
+    m16.feature_dtype = fdt
+    d32 = ref_model(*to_dev(s))["depths_upsampled"]
+    out = m16(*to_dev(s))
+    d16, c16 = out["depths_upsampled"], out["confidence_upsampled"]
+    assert d16.dtype == torch.float32 and c16.dtype == torch.float32
+    assert m16._engine.feature_dtype == {"bf16": torch.bfloat16, "fp16": torch.float16}[fdt]
+    rel = ((d16 - d32).abs() / d32).cpu()
+    gt = s["depth_gt"]
+    e32, e16 = float((d32.cpu() - gt).abs().median()), float((d16.cpu() - gt).abs().median())
+    print(f"feature storage {fdt}: depth vs fp32 engine median {float(rel.median()):.2e}, >1e-3 on {float((rel > 1e-3).float().mean()):.4f} "
+          f"of the pixels; median |depth - ground truth| {e16:.3f} mm (fp32: {e32:.3f} mm)")
+    assert float(rel.median()) <= (1e-3 if fdt == "bf16" else 2e-4)
+    assert float((rel > 1e-2).float().mean()) <= 0.05
+    assert abs(e16 - e32) <= 0.1 and e16 < 1.0               # reconstructs the plane as well as fp32 does
 
 
 def test_graph_replay_equals_eager():
