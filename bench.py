@@ -108,25 +108,36 @@ def transfers_leg(args, dev, samples, world):
     ev_done = [torch.cuda.Event() for _ in range(2)]
     ev_out = [torch.cuda.Event() for _ in range(2)]
     started = [False, False]
+    trace = [] if os.environ.get("ITERMVS_TRACE_TRANSFERS") else None     # (step, 4 timing events): printed to stderr
 
     def step(i: int) -> None:
         k = i % 2
         r = runners[k]
         h_img, h_proj, h_min, h_max = host_in[i % len(host_in)]
+        tev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if trace is not None else None
         with torch.cuda.stream(s_in):
             if started[k]:
                 s_in.wait_event(ev_done[k])                 # replay i-2 has consumed these static inputs
+            if tev:
+                tev[0].record(s_in)
             r.imgs.copy_(h_img, non_blocking=True)
             r.proj_stack.copy_(h_proj, non_blocking=True)
             r.depth_min.copy_(h_min, non_blocking=True)
             r.depth_max.copy_(h_max, non_blocking=True)
             ev_in[k].record(s_in)
+            if tev:
+                tev[1].record(s_in)
         with torch.cuda.stream(s_cmp):
             s_cmp.wait_event(ev_in[k])
             if started[k]:
                 s_cmp.wait_event(ev_out[k])                 # outputs of replay i-2 are on the host
+            if tev:
+                tev[2].record(s_cmp)
             r(r.imgs, r.projs, r.depth_min, r.depth_max)    # static inputs: no staging copies, one graph launch
             ev_done[k].record(s_cmp)
+            if tev:
+                tev[3].record(s_cmp)
+                trace.append((i, tev))
         with torch.cuda.stream(s_out):
             s_out.wait_event(ev_done[k])
             for h, d in zip(host_out[k], r.out):
@@ -136,6 +147,11 @@ def transfers_leg(args, dev, samples, world):
 
     elapsed = shard.timed_steps(step, args.steps, max(args.warmup, 4))
     eng.check_projection_finite()
+    if trace:
+        base = trace[-8][1][0]
+        for i, tev in trace[-8:]:
+            print("transfers step %d: h2d %.3f..%.3f ms, replay %.3f..%.3f ms" % ((i,) + tuple(base.elapsed_time(e) for e in tev)),
+                  file=sys.stderr)
     h2d = sum(t.numel() * t.element_size() for t in host_in[0])
     d2h = sum(t.numel() * t.element_size() for t in host_out[0])
     return {"value": world * args.steps * args.batch / elapsed, "unit": "depth-maps/s", "ms_per_step": elapsed / args.steps * 1e3,

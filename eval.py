@@ -38,7 +38,9 @@ from itermvs_amd.net import Pipeline  # noqa: E402
 def build_parser() -> argparse.ArgumentParser:
     p = argparse.ArgumentParser(description="Predict depth maps (MI355X engine)")
     p.add_argument("--model", default="IterMVS")
-    p.add_argument("--dataset", default="synthetic", help="'synthetic' or module:Class of an MVSDataset")
+    p.add_argument("--dataset", default="synthetic",
+                   help="'synthetic', 'folder' (scan folders under --testpath: pair.txt, cams_1/, images/; decode on the host, "
+                        "normalise / resize / pyramid on the GPU, prefetched) or module:Class of an MVSDataset")
     p.add_argument("--testpath")
     p.add_argument("--testlist")
     p.add_argument("--split", default="intermediate")
@@ -74,9 +76,20 @@ class SyntheticMVSDataset(torch.utils.data.Dataset):
                 "filename": "scan_synthetic/{}/" + "{:0>8}".format(idx) + "{}"}
 
 
+def scan_list(args):
+    """--testlist (one scan folder name per line, eval.py:47 of the reference) or every folder of --testpath with a pair.txt"""
+    if args.testlist:
+        with open(args.testlist) as f:
+            return [line.rstrip() for line in f if line.strip()]
+    return sorted(d for d in os.listdir(args.testpath) if os.path.isfile(os.path.join(args.testpath, d, "pair.txt")))
+
+
 def make_dataset(args):
     if args.dataset == "synthetic":
         return SyntheticMVSDataset(args.n_views, args.img_wh, args.num_samples)
+    if args.dataset == "folder":
+        from itermvs_amd.scan_dataset import ScanFolderDataset
+        return ScanFolderDataset(args.testpath, scan_list(args), args.n_views, tuple(args.img_wh))
     mod, cls = args.dataset.split(":")
     return getattr(importlib.import_module(mod), cls)(args.testpath, args.testlist, args.n_views, tuple(args.img_wh))
 
@@ -120,6 +133,8 @@ def save_depth(args) -> int:
     mine = shard.shard_indices(len(dataset), rank, world)
     model = load_model(args, dev)
     done = 0
+    if args.dataset == "folder":
+        return save_depth_folder(args, dataset, mine, model, dev)
     with torch.no_grad():
         for i in range(0, len(mine), args.batch_size):
             t0 = time.time()
@@ -135,6 +150,27 @@ def save_depth(args) -> int:
                 save_pfm(os.path.join(args.outdir, name.format("depth_est", ".pfm")), np.squeeze(d, 0))
                 save_pfm(os.path.join(args.outdir, name.format("confidence", ".pfm")), np.squeeze(c, 0))
                 done += 1
+    shard.barrier()
+    return done
+
+
+def save_depth_folder(args, dataset, mine, model, dev) -> int:
+    """the folder input side: a host thread decodes the next views while the GPU works; uint8 upload + pyramid kernel on a
+    side stream (itermvs_amd.scan_dataset.Prefetcher); one reference view per forward like the reference's batch_size 1"""
+    from itermvs_amd.scan_dataset import Prefetcher
+    done = 0
+    with torch.no_grad():
+        for n, (sample, (imgs, projs, dmin, dmax)) in enumerate(Prefetcher(dataset, mine, dev)):
+            t0 = time.time()
+            out = model(imgs, projs, dmin, dmax)
+            depth = out["depths_upsampled"].cpu().numpy()
+            conf = out["confidence_upsampled"].cpu().numpy()
+            model.check_projection_finite()
+            print("Iter {}/{}, time = {:.3f}".format(n, len(mine), time.time() - t0))
+            name = sample["filename"]
+            save_pfm(os.path.join(args.outdir, name.format("depth_est", ".pfm")), np.squeeze(depth[0], 0))
+            save_pfm(os.path.join(args.outdir, name.format("confidence", ".pfm")), np.squeeze(conf[0], 0))
+            done += 1
     shard.barrier()
     return done
 

@@ -362,6 +362,16 @@ int itermvs_fuse_depth(const float* depth_ref, const float* conf_ref, const floa
                        void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * itermvs_image_pyramid -- the input side of the path: datasets/dtu_yao_eval.py:61-74
+ * (read_img) on the GPU.  src [V,Hs,Ws,3] uint8 interleaved RGB (the decoded images of one sample, same size) ->
+ *   level0 [V,3,H,W]       = cv2.resize(2 * src / 255. - 1, (W, H), INTER_LINEAR)   (float32)
+ *   level1..3 [V,3,H>>l,W>>l] = cv2.resize(level0, ..., INTER_LINEAR)               (may be NULL: the network reads level 0 only)
+ * H and W multiples of 8 when the lower levels are requested.  cv2's algorithm is restated from its published form.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_image_pyramid(const uint8_t* src, int32_t V, int32_t Hs, int32_t Ws, int32_t H, int32_t W, float* level0,
+                          float* level1, float* level2, float* level3, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optional per-launch timing (HIP events recorded on the launch stream around the kernels of
  * itermvs_corr_iter / itermvs_corr_init).  Used by bench.py for the roofline figure.
  * itermvs_profile_enable(n) allocates n event pairs (n = 0 disables and frees);

@@ -740,6 +740,23 @@ def fuse_depth(depth_ref: Tensor, conf_ref: Tensor, depth_src: Sequence[Tensor],
     return avg, photo, geo, final, cnt
 
 
+def image_pyramid(raw: Tensor, height: int, width: int, all_levels: bool = True) -> Dict[str, Tensor]:
+    """datasets/dtu_yao_eval.py:61-74 on the GPU: raw [V,Hs,Ws,3] uint8 RGB (device) -> {'level_0': [V,3,H,W] float32 in
+    -1..1, resized like cv2.resize(INTER_LINEAR), 'level_1'..'level_3': the reference's lower pyramid levels}"""
+    if not raw.is_cuda or raw.dtype != torch.uint8 or raw.dim() != 4 or raw.shape[3] != 3:
+        raise RuntimeError("image_pyramid: expected a CUDA uint8 tensor [V,Hs,Ws,3]")
+    raw = raw.contiguous()
+    v, hs, ws, _ = raw.shape
+    out = {"level_0": torch.empty((v, 3, height, width), device=raw.device, dtype=torch.float32)}
+    if all_levels:
+        for l in (1, 2, 3):
+            out[f"level_{l}"] = torch.empty((v, 3, height >> l, width >> l), device=raw.device, dtype=torch.float32)
+    check(_lib.load().itermvs_image_pyramid(raw.data_ptr(), v, hs, ws, height, width, out["level_0"].data_ptr(),
+                                            _ptr(out.get("level_1")), _ptr(out.get("level_2")), _ptr(out.get("level_3")), _stream()),
+          "itermvs_image_pyramid")
+    return out
+
+
 _PROFILE_MASK = [0x3]
 
 

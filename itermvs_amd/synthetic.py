@@ -29,16 +29,13 @@ def _look_at_origin(center: np.ndarray) -> np.ndarray:
     return np.stack([x, y, z])
 
 
-def make_cameras(num_views: int, height: int, width: int, radius: float = 680.0,
-                 ref_shift: int = 0) -> Dict[str, np.ndarray]:
-    """V pinhole cameras on an arc around the origin: azimuth steps of 8 deg
-    alternating sign, elevation +-3 deg; DTU-like intrinsics scaled to ``width``.
-    ``ref_shift`` rotates the whole rig so different reference views differ."""
+def camera_parameters(num_views: int, height: int, width: int, radius: float = 680.0, ref_shift: int = 0):
+    """(K0 [3,3] float64 at full resolution, [extrinsic [4,4] float32 per view]) of the rig :func:`make_cameras` projects with"""
     f = 1446.1 * (width / 640.0)
     cx = width / 2.0 + 11.6 * (width / 640.0)
     cy = height / 2.0 + 9.6 * (height / 512.0)
     k0 = np.array([[f, 0, cx], [0, f, cy], [0, 0, 1]], dtype=np.float64)
-    out = {f"level_{l}": [] for l in range(4)}
+    exts = []
     for v in range(num_views):
         step = (v + 1) // 2 * (1 if v % 2 else -1)
         az = math.radians(8.0 * step + 2.5 * ref_shift)
@@ -48,7 +45,18 @@ def make_cameras(num_views: int, height: int, width: int, radius: float = 680.0,
         ext = np.eye(4)
         ext[:3, :3] = rot
         ext[:3, 3] = -rot @ c
-        ext = ext.astype(np.float32)
+        exts.append(ext.astype(np.float32))
+    return k0, exts
+
+
+def make_cameras(num_views: int, height: int, width: int, radius: float = 680.0,
+                 ref_shift: int = 0) -> Dict[str, np.ndarray]:
+    """V pinhole cameras on an arc around the origin: azimuth steps of 8 deg
+    alternating sign, elevation +-3 deg; DTU-like intrinsics scaled to ``width``.
+    ``ref_shift`` rotates the whole rig so different reference views differ."""
+    k0, exts = camera_parameters(num_views, height, width, radius, ref_shift)
+    out = {f"level_{l}": [] for l in range(4)}
+    for ext in exts:
         for l in range(4):
             k = k0.copy()
             k[:2] /= 2 ** l
