@@ -15,6 +15,8 @@
 //     lanes of a pixel with two xor-shuffles; the nine window bins go through LDS and lane q = 0 evaluates
 //     the regression with the arithmetic of prob_regress_kernel (update.hip).
 // W1 (8 KB) and W2 (64 KB) sit in LDS, shared by the four waves of a workgroup (64 pixels).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace itermvs {
@@ -339,6 +341,267 @@ __global__ void __launch_bounds__(256) head_fused_kernel(const FusedArgs a) {
     head_tail(acc1, a.w2p, a.bias2, win, wave, q, l16, live, b, live ? oy * a.W + ox : 0, a.out);
 }
 
+// ---------------------------------------------------------------------------------------------
+// itermvs_head_fused, cooperative form (the default): ONE 16-pixel tile is shared by the four waves of a workgroup.
+//
+// The per-wave form above gives every wave a whole tile (432 MFMAs): at cfg 1 that is 1280 tiles for 1024 SIMDs, so a
+// quarter of the SIMDs run two tiles back to back while the others wait -- 27 us for 6.6 us of matrix work per tile.
+// Here a persistent workgroup walks tiles (row segments of 16 pixels) and splits each layer over its four waves, one
+// wave per SIMD, so every SIMD of a CU carries the same 108 MFMAs per tile:
+//   3x3 dilated conv 32 -> 32   wave (mb0 = w & 1, ch = w >> 1): output block mb0 over input chunk ch, 9 taps x 4 steps;
+//                               the two chunk partials meet in LDS (P)
+//   1x1 32 -> 64 (+ReLU)        wave w: output block w (8 MFMAs), result to LDS (Y)
+//   1x1 64 -> 256               wave w: bins 64w .. 64w+63 (64 MFMAs)
+//   softmax / first arg-max / window regression: statistics combined over the 4 q-lanes (xor shuffles) and the 4 waves
+//                               (LDS), same arithmetic and tie rule as head_tail above
+// Every wave keeps ITS weight slices in registers for the whole launch (36 + 8 + 64 values per lane, loaded once): no
+// per-tile weight traffic at all.  The next tile's hidden-state halo (3 rows x 20 columns x 32 channels) is fetched into
+// registers while the current tile computes.
+// LDS exchange layouts are [..][q][l16][4]: a lane writes / reads one ds_*_b128 at its own (q, l16) position, because the
+// D layout of v_mfma_f32_16x16x4_f32 (channel q*4 + r, pixel l16) is exactly the B layout the next layer needs.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCoT = 2 * 4 * 3 * 20 * 4;   // staged tile: [chunk][q][row][col][s]
+constexpr int kCoP = 2 * 2 * 4 * 16 * 4;   // conv partials: [chunk][mb0][q][l16][r]
+constexpr int kCoY = 4 * 4 * 16 * 4;       // hidden layer: [mb1][q][l16][r]
+constexpr int kCoS = 4 * 16;               // one statistic per wave and pixel
+constexpr int kCoLds = kCoT + kCoP + kCoY + 6 * kCoS + kHeadWin * 16 + 16;
+
+__global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const int tiles_total) {
+    __shared__ __attribute__((aligned(16))) float smem[kCoLds];
+    float* __restrict__ T = smem;
+    float* __restrict__ Pp = T + kCoT;
+    float* __restrict__ Y = Pp + kCoP;
+    float* __restrict__ st_max = Y + kCoY;          // [wave][px]
+    float* __restrict__ st_sum = st_max + kCoS;
+    float* __restrict__ st_bv = st_sum + kCoS;
+    float* __restrict__ st_bi = st_bv + kCoS;       // (int bits)
+    float* __restrict__ st_cl = st_bi + kCoS;       // close counts (int bits)
+    float* __restrict__ st_bp = st_cl + kCoS;       // quotient maxima of the rare tie path
+    float* __restrict__ win = st_bp + kCoS;         // [9][16]
+    int* __restrict__ flag = reinterpret_cast<int*>(win + kHeadWin * 16);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l16 = lane & 15;
+    const int mb0 = wave & 1, ch = wave >> 1;
+    const uint32_t plane = (uint32_t)(a.H * a.W);
+
+    // this wave's weight slices -> registers, once
+    f32x4 wc[9], w1r[2], w2r[4][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+        wc[tap] = *reinterpret_cast<const f32x4*>(a.w0t + ((((tap * 2 + ch) * 4 + q) * 32) + mb0 * 16 + l16) * 4);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) w1r[u] = *reinterpret_cast<const f32x4*>(a.w1p + ((((wave * 2 + u) * 4 + q) * 16) + l16) * 4);
+#pragma unroll
+    for (int mbl = 0; mbl < 4; ++mbl)
+#pragma unroll
+        for (int m1 = 0; m1 < 4; ++m1)
+            w2r[mbl][m1] = *reinterpret_cast<const f32x4*>(a.w2p + (((((wave * 4 + mbl) * 4 + m1) * 4 + q) * 16) + l16) * 4);
+    f32x4 bias[4];
+#pragma unroll
+    for (int mbl = 0; mbl < 4; ++mbl) bias[mbl] = *reinterpret_cast<const f32x4*>(a.bias2 + (wave * 4 + mbl) * 16 + q * 4);
+
+    // staging: 1920 floats per tile = [32 channels][3 rows][20 columns]; thread t fetches items t, t+256, ...
+    constexpr int ITEMS = (32 * 60 + 255) / 256;
+    float st[ITEMS];
+    const int rows_per_b = a.H * a.tiles_x;
+    auto fetch = [&](int tile) {
+        const int b = tile / rows_per_b, rem = tile - b * rows_per_b;
+        const int y = rem / a.tiles_x, x0 = (rem - y * a.tiles_x) * 16;
+        const float* __restrict__ base = a.hidden + (int64_t)b * a.h_sb;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int item = tid + i * 256;
+            const int c = item / 60, r = item - c * 60;
+            const int row = r / 20, col = r - row * 20;
+            const int gy = y + 2 * (row - 1), gx = x0 - 2 + col;
+            const bool ok = item < 32 * 60 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            st[i] = ok ? base[(uint32_t)c * plane + (uint32_t)(gy * a.W + gx)] : 0.0f;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int item = tid + i * 256;
+            if (item < 32 * 60) {
+                const int c = item / 60, r = item - c * 60;
+                const int row = r / 20, col = r - row * 20;
+                // channel c = chunk*16 + qq*4 + s  ->  T[chunk][qq][row][col][s]
+                T[((((c >> 4) * 4 + ((c >> 2) & 3)) * 3 + row) * 20 + col) * 4 + (c & 3)] = st[i];
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < tiles_total) fetch(tile);
+    for (; tile < tiles_total; tile += gridDim.x) {
+        __syncthreads();            // the previous tile's readers of T / Y / win are done
+        stash();
+        __syncthreads();
+        if (tile + (int)gridDim.x < tiles_total) fetch(tile + gridDim.x);      // in flight during this tile's MFMAs
+        const int b = tile / rows_per_b, rem = tile - b * rows_per_b;
+        const int y = rem / a.tiles_x, x0 = (rem - y * a.tiles_x) * 16;
+        const bool live = x0 + l16 < a.W;
+        const int p = y * a.W + x0 + l16;
+
+        // ---- dilated 3x3 layer: block mb0, input chunk ch ----
+        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* __restrict__ tb = T + ((ch * 4 + q) * 3) * 80 + l16 * 4;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(tb + ky * 80 + kx * 8);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[tap][s2], bv[s2], acc0, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4*>(Pp + (((ch * 2 + mb0) * 4 + q) * 16 + l16) * 4) = acc0;
+        __syncthreads();
+
+        // ---- 1x1 layer 32 -> 64: output block `wave`; B = relu(sum of the two chunk partials) ----
+        f32x4 acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 pa = *reinterpret_cast<const f32x4*>(Pp + (((0 * 2 + u) * 4 + q) * 16 + l16) * 4);
+            const f32x4 pb = *reinterpret_cast<const f32x4*>(Pp + (((1 * 2 + u) * 4 + q) * 16 + l16) * 4);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[u][s2], fmaxf(pa[s2] + pb[s2], 0.0f), acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc1[r] = fmaxf(acc1[r], 0.0f);
+        *reinterpret_cast<f32x4*>(Y + ((wave * 4 + q) * 16 + l16) * 4) = acc1;
+        __syncthreads();
+
+        // ---- 1x1 layer 64 -> 256: bins 64*wave .. 64*wave + 63 ----
+        f32x4 acc2[4];
+#pragma unroll
+        for (int mbl = 0; mbl < 4; ++mbl) acc2[mbl] = bias[mbl];
+#pragma unroll
+        for (int m1 = 0; m1 < 4; ++m1) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(Y + ((m1 * 4 + q) * 16 + l16) * 4);
+#pragma unroll
+            for (int mbl = 0; mbl < 4; ++mbl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc2[mbl] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[mbl][m1][r], yv[r], acc2[mbl], 0, 0, 0);
+        }
+
+        // ---- softmax statistics over the pixel's 256 bins (own 16, the 4 q-lanes, the 4 waves) ----
+        float m = acc2[0][0];
+#pragma unroll
+        for (int mbl = 0; mbl < 4; ++mbl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, acc2[mbl][r]);
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (q == 0) st_max[wave * 16 + l16] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(st_max[l16], st_max[16 + l16]), fmaxf(st_max[32 + l16], st_max[48 + l16]));
+        float s = 0.0f, bv = -1.0f;
+        int bi = 0;
+#pragma unroll
+        for (int mbl = 0; mbl < 4; ++mbl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf(acc2[mbl][r] - m);
+                acc2[mbl][r] = e;
+                s += e;
+                if (e > bv) {          // strict: the lowest own bin wins ties (bins are visited in increasing order)
+                    bv = e;
+                    bi = (wave * 4 + mbl) * 16 + q * 4 + r;
+                }
+            }
+        // The four q-lanes' partial sums are combined like head_tail does (xor 16, xor 32); the waves' sums are then added
+        // in wave order -- together the same tree as the per-wave form for the 64 bins of a lane group, extended over waves.
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        float gm = fmaxf(bv, __shfl_xor(bv, 16));
+        gm = fmaxf(gm, __shfl_xor(gm, 32));
+        if (q == 0) {
+            st_sum[wave * 16 + l16] = s;
+            st_bv[wave * 16 + l16] = gm;
+        }
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        s = ((st_sum[l16] + st_sum[16 + l16]) + st_sum[32 + l16]) + st_sum[48 + l16];
+        gm = fmaxf(fmaxf(st_bv[l16], st_bv[16 + l16]), fmaxf(st_bv[32 + l16], st_bv[48 + l16]));
+        // first arg-max of p = e / s: see head_tail (quotients compared only when another bin lies within 2^-22 of the maximum)
+        const float thresh = gm * 0.99999976f;
+        int close = 0;
+#pragma unroll
+        for (int mbl = 0; mbl < 4; ++mbl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) close += acc2[mbl][r] >= thresh ? 1 : 0;
+        close += __shfl_xor(close, 16);
+        close += __shfl_xor(close, 32);
+        if (q == 0) st_cl[wave * 16 + l16] = __int_as_float(close);
+        __syncthreads();
+        close = (__float_as_int(st_cl[l16]) + __float_as_int(st_cl[16 + l16])) + (__float_as_int(st_cl[32 + l16]) + __float_as_int(st_cl[48 + l16]));
+        if (close > 1) *flag = 1;       // benign race: every writer stores 1
+        __syncthreads();
+        float bp = bv;
+        if (*flag) {                    // workgroup-uniform, rare
+            bp = -1.0f;
+#pragma unroll
+            for (int mbl = 0; mbl < 4; ++mbl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pk = acc2[mbl][r] / s;
+                    if (pk > bp) {
+                        bp = pk;
+                        bi = (wave * 4 + mbl) * 16 + q * 4 + r;
+                    }
+                }
+        }
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) {
+            const float op = __shfl_xor(bp, sh);
+            const int oi = __shfl_xor(bi, sh);
+            if (op > bp || (op == bp && oi < bi)) {
+                bp = op;
+                bi = oi;
+            }
+        }
+        if (q == 0) {
+            st_bp[wave * 16 + l16] = bp;
+            st_bi[wave * 16 + l16] = __int_as_float(bi);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {      // waves hold increasing bins: on equal values the lower wave wins
+            const float op = st_bp[w2 * 16 + l16];
+            const int oi = __float_as_int(st_bi[w2 * 16 + l16]);
+            if (w2 == 0 || op > bp || (op == bp && oi < bi)) {
+                bp = op;
+                bi = oi;
+            }
+        }
+        // window k*-4 .. k*+4 (unclamped positions) -> LDS, as e; wave 0, q == 0 divides and regresses
+        const int lo = bi - ITERMVS_WINDOW_RADIUS;
+#pragma unroll
+        for (int mbl = 0; mbl < 4; ++mbl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int off = (wave * 4 + mbl) * 16 + q * 4 + r - lo;
+                if (off >= 0 && off < kHeadWin) win[off * 16 + l16] = acc2[mbl][r];
+            }
+        __syncthreads();
+        if (wave == 0 && q == 0 && live) {
+            float num = 0.0f, den = 1e-6f;   // itermvs.py:212
+            for (int i = 0; i < kHeadWin; ++i) {
+                int k = lo + i;
+                k = k < 0 ? 0 : (k > kHeadBins - 1 ? kHeadBins - 1 : k);   // clamp; duplicates double-counted
+                const float pk = win[(k - lo) * 16 + l16] / s;
+                num = num + (float)k * pk;
+                den = den + pk;
+            }
+            const float nd = (num / den) / (float)(kHeadBins - 1);
+            if (a.out.nd0) a.out.nd0[b * a.out.nd_sb0 + p] = nd;
+            if (a.out.nd1) a.out.nd1[b * a.out.nd_sb1 + p] = nd;
+            if (a.out.best) a.out.best[(size_t)b * a.out.P + p] = bi;
+        }
+    }
+}
+
 }  // namespace itermvs
 
 using namespace itermvs;
@@ -370,6 +633,20 @@ extern "C" int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_
     a.hidden = hidden; a.h_sb = hidden_sb; a.w0t = w0_tile; a.w1p = w1_packed; a.w2p = w2_packed; a.bias2 = bias2;
     a.out.nd0 = nd_out0; a.out.nd1 = nd_out1; a.out.nd_sb0 = nd_sb0; a.out.nd_sb1 = nd_sb1; a.out.best = best; a.out.P = H * W;
     a.H = H; a.W = W; a.tiles_x = (W + 15) / 16;
+    // default: the cooperative form (one tile shared by the four waves of a persistent workgroup); ITERMVS_HEAD_FORM=wave
+    // selects the one-tile-per-wave form for A/B measurements
+    const char* form = getenv("ITERMVS_HEAD_FORM");
+    if (!(form && form[0] == 'w')) {
+        static const int cus = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return n > 0 ? n : 256;
+        }();
+        const int tiles = a.tiles_x * H * B;
+        const int grid = tiles < 2 * cus ? tiles : 2 * cus;
+        hipLaunchKernelGGL(head_coop_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles);
+        return itermvs_launch_status();
+    }
     hipLaunchKernelGGL(head_fused_kernel, dim3(a.tiles_x * ((H + 3) / 4), B), dim3(256), kFusedLds, (hipStream_t)stream, a);
     return itermvs_launch_status();
 }

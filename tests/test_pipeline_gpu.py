@@ -252,7 +252,10 @@ def test_16bit_feature_storage_end_to_end(fdt):
     e32, e16 = float((d32.cpu() - gt).abs().median()), float((d16.cpu() - gt).abs().median())
     print(f"feature storage {fdt}: depth vs fp32 engine median {float(rel.median()):.2e}, >1e-3 on {float((rel > 1e-3).float().mean()):.4f} "
           f"of the pixels; median |depth - ground truth| {e16:.3f} mm (fp32: {e32:.3f} mm)")
-    assert float(rel.median()) <= (1e-3 if fdt == "bf16" else 2e-4)
+    # measured on the MI355X (profiles/r02): median 4.3e-6 (bf16) / 5.4e-7 (fp16); 3.5 % / 2.1 % of the pixels move by more
+    # than 1e-3 (arg-max flips); plane reconstruction 0.743 / 0.741 mm vs 0.742 mm in fp32
+    assert float(rel.median()) <= (2e-5 if fdt == "bf16" else 5e-6)
+    assert float((rel > 1e-3).float().mean()) <= 0.08
     assert float((rel > 1e-2).float().mean()) <= 0.05
     assert abs(e16 - e32) <= 0.1 and e16 < 1.0               # reconstructs the plane as well as fp32 does
 
