@@ -363,22 +363,14 @@ __global__ void __launch_bounds__(256) head_fused_kernel(const FusedArgs a) {
 constexpr int kCoT = 2 * 4 * 3 * 20 * 4;   // staged tile: [chunk][q][row][col][s]
 constexpr int kCoP = 2 * 2 * 4 * 16 * 4;   // conv partials: [chunk][mb0][q][l16][r]
 constexpr int kCoY = 4 * 4 * 16 * 4;       // hidden layer: [mb1][q][l16][r]
-constexpr int kCoS = 4 * 16;               // one statistic per wave and pixel
-constexpr int kCoLds = kCoT + kCoP + kCoY + 6 * kCoS + kHeadWin * 16 + 16;
+constexpr int kCoLgStride = 256 + 4;       // logits [16 pixels][256 bins], rows padded against bank conflicts
+constexpr int kCoLds = 2 * kCoT + kCoP + kCoY + 16 * kCoLgStride;
 
 __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const int tiles_total) {
     __shared__ __attribute__((aligned(16))) float smem[kCoLds];
-    float* __restrict__ T = smem;
-    float* __restrict__ Pp = T + kCoT;
+    float* __restrict__ Pp = smem + 2 * kCoT;       // (two tile buffers in front: the next tile is stashed while this one computes)
     float* __restrict__ Y = Pp + kCoP;
-    float* __restrict__ st_max = Y + kCoY;          // [wave][px]
-    float* __restrict__ st_sum = st_max + kCoS;
-    float* __restrict__ st_bv = st_sum + kCoS;
-    float* __restrict__ st_bi = st_bv + kCoS;       // (int bits)
-    float* __restrict__ st_cl = st_bi + kCoS;       // close counts (int bits)
-    float* __restrict__ st_bp = st_cl + kCoS;       // quotient maxima of the rare tie path
-    float* __restrict__ win = st_bp + kCoS;         // [9][16]
-    int* __restrict__ flag = reinterpret_cast<int*>(win + kHeadWin * 16);
+    float* __restrict__ LG = Y + kCoY;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l16 = lane & 15;
@@ -419,7 +411,7 @@ __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const
             st[i] = ok ? base[(uint32_t)c * plane + (uint32_t)(gy * a.W + gx)] : 0.0f;
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](float* __restrict__ T) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const int item = tid + i * 256;
@@ -432,17 +424,17 @@ __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile < tiles_total) fetch(tile);
-    for (; tile < tiles_total; tile += gridDim.x) {
-        __syncthreads();            // the previous tile's readers of T / Y / win are done
-        stash();
-        __syncthreads();
-        if (tile + (int)gridDim.x < tiles_total) fetch(tile + gridDim.x);      // in flight during this tile's MFMAs
+    int tile = blockIdx.x, buf = 0;
+    if (tile < tiles_total) {
+        fetch(tile);
+        stash(smem);
+    }
+    if (tile + (int)gridDim.x < tiles_total) fetch(tile + gridDim.x);
+    for (; tile < tiles_total; tile += gridDim.x, buf ^= 1) {
+        __syncthreads();            // this tile's staging is visible; the previous tile's readers of P / Y / LG are done
+        const float* __restrict__ T = smem + buf * kCoT;
         const int b = tile / rows_per_b, rem = tile - b * rows_per_b;
         const int y = rem / a.tiles_x, x0 = (rem - y * a.tiles_x) * 16;
-        const bool live = x0 + l16 < a.W;
-        const int p = y * a.W + x0 + l16;
 
         // ---- dilated 3x3 layer: block mb0, input chunk ch ----
         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -455,6 +447,11 @@ __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const
             for (int s2 = 0; s2 < 4; ++s2) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[tap][s2], bv[s2], acc0, 0, 0, 0);
         }
         *reinterpret_cast<f32x4*>(Pp + (((ch * 2 + mb0) * 4 + q) * 16 + l16) * 4) = acc0;
+        // the next tile's halo (fetched one iteration ago) goes to the other buffer, the one after it into registers
+        if (tile + (int)gridDim.x < tiles_total) {
+            stash(smem + (buf ^ 1) * kCoT);
+            if (tile + 2 * (int)gridDim.x < tiles_total) fetch(tile + 2 * gridDim.x);
+        }
         __syncthreads();
 
         // ---- 1x1 layer 32 -> 64: output block `wave`; B = relu(sum of the two chunk partials) ----
@@ -485,75 +482,61 @@ __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const
                 for (int r = 0; r < 4; ++r) acc2[mbl] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[mbl][m1][r], yv[r], acc2[mbl], 0, 0, 0);
         }
 
-        // ---- softmax statistics over the pixel's 256 bins (own 16, the 4 q-lanes, the 4 waves) ----
-        float m = acc2[0][0];
+        // ---- logits -> LDS [pixel][bin]; then wave w owns pixels 4w .. 4w+3 completely (16 lanes x 16 bins each): the
+        //      softmax statistics, first arg-max and window regression need no further workgroup barrier ----
 #pragma unroll
         for (int mbl = 0; mbl < 4; ++mbl)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, acc2[mbl][r]);
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-        if (q == 0) st_max[wave * 16 + l16] = m;
+            *reinterpret_cast<f32x4*>(LG + l16 * kCoLgStride + (wave * 4 + mbl) * 16 + q * 4) = acc2[mbl];
         __syncthreads();
-        m = fmaxf(fmaxf(st_max[l16], st_max[16 + l16]), fmaxf(st_max[32 + l16], st_max[48 + l16]));
+        const int pl = wave * 4 + (lane >> 4), t = lane & 15;      // pixel of the tile, bin group (bins 16t .. 16t+15)
+        float e[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(LG + pl * kCoLgStride + t * 16 + i * 4);
+            e[4 * i] = v[0]; e[4 * i + 1] = v[1]; e[4 * i + 2] = v[2]; e[4 * i + 3] = v[3];
+        }
+        float m = e[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, e[i]);
+#pragma unroll
+        for (int sh = 1; sh <= 8; sh <<= 1) m = fmaxf(m, __shfl_xor(m, sh));
         float s = 0.0f, bv = -1.0f;
         int bi = 0;
 #pragma unroll
-        for (int mbl = 0; mbl < 4; ++mbl)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = expf(acc2[mbl][r] - m);
-                acc2[mbl][r] = e;
-                s += e;
-                if (e > bv) {          // strict: the lowest own bin wins ties (bins are visited in increasing order)
-                    bv = e;
-                    bi = (wave * 4 + mbl) * 16 + q * 4 + r;
-                }
+        for (int i = 0; i < 16; ++i) {
+            e[i] = expf(e[i] - m);
+            s += e[i];
+            if (e[i] > bv) {          // strict: the lowest own bin wins ties (bins are visited in increasing order)
+                bv = e[i];
+                bi = t * 16 + i;
             }
-        // The four q-lanes' partial sums are combined like head_tail does (xor 16, xor 32); the waves' sums are then added
-        // in wave order -- together the same tree as the per-wave form for the 64 bins of a lane group, extended over waves.
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        float gm = fmaxf(bv, __shfl_xor(bv, 16));
-        gm = fmaxf(gm, __shfl_xor(gm, 32));
-        if (q == 0) {
-            st_sum[wave * 16 + l16] = s;
-            st_bv[wave * 16 + l16] = gm;
         }
-        if (tid == 0) *flag = 0;
-        __syncthreads();
-        s = ((st_sum[l16] + st_sum[16 + l16]) + st_sum[32 + l16]) + st_sum[48 + l16];
-        gm = fmaxf(fmaxf(st_bv[l16], st_bv[16 + l16]), fmaxf(st_bv[32 + l16], st_bv[48 + l16]));
+#pragma unroll
+        for (int sh = 1; sh <= 8; sh <<= 1) s += __shfl_xor(s, sh);
+        float gm = bv;
+#pragma unroll
+        for (int sh = 1; sh <= 8; sh <<= 1) gm = fmaxf(gm, __shfl_xor(gm, sh));
         // first arg-max of p = e / s: see head_tail (quotients compared only when another bin lies within 2^-22 of the maximum)
         const float thresh = gm * 0.99999976f;
         int close = 0;
 #pragma unroll
-        for (int mbl = 0; mbl < 4; ++mbl)
+        for (int i = 0; i < 16; ++i) close += e[i] >= thresh ? 1 : 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) close += acc2[mbl][r] >= thresh ? 1 : 0;
-        close += __shfl_xor(close, 16);
-        close += __shfl_xor(close, 32);
-        if (q == 0) st_cl[wave * 16 + l16] = __int_as_float(close);
-        __syncthreads();
-        close = (__float_as_int(st_cl[l16]) + __float_as_int(st_cl[16 + l16])) + (__float_as_int(st_cl[32 + l16]) + __float_as_int(st_cl[48 + l16]));
-        if (close > 1) *flag = 1;       // benign race: every writer stores 1
-        __syncthreads();
+        for (int sh = 1; sh <= 8; sh <<= 1) close += __shfl_xor(close, sh);
         float bp = bv;
-        if (*flag) {                    // workgroup-uniform, rare
+        if (__any(close > 1)) {         // wave-uniform, rare
             bp = -1.0f;
 #pragma unroll
-            for (int mbl = 0; mbl < 4; ++mbl)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pk = acc2[mbl][r] / s;
-                    if (pk > bp) {
-                        bp = pk;
-                        bi = (wave * 4 + mbl) * 16 + q * 4 + r;
-                    }
+            for (int i = 0; i < 16; ++i) {
+                const float pk = e[i] / s;
+                if (pk > bp) {
+                    bp = pk;
+                    bi = t * 16 + i;
                 }
+            }
         }
 #pragma unroll
-        for (int sh = 16; sh <= 32; sh <<= 1) {
+        for (int sh = 1; sh <= 8; sh <<= 1) {
             const float op = __shfl_xor(bp, sh);
             const int oi = __shfl_xor(bi, sh);
             if (op > bp || (op == bp && oi < bi)) {
@@ -561,39 +544,24 @@ __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const
                 bi = oi;
             }
         }
-        if (q == 0) {
-            st_bp[wave * 16 + l16] = bp;
-            st_bi[wave * 16 + l16] = __int_as_float(bi);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) {      // waves hold increasing bins: on equal values the lower wave wins
-            const float op = st_bp[w2 * 16 + l16];
-            const int oi = __float_as_int(st_bi[w2 * 16 + l16]);
-            if (w2 == 0 || op > bp || (op == bp && oi < bi)) {
-                bp = op;
-                bi = oi;
-            }
-        }
-        // window k*-4 .. k*+4 (unclamped positions) -> LDS, as e; wave 0, q == 0 divides and regresses
+        // window k*-4 .. k*+4 (clamped; border duplicates double-counted): lane i < 9 of the pixel's 16 lanes fetches its bin
+        // back from LDS as e, the nine terms are then summed in window order by lane 0 (the arithmetic of prob_regress_kernel)
         const int lo = bi - ITERMVS_WINDOW_RADIUS;
+        int kbin = lo + t;
+        kbin = kbin < 0 ? 0 : (kbin > kHeadBins - 1 ? kHeadBins - 1 : kbin);
+        const float pk_mine = expf(LG[pl * kCoLgStride + kbin] - m) / s;
+        float num = 0.0f, den = 1e-6f;   // itermvs.py:212
 #pragma unroll
-        for (int mbl = 0; mbl < 4; ++mbl)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int off = (wave * 4 + mbl) * 16 + q * 4 + r - lo;
-                if (off >= 0 && off < kHeadWin) win[off * 16 + l16] = acc2[mbl][r];
-            }
-        __syncthreads();
-        if (wave == 0 && q == 0 && live) {
-            float num = 0.0f, den = 1e-6f;   // itermvs.py:212
-            for (int i = 0; i < kHeadWin; ++i) {
-                int k = lo + i;
-                k = k < 0 ? 0 : (k > kHeadBins - 1 ? kHeadBins - 1 : k);   // clamp; duplicates double-counted
-                const float pk = win[(k - lo) * 16 + l16] / s;
-                num = num + (float)k * pk;
-                den = den + pk;
-            }
+        for (int i = 0; i < kHeadWin; ++i) {
+            const float pk = __shfl(pk_mine, (lane & 48) + i);
+            int k = lo + i;
+            k = k < 0 ? 0 : (k > kHeadBins - 1 ? kHeadBins - 1 : k);
+            num = num + (float)k * pk;
+            den = den + pk;
+        }
+        const int px = x0 + pl;
+        if (t == 0 && px < a.W) {
+            const int p = y * a.W + px;
             const float nd = (num / den) / (float)(kHeadBins - 1);
             if (a.out.nd0) a.out.nd0[b * a.out.nd_sb0 + p] = nd;
             if (a.out.nd1) a.out.nd1[b * a.out.nd_sb1 + p] = nd;
