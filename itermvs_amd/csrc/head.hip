@@ -393,9 +393,24 @@ __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const
 #pragma unroll
     for (int mbl = 0; mbl < 4; ++mbl) bias[mbl] = *reinterpret_cast<const f32x4*>(a.bias2 + (wave * 4 + mbl) * 16 + q * 4);
 
-    // staging: 1920 floats per tile = [32 channels][3 rows][20 columns]; thread t fetches items t, t+256, ...
+    // staging: 1920 floats per tile = [32 channels][3 rows][20 columns]; thread t moves items t, t+256, ...  Which (channel,
+    // row, column) an item is does not depend on the tile: its plane offset, row / column displacement and LDS slot are
+    // computed once.
     constexpr int ITEMS = (32 * 60 + 255) / 256;
     float st[ITEMS];
+    uint32_t it_plane[ITEMS];
+    int it_dy[ITEMS], it_dx[ITEMS], it_lds[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int item = tid + i * 256;
+        const int c = item / 60, r = item - c * 60;
+        const int row = r / 20, col = r - row * 20;
+        it_plane[i] = (uint32_t)c * plane;
+        it_dy[i] = item < 32 * 60 ? 2 * (row - 1) : -(1 << 20);        // surplus items: always out of range
+        it_dx[i] = col - 2;
+        // channel c = chunk*16 + qq*4 + s  ->  T[chunk][qq][row][col][s]
+        it_lds[i] = item < 32 * 60 ? ((((c >> 4) * 4 + ((c >> 2) & 3)) * 3 + row) * 20 + col) * 4 + (c & 3) : -1;
+    }
     const int rows_per_b = a.H * a.tiles_x;
     auto fetch = [&](int tile) {
         const int b = tile / rows_per_b, rem = tile - b * rows_per_b;
@@ -403,25 +418,15 @@ __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const
         const float* __restrict__ base = a.hidden + (int64_t)b * a.h_sb;
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            const int item = tid + i * 256;
-            const int c = item / 60, r = item - c * 60;
-            const int row = r / 20, col = r - row * 20;
-            const int gy = y + 2 * (row - 1), gx = x0 - 2 + col;
-            const bool ok = item < 32 * 60 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            st[i] = ok ? base[(uint32_t)c * plane + (uint32_t)(gy * a.W + gx)] : 0.0f;
+            const int gy = y + it_dy[i], gx = x0 + it_dx[i];
+            const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            st[i] = ok ? base[it_plane[i] + (uint32_t)(gy * a.W + gx)] : 0.0f;
         }
     };
     auto stash = [&](float* __restrict__ T) {
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int item = tid + i * 256;
-            if (item < 32 * 60) {
-                const int c = item / 60, r = item - c * 60;
-                const int row = r / 20, col = r - row * 20;
-                // channel c = chunk*16 + qq*4 + s  ->  T[chunk][qq][row][col][s]
-                T[((((c >> 4) * 4 + ((c >> 2) & 3)) * 3 + row) * 20 + col) * 4 + (c & 3)] = st[i];
-            }
-        }
+        for (int i = 0; i < ITEMS; ++i)
+            if (it_lds[i] >= 0) T[it_lds[i]] = st[i];
     };
 
     int tile = blockIdx.x, buf = 0;
@@ -504,7 +509,7 @@ __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const
         int bi = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            e[i] = expf(e[i] - m);
+            e[i] = __expf(e[i] - m);      // v_exp_f32 (1 ulp, like the vectorised exp of the reference's CPU softmax): 16 per lane
             s += e[i];
             if (e[i] > bv) {          // strict: the lowest own bin wins ties (bins are visited in increasing order)
                 bv = e[i];
@@ -549,7 +554,7 @@ __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const
         const int lo = bi - ITERMVS_WINDOW_RADIUS;
         int kbin = lo + t;
         kbin = kbin < 0 ? 0 : (kbin > kHeadBins - 1 ? kHeadBins - 1 : kbin);
-        const float pk_mine = expf(LG[pl * kCoLgStride + kbin] - m) / s;
+        const float pk_mine = __expf(LG[pl * kCoLgStride + kbin] - m) / s;
         float num = 0.0f, den = 1e-6f;   // itermvs.py:212
 #pragma unroll
         for (int i = 0; i < kHeadWin; ++i) {
