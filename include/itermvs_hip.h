@@ -346,6 +346,19 @@ typedef struct itermvs_conv_params {
 int itermvs_conv2d(const itermvs_conv_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * itermvs_corrnet -- the whole CorrNet (models/itermvs.py:352-381: conv0..conv2, the two transposed convolutions with
+ * their skip additions, conv5 + bias) in ONE launch, every intermediate in LDS (32 x 32 output tiles, halos recomputed).
+ *   x [M,8,H,W] planes (batch stride x_sn), H and W multiples of 4;  out / out2 (optional) [M,1,H,W] at batch strides
+ *   out_sn / out2_sn (the GRU input buffers take the scores in place);
+ *   weights: host array of n_seg (1..3) device pointers to PACKED weight sets, batch items [0,seg_end[0]) use set 0,
+ *   [seg_end[0],seg_end[1]) set 1, the rest set 2 (the three CorrNets of one GRU iteration in one launch).
+ *   Packed set (fp32, 12172 floats, 16-byte aligned): conv0 [ci 8][ky][kx][co 8] | conv1 [8][3][3][16] | conv2 [16][3][3][32] |
+ *   conv3 (transposed) [ci 32][ky][kx][co 16] | conv4 (transposed) [16][3][3][8] | conv5 [ci 8][ky][kx] | bias | 3 pad.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_corrnet(const float* x, int64_t x_sn, const float* const* weights, const int32_t* seg_end, int32_t n_seg,
+                    int32_t M, int32_t H, int32_t W, float* out, int64_t out_sn, float* out2, int64_t out2_sn, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * itermvs_fuse_depth -- the filter that follows the depth-inference path:
  *   reproject_with_depth (eval.py:154-194), check_geometric_consistency (eval.py:197-212) and the per-reference
  *   arithmetic of filter_depth (eval.py:238-269) for ONE reference view against its S source views, one pass.

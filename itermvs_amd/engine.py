@@ -88,6 +88,8 @@ class InferenceEngine:
         self.nan_flag = torch.zeros((1,), device=dev, dtype=torch.int32)
         self.profile_iterations = None   # set of iteration indices whose corr_iter launch carries timing events (None = all)
         self.profile_init = True         # whether the corr_init launch carries timing events (bench.py)
+        import os
+        self._corrnet_fused = os.environ.get("ITERMVS_CORRNET", "fused") != "layers"
         self.pk: Dict[str, object] = {}
         self._pack_weights()
 
@@ -108,6 +110,7 @@ class InferenceEngine:
                 pk[k] = ops.MfmaWeight(v, transposed=True)
             else:
                 pk[k] = pack(v)
+        self.corrnet_w = {l: ops.pack_corrnet_weights(w, f"iter_mvs.evaluation.corr_conv1.{l - 1}.") for l in (1, 2, 3)}
         dh = "iter_mvs.update.depth_head."
         self.head_w1, self.head_w2 = ops.pack_head_weights(w[dh + "2.weight"], w[dh + "4.weight"])
         self.pk_zr = ops.MfmaWeight(self.w_zr)
@@ -158,8 +161,11 @@ class InferenceEngine:
 
     # -- small stacks ---------------------------------------------------------------------------
     def corr_nets(self, x: Tensor, levels, seg_end=(), out: Tensor = None, out2: Tensor = None) -> Tensor:
-        """itermvs.py:352-381 for one or three levels in ONE launch per layer: x [M,8,h,w] whose batch
-        items [0,seg_end[0]) / [seg_end[0],seg_end[1]) / rest belong to levels[0..2] -> [M,1,h,w]."""
+        """itermvs.py:352-381 for one or three levels: x [M,8,h,w] whose batch items [0,seg_end[0]) / [seg_end[0],seg_end[1]) /
+        rest belong to levels[0..2] -> [M,1,h,w].  ONE launch (itermvs_corrnet: the whole U-Net per 32 x 32 tile in LDS);
+        ITERMVS_CORRNET=layers evaluates it layer by layer (six itermvs_conv2d launches) for A/B measurements."""
+        if self._corrnet_fused:
+            return ops.corrnet(x, [self.corrnet_w[l] for l in levels], seg_end, out=out, out2=out2)
         ps = [f"iter_mvs.evaluation.corr_conv1.{l - 1}." for l in levels]
         wl = lambda n: [self.pk[p + n] for p in ps]
         c0 = ops.conv2d(x, wl("conv0.conv.weight"), None, act="relu", seg_end=seg_end)

@@ -740,6 +740,46 @@ def fuse_depth(depth_ref: Tensor, conf_ref: Tensor, depth_src: Sequence[Tensor],
     return avg, photo, geo, final, cnt
 
 
+CORRNET_WEIGHT_FLOATS = 12172
+
+
+def pack_corrnet_weights(w: Dict[str, Tensor], prefix: str) -> Tensor:
+    """the six layers of one CorrNet (state-dict names ``prefix`` + conv0.conv.weight ... conv5.bias) in the layout of
+    itermvs_corrnet: input channel outermost, output channel innermost, so the weights of one (input channel, tap) are one
+    contiguous run the kernel reads through the scalar cache"""
+    parts = [w[prefix + "conv0.conv.weight"].permute(1, 2, 3, 0),      # Conv2d [co,ci,ky,kx] -> [ci,ky,kx,co]
+             w[prefix + "conv1.conv.weight"].permute(1, 2, 3, 0),
+             w[prefix + "conv2.conv.weight"].permute(1, 2, 3, 0),
+             w[prefix + "conv3.weight"].permute(0, 2, 3, 1),           # ConvTranspose2d [ci,co,ky,kx] -> [ci,ky,kx,co]
+             w[prefix + "conv4.weight"].permute(0, 2, 3, 1),
+             w[prefix + "conv5.weight"].permute(1, 2, 3, 0),
+             w[prefix + "conv5.bias"]]
+    flat = torch.cat([t.reshape(-1).float() for t in parts] + [torch.zeros(3, device=parts[0].device)])
+    assert flat.numel() == CORRNET_WEIGHT_FLOATS
+    return flat.contiguous()
+
+
+def corrnet(x: Tensor, weight_sets: Sequence[Tensor], seg_end: Sequence[int] = (), out: Optional[Tensor] = None,
+            out2: Optional[Tensor] = None) -> Tensor:
+    """itermvs_corrnet: x [M,8,H,W] -> [M,1,H,W]; ``weight_sets`` = 1..3 tensors from pack_corrnet_weights, ``seg_end`` the
+    batch boundaries between them; ``out`` / ``out2``: [M,1,H,W] views with dense planes (e.g. channels of the GRU buffers)"""
+    ptr, x_sn = _planes(x, "corrnet input")
+    m, c, h, w = x.shape
+    if c != 8 or h % 4 or w % 4:
+        raise RuntimeError("corrnet: expects [M,8,H,W] with H and W multiples of 4")
+    if out is None:
+        out = torch.empty((m, 1, h, w), device=x.device, dtype=torch.float32)
+    po, o_sn = _planes(out, "corrnet output")
+    p2, o2_sn = _planes(out2, "corrnet output 2") if out2 is not None else (None, 0)
+    for t in (out, out2):
+        if t is not None and tuple(t.shape) != (m, 1, h, w):
+            raise RuntimeError(f"corrnet: output has shape {tuple(t.shape)}, expected {(m, 1, h, w)}")
+    wp = (C.c_void_p * len(weight_sets))(*[_dev(t, "corrnet weights").data_ptr() for t in weight_sets])
+    se = (C.c_int32 * 3)(*(list(seg_end) + [m] * (3 - len(seg_end))))
+    check(_lib.load().itermvs_corrnet(ptr, x_sn, wp, se, len(weight_sets), m, h, w, po, o_sn, p2, o2_sn, _stream()), "itermvs_corrnet")
+    return out
+
+
 def image_pyramid(raw: Tensor, height: int, width: int, all_levels: bool = True) -> Dict[str, Tensor]:
     """datasets/dtu_yao_eval.py:61-74 on the GPU: raw [V,Hs,Ws,3] uint8 RGB (device) -> {'level_0': [V,3,H,W] float32 in
     -1..1, resized like cv2.resize(INTER_LINEAR), 'level_1'..'level_3': the reference's lower pyramid levels}"""

@@ -225,3 +225,37 @@ def test_channels_last_output_in_16bit_storage(dtype):
     assert torch.equal(planar, o32.contiguous())                 # the planar copy stays fp32
     with pytest.raises(RuntimeError):
         ops().conv2d(x, pk, bias, out=torch.empty((3, 32, 20, 28), device=DEV, dtype=dtype))
+
+
+@pytest.mark.parametrize("case", [(10, 128, 160, (1, 2, 3), (4, 8)), (32, 64, 80, (3,), ()), (5, 36, 52, (2, 1), (3,)), (2, 8, 4, (1,), ())])
+def test_corrnet_one_launch_matches_torch(case):
+    """itermvs_corrnet (the whole U-Net of itermvs.py:352-381 per 32x32 tile in LDS, halos recomputed, zero padding of
+    every intermediate reproduced at the image border) against the torch layer chain, with per-segment weight sets, ragged
+    sizes (not multiples of the tile) and maps smaller than a tile; outputs may land in channel slices of wider buffers"""
+    from conftest import load_weights
+    m, h, w, levels, seg_end = case
+    wts = {k: v.to(DEV) for k, v in load_weights("dtu").items() if "corr_conv1" in k}
+    gen = torch.Generator().manual_seed(m * h + w)
+    x = torch.randn((m, 8, h, w), generator=gen).to(DEV)
+    bounds = [0] + list(seg_end) + [m]
+    want = []
+    for i, l in enumerate(levels):
+        p = f"iter_mvs.evaluation.corr_conv1.{l - 1}."
+        xi = x[bounds[i]:bounds[i + 1]]
+        c0 = F.relu(F.conv2d(xi, wts[p + "conv0.conv.weight"], padding=1))
+        c1 = F.relu(F.conv2d(c0, wts[p + "conv1.conv.weight"], stride=2, padding=1))
+        c2 = F.relu(F.conv2d(c1, wts[p + "conv2.conv.weight"], stride=2, padding=1))
+        u1 = c1 + F.conv_transpose2d(c2, wts[p + "conv3.weight"], stride=2, padding=1, output_padding=1)
+        u0 = c0 + F.conv_transpose2d(u1, wts[p + "conv4.weight"], stride=2, padding=1, output_padding=1)
+        want.append(F.conv2d(u0, wts[p + "conv5.weight"], wts[p + "conv5.bias"], padding=1))
+    want = torch.cat(want)
+    packs = [ops().pack_corrnet_weights(wts, f"iter_mvs.evaluation.corr_conv1.{l - 1}.") for l in levels]
+    got = ops().corrnet(x, packs, seg_end)
+    assert got.shape == want.shape and rel_err(got, want) <= 3e-6, rel_err(got, want)
+    if m == 10:                               # the GRU input buffers take the ten score planes in place
+        wide = torch.zeros((1, 43, h, w), device=DEV)
+        wide2 = torch.zeros((1, 43, h, w), device=DEV)
+        ops().corrnet(x, packs, seg_end, out=wide[0, 33:].unsqueeze(1), out2=wide2[0, 33:].unsqueeze(1))
+        assert torch.equal(wide[0, 33:], got[:, 0]) and torch.equal(wide2, wide) and float(wide[:, :33].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ops().corrnet(torch.zeros((1, 8, 6, 8), device=DEV), packs[:1])
