@@ -83,11 +83,13 @@ def cpu_baseline(args, target_seconds: float = 15.0):
             "s_per_depth_map": dt / n}
 
 
-def transfers_leg(args, dev, samples, world):
+def transfers_leg(args, dev, samples, world, u8: bool = False):
     """depth-maps/s with PCIe in the loop: H2D of the sample (imgs level_0, cameras, depth range) and D2H of the two output
-    maps, overlapped with compute through two graph runners' static buffers (double buffering) and three HIP streams."""
+    maps, overlapped with compute through two graph runners' static buffers (double buffering) and three HIP streams.
+    ``u8``: the images travel as the decoded uint8 RGB arrays (what eval.py --dataset folder uploads, 5x fewer bytes) and
+    itermvs_image_pyramid normalises them into the runner's static input on the copy stream."""
     import torch
-    from itermvs_amd import shard, synthetic
+    from itermvs_amd import ops, shard, synthetic
     from itermvs_amd.engine import GraphedRunner, InferenceEngine
     from itermvs_amd.net import Pipeline
     m = Pipeline(iteration=args.iters, test=True)
@@ -99,10 +101,14 @@ def transfers_leg(args, dev, samples, world):
     runners = [GraphedRunner(eng, imgs0["level_0"].float(), pj, dmin0.float(), dmax0.float()) for _ in range(2)]
     host_in = []
     for imgs, projs, dmin, dmax in samples:
-        host_in.append((imgs["level_0"].float().cpu().pin_memory(),
+        img = imgs["level_0"].float().cpu()
+        if u8:      # [1,V,3,H,W] in -1..1 -> [V,H,W,3] uint8, like a decoded image file
+            img = ((img[0].permute(0, 2, 3, 1) + 1) * 127.5).round().clamp(0, 255).to(torch.uint8).contiguous()
+        host_in.append((img.pin_memory(),
                         torch.stack([projs[f"level_{l}"].float() for l in (1, 2, 3)]).cpu().pin_memory(),
                         dmin.float().cpu().pin_memory(), dmax.float().cpu().pin_memory()))
     host_out = [tuple(torch.empty(o.shape, dtype=o.dtype).pin_memory() for o in r.out) for r in runners]
+    raw_dev = [torch.empty(host_in[0][0].shape, dtype=torch.uint8, device=dev) for _ in runners] if u8 else None
     s_in, s_cmp, s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
     ev_in = [torch.cuda.Event() for _ in range(2)]
     ev_done = [torch.cuda.Event() for _ in range(2)]
@@ -120,7 +126,11 @@ def transfers_leg(args, dev, samples, world):
                 s_in.wait_event(ev_done[k])                 # replay i-2 has consumed these static inputs
             if tev:
                 tev[0].record(s_in)
-            r.imgs.copy_(h_img, non_blocking=True)
+            if u8:
+                raw_dev[k].copy_(h_img, non_blocking=True)
+                ops.image_pyramid(raw_dev[k], args.height, args.width, all_levels=False, out0=r.imgs[0])
+            else:
+                r.imgs.copy_(h_img, non_blocking=True)
             r.proj_stack.copy_(h_proj, non_blocking=True)
             r.depth_min.copy_(h_min, non_blocking=True)
             r.depth_max.copy_(h_max, non_blocking=True)
@@ -156,6 +166,7 @@ def transfers_leg(args, dev, samples, world):
     d2h = sum(t.numel() * t.element_size() for t in host_out[0])
     return {"value": world * args.steps * args.batch / elapsed, "unit": "depth-maps/s", "ms_per_step": elapsed / args.steps * 1e3,
             "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h,
+            "images": "uint8 RGB, normalised on the GPU (itermvs_image_pyramid)" if u8 else "float32 level_0 tensor",
             "note": "pinned host inputs -> H2D on a copy stream into the static inputs of two alternating hipGraph runners, "
                     "compute stream, D2H of depth + confidence into pinned host buffers on a third stream; "
                     "same steps / barrier / max-over-ranks timing as `value`"}
@@ -337,6 +348,8 @@ def main() -> None:
     with_transfers = None
     if args.streams == 1 and not args.eager and not args.no_transfers:
         with_transfers = transfers_leg(args, dev, samples, world)
+        if args.batch == 1:
+            with_transfers["uint8_images"] = transfers_leg(args, dev, samples, world, u8=True)
 
     # second roofline: the matrix-core convolutions (FeatureNet, CorrNet, ConvGRU, heads) -- timed with
     # HIP-event pairs around every itermvs_conv2d launch in a short EXTRA pass after the timed region

@@ -352,8 +352,9 @@ int itermvs_conv2d(const itermvs_conv_params* p, void* stream);
  *   out_sn / out2_sn (the GRU input buffers take the scores in place);
  *   weights: host array of n_seg (1..3) device pointers to PACKED weight sets, batch items [0,seg_end[0]) use set 0,
  *   [seg_end[0],seg_end[1]) set 1, the rest set 2 (the three CorrNets of one GRU iteration in one launch).
- *   Packed set (fp32, 12172 floats, 16-byte aligned): conv0 [ci 8][ky][kx][co 8] | conv1 [8][3][3][16] | conv2 [16][3][3][32] |
- *   conv3 (transposed) [ci 32][ky][kx][co 16] | conv4 (transposed) [16][3][3][8] | conv5 [ci 8][ky][kx] | bias | 3 pad.
+ *   Packed set (fp32, 13904 floats, 16-byte aligned): the five matrix-core layers in operand order
+ *   [tap = ky*3+kx][k-step = ci/4][q = ci%4][co, zero padded] -- conv0 (co 16) | conv1 (16) | conv2 (32) | conv3, transposed
+ *   (16) | conv4, transposed (16) -- then conv5 as [ci 8][tap 9], the bias, 7 pad (itermvs_amd.ops.pack_corrnet_weights).
  * ------------------------------------------------------------------------------------------ */
 int itermvs_corrnet(const float* x, int64_t x_sn, const float* const* weights, const int32_t* seg_end, int32_t n_seg,
                     int32_t M, int32_t H, int32_t W, float* out, int64_t out_sn, float* out2, int64_t out2_sn, void* stream);

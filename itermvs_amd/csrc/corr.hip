@@ -40,15 +40,25 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
     const uint32_t sy = (uint32_t)L.sy, sx = (uint32_t)L.sx;
     const int lane = threadIdx.x & 63;
 
+    // index arithmetic without integer division on the common path (an unsigned division costs ~25 vector instructions,
+    // and these gather kernels are bound by instruction issue): items per pixel is a power of two for the reference's
+    // hypothesis counts, and a tile of 32 consecutive pixels wraps at most one image row when W >= 32
+    const int px_shift = (per_px & (per_px - 1)) == 0 ? 31 - __clz(per_px) : -1;
+    const int tile_y0 = p0 / a.W, tile_x0 = p0 - tile_y0 * a.W;
 #pragma unroll 1
     for (int item = threadIdx.x; item < items; item += kThreads) {
-        const int px = item / per_px;
+        const int px = px_shift >= 0 ? item >> px_shift : item / per_px;
         const int rem = item - px * per_px;
         const int n = rem / K::LPT;
         const int j = rem - n * K::LPT;      // the LPT lanes of one (pixel, hypothesis) are adjacent lanes
         const int p = p0 + px;
         if (p >= P) continue;                // whole lane groups drop out together
-        const int y = p / a.W, x = p - y * a.W;
+        int y = tile_y0, x = tile_x0 + px;
+        if (a.W >= TILE) {
+            if (x >= a.W) { x -= a.W; ++y; }
+        } else {
+            y = p / a.W; x = p - y * a.W;
+        }
 
         float d;
         if (L.depth) {
@@ -349,15 +359,25 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
     const uint32_t sy = (uint32_t)a.sy, sx = (uint32_t)a.sx;
     const int lane = threadIdx.x & 63;
 
+    // index arithmetic without integer division on the common path (an unsigned division costs ~25 vector instructions,
+    // and these gather kernels are bound by instruction issue): items per pixel is a power of two for the reference's
+    // hypothesis counts, and a tile of 32 consecutive pixels wraps at most one image row when W >= 32
+    const int px_shift = (per_px & (per_px - 1)) == 0 ? 31 - __clz(per_px) : -1;
+    const int tile_y0 = p0 / a.W, tile_x0 = p0 - tile_y0 * a.W;
 #pragma unroll 1
     for (int item = threadIdx.x; item < items; item += kThreads) {
-        const int px = item / per_px;
+        const int px = px_shift >= 0 ? item >> px_shift : item / per_px;
         const int rem = item - px * per_px;
         const int grp = rem / K::LPT;
         const int j = rem - grp * K::LPT;
         const int p = p0 + px;
         if (p >= P) continue;
-        const int y = p / a.W, x = p - y * a.W;
+        int y = tile_y0, x = tile_x0 + px;
+        if (a.W >= TILE) {
+            if (x >= a.W) { x -= a.W; ++y; }
+        } else {
+            y = p / a.W; x = p - y * a.W;
+        }
         float refv[K::VEC];
 #pragma unroll
         for (int c = 0; c < K::VEC; ++c)

@@ -4,23 +4,27 @@
 //   u1 = c1 + deconv3x3 s2 (c2, 32 -> 16)            u0 = c0 + deconv3x3 s2 (u1, 16 -> 8)      y  = conv3x3(u0, 8 -> 1) + bias
 //
 // As six launches (itermvs_conv2d per layer) one CorrNet costs ~55 us at cfg 1 for ~4 us of arithmetic: five launch
-// boundaries and five ramp-ups on maps of 20k pixels.  Here a workgroup owns a 32 x 32 output tile of one map and walks the
-// U-Net with every intermediate in LDS; the halo each layer needs is recomputed (x 45 x 45 -> c0 43 x 43 -> c1 21 x 21 ->
-// c2 10 x 10 -> u1 18 x 18 -> u0 34 x 34 -> y 32 x 32; 1.5x the multiply-adds of the layer-by-layer form), positions
-// outside the image are stored as zeros so every layer sees the zero padding the reference's layer sees.
+// boundaries and five ramp-ups (weight staging, first fetch, drain) on maps of 20k pixels.  Here a workgroup owns a 32 x 32
+// output tile of one map and walks the U-Net with every intermediate in LDS; the halo each layer needs is recomputed
+// (x 45x45 -> c0 43x43 -> c1 21x21 -> c2 10x10 -> u1 18x18 -> u0 34x34 -> y 32x32), positions outside the image are stored
+// as zeros so every layer sees the zero padding the reference's layer sees.
 //
-// Arithmetic: fp32 on the vector ALUs as v_pk_fma_f32 -- a thread owns 1 or 2 pixels and 2 .. 8 output channels in
-// (channel, channel+1) register pairs; the weights of a (input channel, tap) are wave-uniform, reach the SIMD through the
-// scalar cache (s_load) and enter the packed FMA as an SGPR pair, the input value is splat with op_sel.  (The layers with 8
-// output channels would waste half of a 16-wide matrix-core tile, and fp32 MFMA has the vector rate on gfx950 anyway.)
+// Arithmetic: v_mfma_f32_16x16x4_f32 (exact fp32) as implicit GEMMs LDS -> LDS: a wave takes groups of 16 consecutive
+// output positions (row-major over the layer's region), A = the layer's weights staged in LDS in operand order
+// [tap][k-step][q][co], B = the activations read from the channel-planar LDS tile at the tap's displacement, D = 16 output
+// channels x 16 positions.  The transposed convolutions run as four parity classes on the INPUT grid (1, 2, 2 and 4 taps).
+// (A first version on packed vector FMAs with the weights fed through the scalar cache lost to the six-launch form,
+// 68 vs 55 us: a vector FMA needs a fresh weight operand per 128 multiply-adds and neither the scalar cache nor LDS
+// broadcasts deliver that; the matrix core reuses each operand register 16 times.)
 #include "common.hpp"
 
 namespace itermvs {
 
-typedef float v2f __attribute__((ext_vector_type(2)));
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kCnTile = 32;
 constexpr int kCnThreads = 512;
+constexpr int kCnWaves = kCnThreads / 64;
 constexpr int XS = 45, XP = 46;      // region size / LDS row pitch of x
 constexpr int C0S = 43, C0P = 44;    // c0 (later u0 in place, region rows / columns 6 .. 39)
 constexpr int C1S = 21, C1P = 22;    // c1 (later u1 in place, 2 .. 19), half resolution
@@ -28,16 +32,19 @@ constexpr int C2S = 10, C2P = 11;    // c2, quarter resolution
 constexpr int kSzX = 8 * XS * XP, kSzC0 = 8 * C0S * C0P, kSzC1 = 16 * C1S * C1P, kSzC2 = 32 * C2S * C2P;
 constexpr int kOffC0 = kSzX, kOffC1 = 0, kOffC2 = kSzC1;      // c1 / c2 reuse the x region once c0 is complete
 static_assert(kSzC1 + kSzC2 <= kSzX, "c1 + c2 must fit the x region");
-constexpr int kCnLdsFloats = kSzX + kSzC0;
-// packed weight set of one CorrNet (floats): see ops.pack_corrnet_weights
-constexpr int kW0 = 0;                         // [ci 8][tap 9][co 8]
-constexpr int kW1 = kW0 + 8 * 9 * 8;           // [ci 8][tap 9][co 16]
-constexpr int kW2 = kW1 + 8 * 9 * 16;          // [ci 16][tap 9][co 32]
-constexpr int kW3 = kW2 + 16 * 9 * 32;         // deconv [ci 32][ky 3][kx 3][co 16]
-constexpr int kW4 = kW3 + 32 * 9 * 16;         // deconv [ci 16][ky 3][kx 3][co 8]
-constexpr int kW5 = kW4 + 16 * 9 * 8;          // [ci 8][tap 9] (co = 1)
+constexpr int kOffW = kSzX + kSzC0;                           // the current layer's weights
+constexpr int kSzW = 4608;
+constexpr int kCnLdsFloats = kOffW + kSzW;
+// packed weight set of one CorrNet (floats), every layer in MFMA operand order [tap][k-step][q][co padded to 16 / 32]:
+// see ops.pack_corrnet_weights
+constexpr int kW0 = 0;                         // conv0: 9 x 2 x 4 x 16
+constexpr int kW1 = kW0 + 9 * 2 * 4 * 16;      // conv1: 9 x 2 x 4 x 16
+constexpr int kW2 = kW1 + 9 * 2 * 4 * 16;      // conv2: 9 x 4 x 4 x 32
+constexpr int kW3 = kW2 + 9 * 4 * 4 * 32;      // conv3 (transposed): 9 x 8 x 4 x 16
+constexpr int kW4 = kW3 + 9 * 8 * 4 * 16;      // conv4 (transposed): 9 x 4 x 4 x 16
+constexpr int kW5 = kW4 + 9 * 4 * 4 * 16;      // conv5: [ci 8][tap 9], then the bias
 constexpr int kWBias = kW5 + 72;
-constexpr int kCnWeightFloats = kWBias + 4;
+constexpr int kCnWeightFloats = kWBias + 8;
 
 struct CorrNetArgs {
     const float* x;
@@ -49,8 +56,111 @@ struct CorrNetArgs {
     int M, H, W, tiles_x;
 };
 
-__device__ __forceinline__ v2f splat(float v) { return v2f{v, v}; }
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// the next layer's weights: global -> registers now, registers -> LDS once the current layer is done with the buffer
+template <int N>
+struct WeightStage {
+    static constexpr int PER = (N + kCnThreads - 1) / kCnThreads;
+    float r[PER];
+    __device__ __forceinline__ void fetch(const float* __restrict__ src, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) r[i] = tid + i * kCnThreads < N ? src[tid + i * kCnThreads] : 0.0f;
+    }
+    __device__ __forceinline__ void commit(float* __restrict__ dst, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if (tid + i * kCnThreads < N) dst[tid + i * kCnThreads] = r[i];
+    }
+};
+
+// 3x3 convolution LDS -> LDS on the matrix cores.  In: [CIN][INS][INP] region whose (0,0) is tap (0,0) of output (0,0)
+// (stride S); Out: [COUT][OUTS][OUTP]; Wl: [9][CIN/4][4][MB*16].  Output position (oy, ox) has image coordinates
+// (gy0 + oy, gx0 + ox) at this layer's resolution; outside [0,imgH) x [0,imgW) a zero is stored.
+template <int CIN, int COUT, int MB, int S, int INS, int INP, int OUTS, int OUTP>
+__device__ __forceinline__ void conv_layer(const float* __restrict__ In, float* __restrict__ Out, const float* __restrict__ Wl,
+                                           int gy0, int gx0, int imgH, int imgW, int wave, int lane) {
+    constexpr int KS = CIN / 4, NPOS = OUTS * OUTS, GROUPS = (NPOS + 15) / 16;
+    const int q = lane >> 4, l16 = lane & 15;
+    for (int g = wave; g < GROUPS; g += kCnWaves) {
+        const int pos = g * 16 + l16;
+        const int pc = pos < NPOS ? pos : NPOS - 1;          // surplus lanes recompute the last position, never store
+        const int oy = pc / OUTS, ox = pc - oy * OUTS;
+        f32x4 acc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float* __restrict__ bp = In + (q * INS + oy * S) * INP + ox * S;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float b = bp[(ks * 4 * INS + ky) * INP + kx];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[((tap * KS + ks) * 4 + q) * (MB * 16) + mb * 16 + l16], b, acc[mb], 0, 0, 0);
+            }
+        }
+        const int gy = gy0 + oy, gx = gx0 + ox;
+        const bool inside = gy >= 0 && gy < imgH && gx >= 0 && gx < imgW;
+        if (pos < NPOS) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = mb * 16 + q * 4 + r;
+                    if (co < COUT) Out[(co * OUTS + oy) * OUTP + ox] = inside ? fmaxf(acc[mb][r], 0.0f) : 0.0f;
+                }
+        }
+    }
+}
+
+// ConvTranspose2d(3, stride 2, pad 1, out_pad 1) + skip, LDS -> LDS in place: out[o] = sum_i in[i] w[o - 2i + 1].
+// The output region's origin is an ODD coordinate, so output (2a + py, 2b + px) of the region takes
+//   py = 0: rows a+1 (ky 0) and a (ky 2);  py = 1: row a+1 (ky 1)           -- same for columns --
+// i.e. parity class (py, px) is a small convolution on the input grid with (2 - py)(2 - px) taps.  NB x NB blocks; input
+// block (a, b) sits at In[..][a + IO][b + IO], output (o, p) at Skip[..][o + OO][p + OO] (holding the skip tensor, updated
+// in place).  Wl: [9][CIN/4][4][16].
+template <int CIN, int COUT, int NB, int IO, int INS, int INP, int OO, int OUTS, int OUTP>
+__device__ __forceinline__ void deconv_layer(const float* __restrict__ In, float* __restrict__ Skip, const float* __restrict__ Wl,
+                                             int gy0, int gx0, int imgH, int imgW, int wave, int lane) {
+    constexpr int KS = CIN / 4, NPOS = NB * NB, GROUPS = (NPOS + 15) / 16;
+    const int q = lane >> 4, l16 = lane & 15;
+    for (int u = wave; u < GROUPS * 4; u += kCnWaves) {      // unit = (group, parity class); classes of one group on different waves
+        const int g = u >> 2, py = (u >> 1) & 1, px = u & 1;
+        const int pos = g * 16 + l16;
+        const int pc = pos < NPOS ? pos : NPOS - 1;
+        const int ba = pc / NB, bb = pc - ba * NB;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* __restrict__ bp = In + (q * INS + ba + IO) * INP + bb + IO;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                // input (a + dy, b + dx) reaches output row parity py through ky: dy = 1 -> ky = py (0 or 1), dy = 0 -> ky = 2 (py = 0 only)
+                const bool used = (dy == 1 || py == 0) && (dx == 1 || px == 0);      // wave-uniform
+                if (used) {
+                    const int ky = dy == 1 ? py : 2, kx = dx == 1 ? px : 2;
+                    const int tap = ky * 3 + kx;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[((tap * KS + ks) * 4 + q) * 16 + l16],
+                                                                   bp[(ks * 4 * INS + dy) * INP + dx], acc, 0, 0, 0);
+                }
+            }
+        const int o = 2 * ba + py, p = 2 * bb + px;
+        const int gy = gy0 + o, gx = gx0 + p;
+        const bool inside = gy >= 0 && gy < imgH && gx >= 0 && gx < imgW;
+        if (pos < NPOS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = q * 4 + r;
+                if (co < COUT) {
+                    float* __restrict__ d = Skip + (co * OUTS + o + OO) * OUTP + p + OO;
+                    *d = inside ? *d + acc[r] : 0.0f;
+                }
+            }
+        }
+    }
+}
 
 __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -58,6 +168,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
     float* __restrict__ C0 = lds + kOffC0;
     float* __restrict__ C1 = lds + kOffC1;
     float* __restrict__ C2 = lds + kOffC2;
+    float* __restrict__ WL = lds + kOffW;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int m = blockIdx.y;
@@ -66,7 +177,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
     const float* __restrict__ wt = a.w[m < a.seg_end[0] ? 0 : (m < a.seg_end[1] ? 1 : 2)];
     const int H = a.H, W = a.W, H2 = H >> 1, W2 = W >> 1, H4 = H >> 2, W4 = W >> 2;
 
-    // ---- x tile (+8 / +12 halo) -> LDS, zeros outside the image and in the pad column ----
+    // ---- x tile (+8 / +12 halo) and conv0's weights -> LDS; zeros outside the image and in the pad column ----
     {
         const float* __restrict__ xm = a.x + (int64_t)m * a.x_sn;
         for (int i = tid; i < kSzX; i += kCnThreads) {
@@ -76,196 +187,50 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
             const bool ok = rx < XS && gy >= 0 && gy < H && gx >= 0 && gx < W;
             X[i] = ok ? xm[(int64_t)ci * H * W + gy * W + gx] : 0.0f;
         }
+        for (int i = tid; i < kW1 - kW0; i += kCnThreads) WL[i] = wt[kW0 + i];
     }
     __syncthreads();
-
-    // ---- c0 = relu(conv(x)): 43 x 43, a thread owns 2 neighbouring pixels x 8 channels ----
-    for (int item = tid; item < C0S * 22; item += kCnThreads) {
-        const int oy = item / 22, ox = (item - oy * 22) * 2;
-        v2f acc[2][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[0][k] = acc[1][k] = v2f{0.0f, 0.0f};
-#pragma unroll
-        for (int ci = 0; ci < 8; ++ci)
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const float* __restrict__ row = X + (ci * XS + oy + ky) * XP + ox;
-                const float in[4] = {row[0], row[1], row[2], row[3]};
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const v2f* __restrict__ w = reinterpret_cast<const v2f*>(wt + kW0 + (ci * 9 + ky * 3 + kx) * 8);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        acc[0][k] = pk_fma(w[k], splat(in[kx]), acc[0][k]);
-                        acc[1][k] = pk_fma(w[k], splat(in[kx + 1]), acc[1][k]);
-                    }
-                }
-            }
-        const int gy = Y0 - 7 + oy, gx = X0 - 7 + ox;
-        const bool iny = gy >= 0 && gy < H;
-        const bool in0 = iny && gx >= 0 && gx < W, in1 = iny && gx + 1 >= 0 && gx + 1 < W && ox + 1 < C0S;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float* __restrict__ o = C0 + ((2 * k + h) * C0S + oy) * C0P + ox;
-                o[0] = in0 ? fmaxf(acc[0][k][h], 0.0f) : 0.0f;
-                o[1] = in1 ? fmaxf(acc[1][k][h], 0.0f) : 0.0f;      // (ox + 1 == 43 lands in the pad column)
-            }
+    {   // c0 = relu(conv(x)): 43 x 43
+        WeightStage<kW2 - kW1> nw;
+        nw.fetch(wt + kW1, tid);
+        conv_layer<8, 8, 1, 1, XS, XP, C0S, C0P>(X, C0, WL, Y0 - 7, X0 - 7, H, W, wave, lane);
+        __syncthreads();
+        nw.commit(WL, tid);
     }
     __syncthreads();
-
-    // ---- c1 = relu(conv s2 (c0)): 21 x 21 at half resolution, a thread owns 1 pixel x 16 channels ----
-    if (tid < C1S * C1S) {
-        const int oy = tid / C1S, ox = tid - oy * C1S;
-        v2f acc[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = v2f{0.0f, 0.0f};
-#pragma unroll
-        for (int ci = 0; ci < 8; ++ci)
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const float* __restrict__ row = C0 + (ci * C0S + 2 * oy + ky) * C0P + 2 * ox;
-                const float in[3] = {row[0], row[1], row[2]};
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const v2f* __restrict__ w = reinterpret_cast<const v2f*>(wt + kW1 + (ci * 9 + ky * 3 + kx) * 16);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[k] = pk_fma(w[k], splat(in[kx]), acc[k]);
-                }
-            }
-        const int gy = (Y0 >> 1) - 3 + oy, gx = (X0 >> 1) - 3 + ox;
-        const bool ok = gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) C1[((2 * k + h) * C1S + oy) * C1P + ox] = ok ? fmaxf(acc[k][h], 0.0f) : 0.0f;
+    {   // c1 = relu(conv s2 (c0)): 21 x 21 at half resolution (over the x region)
+        WeightStage<kW3 - kW2> nw;
+        nw.fetch(wt + kW2, tid);
+        conv_layer<8, 16, 1, 2, C0S, C0P, C1S, C1P>(C0, C1, WL, (Y0 >> 1) - 3, (X0 >> 1) - 3, H2, W2, wave, lane);
+        __syncthreads();
+        nw.commit(WL, tid);
     }
     __syncthreads();
-
-    // ---- c2 = relu(conv s2 (c1)): 10 x 10 at quarter resolution; waves 2c, 2c+1 own channels 8c .. 8c+7 ----
-    {
-        const int chunk = wave >> 1, idx = (wave & 1) * 64 + lane;
-        if (idx < C2S * C2S) {
-            const int oy = idx / C2S, ox = idx - oy * C2S;
-            v2f acc[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = v2f{0.0f, 0.0f};
-#pragma unroll 4
-            for (int ci = 0; ci < 16; ++ci)
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const float* __restrict__ row = C1 + (ci * C1S + 2 * oy + ky) * C1P + 2 * ox;
-                    const float in[3] = {row[0], row[1], row[2]};
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const v2f* __restrict__ w = reinterpret_cast<const v2f*>(wt + kW2 + (ci * 9 + ky * 3 + kx) * 32 + chunk * 8);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) acc[k] = pk_fma(w[k], splat(in[kx]), acc[k]);
-                    }
-                }
-            const int gy = (Y0 >> 2) - 1 + oy, gx = (X0 >> 2) - 1 + ox;
-            const bool ok = gy >= 0 && gy < H4 && gx >= 0 && gx < W4;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) C2[((chunk * 8 + 2 * k + h) * C2S + oy) * C2P + ox] = ok ? fmaxf(acc[k][h], 0.0f) : 0.0f;
-        }
+    {   // c2 = relu(conv s2 (c1)): 10 x 10 at quarter resolution
+        WeightStage<kW4 - kW3> nw;
+        nw.fetch(wt + kW3, tid);
+        conv_layer<16, 32, 2, 2, C1S, C1P, C2S, C2P>(C1, C2, WL, (Y0 >> 2) - 1, (X0 >> 2) - 1, H4, W4, wave, lane);
+        __syncthreads();
+        nw.commit(WL, tid);
     }
     __syncthreads();
-
-    // ---- u1 = c1 + deconv(c2): 18 x 18 (c1 rows / columns 2 .. 19), in place.  ConvTranspose2d(3, stride 2, pad 1, out_pad 1):
-    //      out[o] = sum_i in[i] w[o - 2i + 1].  A thread owns the 2 x 2 output block (2a, 2b) .. (2a+1, 2b+1) of the region (whose
-    //      origin is an odd coordinate) and 4 channels; it needs in[a .. a+1][b .. b+1]:
-    //        (2a  , 2b  ) = in11 w00 + in10 w02 + in01 w20 + in00 w22        (2a  , 2b+1) = in11 w01 + in01 w21
-    //        (2a+1, 2b  ) = in11 w10 + in10 w12                              (2a+1, 2b+1) = in11 w11
-    //      waves 2c, 2c+1 own channels 4c .. 4c+3 ----
-    {
-        const int chunk = wave >> 1, idx = (wave & 1) * 64 + lane;
-        if (idx < 81) {
-            const int ba = idx / 9, bb = idx - ba * 9;
-            v2f ee[2], eo[2], oe[2], oo[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) ee[k] = eo[k] = oe[k] = oo[k] = v2f{0.0f, 0.0f};
-#pragma unroll 4
-            for (int ci = 0; ci < 32; ++ci) {
-                const float* __restrict__ p = C2 + (ci * C2S + ba) * C2P + bb;
-                const float in00 = p[0], in01 = p[1], in10 = p[C2P], in11 = p[C2P + 1];
-                const v2f* __restrict__ w = reinterpret_cast<const v2f*>(wt + kW3 + ci * 9 * 16 + chunk * 4);   // [tap][16 co]: tap stride 8 v2f
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    ee[k] = pk_fma(w[0 * 8 + k], splat(in11), ee[k]);
-                    ee[k] = pk_fma(w[2 * 8 + k], splat(in10), ee[k]);
-                    ee[k] = pk_fma(w[6 * 8 + k], splat(in01), ee[k]);
-                    ee[k] = pk_fma(w[8 * 8 + k], splat(in00), ee[k]);
-                    eo[k] = pk_fma(w[1 * 8 + k], splat(in11), eo[k]);
-                    eo[k] = pk_fma(w[7 * 8 + k], splat(in01), eo[k]);
-                    oe[k] = pk_fma(w[3 * 8 + k], splat(in11), oe[k]);
-                    oe[k] = pk_fma(w[5 * 8 + k], splat(in10), oe[k]);
-                    oo[k] = pk_fma(w[4 * 8 + k], splat(in11), oo[k]);
-                }
-            }
-            const int gy = (Y0 >> 1) - 1 + 2 * ba, gx = (X0 >> 1) - 1 + 2 * bb;
-            const bool y0 = gy >= 0 && gy < H2, y1 = gy + 1 >= 0 && gy + 1 < H2;
-            const bool x0 = gx >= 0 && gx < W2, x1 = gx + 1 >= 0 && gx + 1 < W2;
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float* __restrict__ o = C1 + ((chunk * 4 + 2 * k + h) * C1S + 2 * ba + 2) * C1P + 2 * bb + 2;
-                    o[0] = (y0 && x0) ? o[0] + ee[k][h] : 0.0f;
-                    o[1] = (y0 && x1) ? o[1] + eo[k][h] : 0.0f;
-                    o[C1P] = (y1 && x0) ? o[C1P] + oe[k][h] : 0.0f;
-                    o[C1P + 1] = (y1 && x1) ? o[C1P + 1] + oo[k][h] : 0.0f;
-                }
-        }
+    {   // u1 = c1 + deconv(c2): 18 x 18 = c1 rows / columns 2 .. 19, in place
+        WeightStage<kW5 - kW4> nw;
+        nw.fetch(wt + kW4, tid);
+        deconv_layer<32, 16, 9, 0, C2S, C2P, 2, C1S, C1P>(C2, C1, WL, (Y0 >> 1) - 1, (X0 >> 1) - 1, H2, W2, wave, lane);
+        __syncthreads();
+        nw.commit(WL, tid);
     }
     __syncthreads();
-
-    // ---- u0 = c0 + deconv(u1): 34 x 34 (c0 rows / columns 6 .. 39), in place; a thread owns one 2 x 2 block x 8 channels ----
-    if (tid < 17 * 17) {
-        const int ba = tid / 17, bb = tid - ba * 17;
-        v2f ee[4], eo[4], oe[4], oo[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ee[k] = eo[k] = oe[k] = oo[k] = v2f{0.0f, 0.0f};
-#pragma unroll 2
-        for (int ci = 0; ci < 16; ++ci) {
-            const float* __restrict__ p = C1 + (ci * C1S + ba + 2) * C1P + bb + 2;
-            const float in00 = p[0], in01 = p[1], in10 = p[C1P], in11 = p[C1P + 1];
-            const v2f* __restrict__ w = reinterpret_cast<const v2f*>(wt + kW4 + ci * 9 * 8);   // [tap][8 co]: tap stride 4 v2f
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                ee[k] = pk_fma(w[0 * 4 + k], splat(in11), ee[k]);
-                ee[k] = pk_fma(w[2 * 4 + k], splat(in10), ee[k]);
-                ee[k] = pk_fma(w[6 * 4 + k], splat(in01), ee[k]);
-                ee[k] = pk_fma(w[8 * 4 + k], splat(in00), ee[k]);
-                eo[k] = pk_fma(w[1 * 4 + k], splat(in11), eo[k]);
-                eo[k] = pk_fma(w[7 * 4 + k], splat(in01), eo[k]);
-                oe[k] = pk_fma(w[3 * 4 + k], splat(in11), oe[k]);
-                oe[k] = pk_fma(w[5 * 4 + k], splat(in10), oe[k]);
-                oo[k] = pk_fma(w[4 * 4 + k], splat(in11), oo[k]);
-            }
-        }
-        const int gy = Y0 - 1 + 2 * ba, gx = X0 - 1 + 2 * bb;
-        const bool y0 = gy >= 0 && gy < H, y1 = gy + 1 >= 0 && gy + 1 < H;
-        const bool x0 = gx >= 0 && gx < W, x1 = gx + 1 >= 0 && gx + 1 < W;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float* __restrict__ o = C0 + ((2 * k + h) * C0S + 2 * ba + 6) * C0P + 2 * bb + 6;
-                o[0] = (y0 && x0) ? o[0] + ee[k][h] : 0.0f;
-                o[1] = (y0 && x1) ? o[1] + eo[k][h] : 0.0f;
-                o[C0P] = (y1 && x0) ? o[C0P] + oe[k][h] : 0.0f;
-                o[C0P + 1] = (y1 && x1) ? o[C0P + 1] + oo[k][h] : 0.0f;
-            }
-    }
+    // u0 = c0 + deconv(u1): 34 x 34 = c0 rows / columns 6 .. 39, in place
+    deconv_layer<16, 8, 17, 2, C1S, C1P, 6, C0S, C0P>(C1, C0, WL, Y0 - 1, X0 - 1, H, W, wave, lane);
     __syncthreads();
 
-    // ---- y = conv(u0, 8 -> 1) + bias: 32 x 32, a thread owns 2 neighbouring pixels ----
+    // ---- y = conv(u0, 8 -> 1) + bias on the vector ALUs: 32 x 32, a thread owns 2 neighbouring pixels; the 72 weights are
+    //      wave-uniform (scalar loads) ----
     {
         const int oy = tid >> 4, ox = (tid & 15) * 2;
-        v2f acc = splat(wt[kWBias]);
+        float y0 = wt[kWBias], y1 = y0;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
@@ -273,17 +238,21 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
                 const float* __restrict__ row = C0 + (ci * C0S + oy + ky + 6) * C0P + ox + 6;
                 const float in[4] = {row[0], row[1], row[2], row[3]};
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc = pk_fma(splat(wt[kW5 + ci * 9 + ky * 3 + kx]), v2f{in[kx], in[kx + 1]}, acc);
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float wv = wt[kW5 + ci * 9 + ky * 3 + kx];
+                    y0 = fmaf(wv, in[kx], y0);
+                    y1 = fmaf(wv, in[kx + 1], y1);
+                }
             }
         const int gy = Y0 + oy, gx = X0 + ox;
         if (gy < H) {
             float* __restrict__ o = a.out + (int64_t)m * a.out_sn + gy * W + gx;
-            if (gx < W) o[0] = acc[0];
-            if (gx + 1 < W) o[1] = acc[1];
+            if (gx < W) o[0] = y0;
+            if (gx + 1 < W) o[1] = y1;
             if (a.out2) {
                 float* __restrict__ o2 = a.out2 + (int64_t)m * a.out2_sn + gy * W + gx;
-                if (gx < W) o2[0] = acc[0];
-                if (gx + 1 < W) o2[1] = acc[1];
+                if (gx < W) o2[0] = y0;
+                if (gx + 1 < W) o2[1] = y1;
             }
         }
     }

@@ -612,7 +612,7 @@ extern "C" int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_
     if (!(form && form[0] == 'w')) {
         static const int cus = [] {
             int dev = 0, n = 256;
-            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
             return n > 0 ? n : 256;
         }();
         const int tiles = a.tiles_x * H * B;

@@ -740,21 +740,28 @@ def fuse_depth(depth_ref: Tensor, conf_ref: Tensor, depth_src: Sequence[Tensor],
     return avg, photo, geo, final, cnt
 
 
-CORRNET_WEIGHT_FLOATS = 12172
+CORRNET_WEIGHT_FLOATS = 13904
+
+
+def _mfma_operand_order(w_tap_ci_co: Tensor, co_pad: int) -> Tensor:
+    """[9, Cin, Cout] -> [9][Cin/4][4][co_pad] (zero padded): the A-operand order of v_mfma_f32_16x16x4_f32 in itermvs_corrnet"""
+    taps, cin, cout = w_tap_ci_co.shape
+    out = torch.zeros((taps, cin // 4, 4, co_pad), device=w_tap_ci_co.device, dtype=torch.float32)
+    out[..., :cout] = w_tap_ci_co.reshape(taps, cin // 4, 4, cout)
+    return out.reshape(-1)
 
 
 def pack_corrnet_weights(w: Dict[str, Tensor], prefix: str) -> Tensor:
     """the six layers of one CorrNet (state-dict names ``prefix`` + conv0.conv.weight ... conv5.bias) in the layout of
-    itermvs_corrnet: input channel outermost, output channel innermost, so the weights of one (input channel, tap) are one
-    contiguous run the kernel reads through the scalar cache"""
-    parts = [w[prefix + "conv0.conv.weight"].permute(1, 2, 3, 0),      # Conv2d [co,ci,ky,kx] -> [ci,ky,kx,co]
-             w[prefix + "conv1.conv.weight"].permute(1, 2, 3, 0),
-             w[prefix + "conv2.conv.weight"].permute(1, 2, 3, 0),
-             w[prefix + "conv3.weight"].permute(0, 2, 3, 1),           # ConvTranspose2d [ci,co,ky,kx] -> [ci,ky,kx,co]
-             w[prefix + "conv4.weight"].permute(0, 2, 3, 1),
-             w[prefix + "conv5.weight"].permute(1, 2, 3, 0),
-             w[prefix + "conv5.bias"]]
-    flat = torch.cat([t.reshape(-1).float() for t in parts] + [torch.zeros(3, device=parts[0].device)])
+    itermvs_corrnet (include/itermvs_hip.h): the five matrix-core layers in operand order [tap][k-step][q][co], conv5 as
+    [ci][tap], the bias, padding"""
+    conv = lambda name, pad: _mfma_operand_order(w[prefix + name].float().permute(2, 3, 1, 0).reshape(9, w[prefix + name].shape[1], -1), pad)
+    # ConvTranspose2d weights are [ci, co, ky, kx]
+    dconv = lambda name, pad: _mfma_operand_order(w[prefix + name].float().permute(2, 3, 0, 1).reshape(9, w[prefix + name].shape[0], -1), pad)
+    parts = [conv("conv0.conv.weight", 16), conv("conv1.conv.weight", 16), conv("conv2.conv.weight", 32),
+             dconv("conv3.weight", 16), dconv("conv4.weight", 16),
+             w[prefix + "conv5.weight"].float().permute(1, 2, 3, 0).reshape(-1), w[prefix + "conv5.bias"].float().reshape(-1)]
+    flat = torch.cat(parts + [torch.zeros(7, device=parts[0].device)])
     assert flat.numel() == CORRNET_WEIGHT_FLOATS
     return flat.contiguous()
 
@@ -780,14 +787,16 @@ def corrnet(x: Tensor, weight_sets: Sequence[Tensor], seg_end: Sequence[int] = (
     return out
 
 
-def image_pyramid(raw: Tensor, height: int, width: int, all_levels: bool = True) -> Dict[str, Tensor]:
+def image_pyramid(raw: Tensor, height: int, width: int, all_levels: bool = True, out0: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """datasets/dtu_yao_eval.py:61-74 on the GPU: raw [V,Hs,Ws,3] uint8 RGB (device) -> {'level_0': [V,3,H,W] float32 in
     -1..1, resized like cv2.resize(INTER_LINEAR), 'level_1'..'level_3': the reference's lower pyramid levels}"""
     if not raw.is_cuda or raw.dtype != torch.uint8 or raw.dim() != 4 or raw.shape[3] != 3:
         raise RuntimeError("image_pyramid: expected a CUDA uint8 tensor [V,Hs,Ws,3]")
     raw = raw.contiguous()
     v, hs, ws, _ = raw.shape
-    out = {"level_0": torch.empty((v, 3, height, width), device=raw.device, dtype=torch.float32)}
+    if out0 is not None and (tuple(out0.shape) != (v, 3, height, width) or not out0.is_contiguous() or out0.dtype != torch.float32):
+        raise RuntimeError("image_pyramid: out0 must be a contiguous float32 [V,3,H,W] tensor")
+    out = {"level_0": out0 if out0 is not None else torch.empty((v, 3, height, width), device=raw.device, dtype=torch.float32)}
     if all_levels:
         for l in (1, 2, 3):
             out[f"level_{l}"] = torch.empty((v, 3, height >> l, width >> l), device=raw.device, dtype=torch.float32)
