@@ -23,7 +23,10 @@ namespace itermvs {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kCnTile = 32;
-constexpr int kCnThreads = 512;
+#ifndef ITERMVS_CORRNET_THREADS
+#define ITERMVS_CORRNET_THREADS 1024
+#endif
+constexpr int kCnThreads = ITERMVS_CORRNET_THREADS;
 constexpr int kCnWaves = kCnThreads / 64;
 constexpr int XS = 45, XP = 46;      // region size / LDS row pitch of x
 constexpr int C0S = 43, C0P = 44;    // c0 (later u0 in place, region rows / columns 6 .. 39)
@@ -80,6 +83,12 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ In, float* 
                                            int gy0, int gx0, int imgH, int imgW, int wave, int lane) {
     constexpr int KS = CIN / 4, NPOS = OUTS * OUTS, GROUPS = (NPOS + 15) / 16;
     const int q = lane >> 4, l16 = lane & 15;
+    // the A operands (this lane's weight of every (tap, k-step, block)) are the same for every group: read them once
+    float aw[9 * KS * MB];
+#pragma unroll
+    for (int i = 0; i < 9 * KS; ++i)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) aw[i * MB + mb] = Wl[(i * 4 + q) * (MB * 16) + mb * 16 + l16];
     for (int g = wave; g < GROUPS; g += kCnWaves) {
         const int pos = g * 16 + l16;
         const int pc = pos < NPOS ? pos : NPOS - 1;          // surplus lanes recompute the last position, never store
@@ -96,7 +105,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ In, float* 
                 const float b = bp[(ks * 4 * INS + ky) * INP + kx];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
-                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[((tap * KS + ks) * 4 + q) * (MB * 16) + mb * 16 + l16], b, acc[mb], 0, 0, 0);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[(tap * KS + ks) * MB + mb], b, acc[mb], 0, 0, 0);
             }
         }
         const int gy = gy0 + oy, gx = gx0 + ox;
@@ -179,13 +188,18 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
 
     // ---- x tile (+8 / +12 halo) and conv0's weights -> LDS; zeros outside the image and in the pad column ----
     {
+        // one (channel, row) of the region per wave iteration, lanes = columns: no per-element index arithmetic, all of a
+        // wave's loads independent
         const float* __restrict__ xm = a.x + (int64_t)m * a.x_sn;
-        for (int i = tid; i < kSzX; i += kCnThreads) {
-            const int ci = i / (XS * XP), r = i - ci * (XS * XP);
-            const int ry = r / XP, rx = r - ry * XP;
-            const int gy = Y0 - 8 + ry, gx = X0 - 8 + rx;
-            const bool ok = rx < XS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            X[i] = ok ? xm[(int64_t)ci * H * W + gy * W + gx] : 0.0f;
+        const int gx = X0 - 8 + lane;
+        const bool okx = lane < XS && gx >= 0 && gx < W;
+#pragma unroll 4
+        for (int r = wave; r < 8 * XS; r += kCnWaves) {
+            const int ci = r / XS, ry = r - ci * XS;             // wave-uniform
+            const int gy = Y0 - 8 + ry;
+            const bool ok = okx && gy >= 0 && gy < H;
+            const float v = ok ? xm[(int64_t)ci * H * W + gy * W + gx] : 0.0f;
+            if (lane < XP) X[r * XP + lane] = v;
         }
         for (int i = tid; i < kW1 - kW0; i += kCnThreads) WL[i] = wt[kW0 + i];
     }
@@ -228,7 +242,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
 
     // ---- y = conv(u0, 8 -> 1) + bias on the vector ALUs: 32 x 32, a thread owns 2 neighbouring pixels; the 72 weights are
     //      wave-uniform (scalar loads) ----
-    {
+    if (tid < 512) {
         const int oy = tid >> 4, ox = (tid & 15) * 2;
         float y0 = wt[kWBias], y1 = y0;
 #pragma unroll
