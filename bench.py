@@ -256,8 +256,8 @@ def main() -> None:
     # HIP-event pairs around the fused kernels' launches (on their launch stream).  Graph mode: external
     # event-record nodes captured with the launches (enabled BEFORE the capture below); eager mode: plain records.
     per_step = args.iters + 1
-    # (graph mode: an event-record node costs ~5 us of graph time, so runner A carries them around corr_init and the even
-    # GRU iterations' corr_iter, runner B around the odd iterations' corr_iter)
+    # (graph mode: an event-record node costs ~5-6 us of graph time on either side of the launch it brackets, so each replay
+    # carries ONE timed launch: runner A a corr_iter (GRU iteration 1), runner B the corr_init)
     ops.profile_enable((args.steps + args.warmup) * per_step + 8 * per_step, mask=0x3)
     for k in range(n_models):                          # set-up, not a step: capture every runner's hipGraph
         with torch.cuda.stream(streams[k]):
@@ -266,8 +266,8 @@ def main() -> None:
                 # runner B on 1, 3, ... -- every iteration position is sampled in every second replay
                 from itermvs_amd.engine import InferenceEngine
                 models[k]._engine = InferenceEngine(models[k].weights(), models[k].iteration, args.feature_dtype)
-                models[k]._engine.profile_iterations = set(range(k % 2, args.iters, 2))
-                models[k]._engine.profile_init = (k % 2 == 0)
+                models[k]._engine.profile_iterations = {min(1, args.iters - 1)} if k % 2 == 0 else set()
+                models[k]._engine.profile_init = (k % 2 == 1)
             models[k](*samples[0])
     torch.cuda.synchronize()
     ops.profile_collect(max_samples=4096)              # drop the set-up launches' samples
@@ -295,8 +295,10 @@ def main() -> None:
         roofline = {"bound": "hbm", "kernel": f"itermvs_corr_iter ({kernel_name})", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": b_iter, "avg_launch_ms": avg_ms, "launches_timed": len(t_iter),
-                    "timing": ("external hipEvent record nodes around the launch inside the replayed hipGraph, every replay of "
-                               "the timed region read; the two alternating runners carry the nodes on even / odd GRU iterations" if ab == 2 else "hipEvent pairs on the launch stream inside the timed region")}
+                    "timing": ("external hipEvent record nodes around the launch inside the replayed hipGraph, read for every replay "
+                               "of the timed region; of the two alternating runners one brackets the corr_iter launch of GRU "
+                               "iteration 1, the other the corr_init launch (one timed launch per replay keeps the ~12 us a "
+                               "bracket costs out of most of the step)" if ab == 2 else "hipEvent pairs on the launch stream inside the timed region")}
         # HBM bytes per launch: rocprofv3 --pmc passes of THIS command (tools/pmc_kernels.sh -> tools/pmc_summary.py ->
         # profiles/<round>_pmc_kernels.json); taken only if the summary names the kernel that ran here and the same workload
         pmc_file = os.path.join(ROOT, "profiles", PMC_SUMMARY)

@@ -230,6 +230,29 @@ __device__ __forceinline__ void conv_epilogue_nhwc(const EpilogueArgs& e, const 
     }
 }
 
+// act 6 -- a 1x1 convolution to ONE channel folded into the epilogue of a 16-channel layer (PixelViewWeight, itermvs.py:
+// 337-346: conv3x3 8 -> 16, ReLU, conv1x1 16 -> 1): out[p] = sum_co relu(acc[co][p]) * w[co] + w[16].  A lane holds channels
+// q*4 .. q*4+3 of its pixel: four FMAs, then the four q-lanes of the pixel are added with two xor-shuffles and lane q = 0
+// stores ONE value -- the 16-channel tensor (42 MB at cfg 1) is never written.  `aux1` = the 17 floats {w[0..15], bias}.
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_dot(const EpilogueArgs& e, const f32x4 (&acc)[MB][NB], int q,
+                                                  const uint32_t (&pix_off)[NB]) {
+    const __amdgpu_buffer_rsrc_t ro = epi_rsrc(e.out, (uint32_t)e.P * 4u);
+    float wv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wv[r] = e.aux1[q * 4 + r];
+    const float bias = e.aux1[16];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        float s = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s = fmaf(fmaxf(acc[0][nb][r], 0.0f), wv[r], s);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        epi_store(s + bias, ro, q == 0 ? pix_off[nb] : kEpiOob, 0);
+    }
+}
+
 // The optional residual operand is a template parameter as well: a run-time `if (add)` around its loads
 // makes the compiler wait for vmcnt(0) in front of EVERY pixel slot -- i.e. for the previous slot's stores.
 // py / px: output coordinates of this lane's pixel per slot (only read by the bilinear residual).
@@ -237,6 +260,7 @@ template <int MB, int NB>
 __device__ __forceinline__ void conv_epilogue(const EpilogueArgs& e, const f32x4 (&acc)[MB][NB], int m0, int q,
                                               const uint32_t (&pix_off)[NB], const int (&py)[NB], const int (&px)[NB]) {
     if (e.out_nhwc) return conv_epilogue_nhwc<MB, NB>(e, acc, m0, q, pix_off);
+    if (e.act == 6) return conv_epilogue_dot<MB, NB>(e, acc, q, pix_off);
     const int key = e.act * 3 + (e.add ? 1 + e.add_mode : 0);
     switch (key) {
         case 0: conv_epilogue_act<0, 0, MB, NB>(e, acc, m0, q, pix_off, py, px); break;

@@ -110,6 +110,8 @@ class InferenceEngine:
                 pk[k] = ops.MfmaWeight(v, transposed=True)
             else:
                 pk[k] = pack(v)
+        pv = "iter_mvs.evaluation.pixel_view_weight.conv.1."
+        self.pvw_dot = torch.cat([w[pv + "weight"].reshape(-1), w[pv + "bias"].reshape(-1)]).float().contiguous()
         self.corrnet_w = {l: ops.pack_corrnet_weights(w, f"iter_mvs.evaluation.corr_conv1.{l - 1}.") for l in (1, 2, 3)}
         dh = "iter_mvs.update.depth_head."
         self.head_w1, self.head_w2 = ops.pack_head_weights(w[dh + "2.weight"], w[dh + "4.weight"])
@@ -230,8 +232,10 @@ class InferenceEngine:
         w = self.w
         corr_v = ops.corr_init(src3, ref3, proj3, inv_min, inv_max, INIT_SAMPLES, timed=self.profile_init)   # [B,S,32,8,h3,w3]
         pv = "iter_mvs.evaluation.pixel_view_weight."
-        x = self._conv(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), pv + "conv.0.conv.", act="relu")
-        vw = ops.pvw_tail(x, w[pv + "conv.1.weight"], w[pv + "conv.1.bias"], INIT_SAMPLES)        # 1x1 + softmax + max
+        # PixelViewWeight (itermvs.py:333-350): 3x3 layer with ReLU and the 1x1 layer to one channel in its epilogue (the
+        # 16-channel tensor is never stored), then softmax over the 32 hypotheses and its maximum
+        logit = self._conv(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), pv + "conv.0.conv.", act="relu_dot", aux1=self.pvw_dot)
+        vw = ops.softmax_max(logit.view(b * s, INIT_SAMPLES, h3, w3))
         view_w = ops.bilinear_up(vw, 2).view(b, s, 2 * h3, 2 * w3)                                 # itermvs.py:56-57,71
         agg0 = ops.view_aggregate(corr_v, vw.view(b, s, h3, w3))                                   # [B,32,8,h3,w3]
         score0 = self.stage_score0(agg0)

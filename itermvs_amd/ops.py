@@ -567,7 +567,7 @@ def bilinear_up(x: Tensor, scale: int, act: str = "none") -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------
-ACT = {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "gru_rh": 4, "gru_out": 5}
+ACT = {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "gru_rh": 4, "gru_out": 5, "relu_dot": 6}
 
 
 def pack_conv_weight(w: Tensor, transposed: bool = False) -> Tensor:
@@ -655,6 +655,11 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
         span = (ksize - 1) * dilation + 1
         hout, wout = (hin + 2 * pad - span) // stride + 1, (win + 2 * pad - span) // stride + 1
     cout_total = cout
+    dot = None
+    if act == "relu_dot":      # ReLU + a 1x1 convolution to one channel in the epilogue: aux1 = 17 floats {w[16], bias}
+        if not (mfma and tiled and cout == 16 and aux1 is not None and aux1.numel() == 17 and add is None and out2 is None and split is None):
+            raise RuntimeError("conv2d: act='relu_dot' needs a 16-channel 3x3 matrix-core layer and aux1 = 17 floats")
+        dot, aux1, cout = _dev(aux1, "aux1").contiguous(), None, 1
     if split is not None:
         if not (mfma and ksize == 3 and not transposed):
             raise RuntimeError("conv2d: split results need the tiled matrix-core kernel (3x3 MfmaWeight)")
@@ -696,6 +701,8 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     for i, e in enumerate(seg_end):
         p.seg_end[i] = e
     p.N, p.Cin, p.Hin, p.Win, p.Cout = n, cin, hin, win, cout_total
+    if dot is not None:
+        p.aux1, p.aux1_sn = dot.data_ptr(), 0
     if split is not None:
         ob = split[2]
         if tuple(ob.shape) != (n, cout_total - cout, hout, wout):

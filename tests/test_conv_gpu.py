@@ -259,3 +259,18 @@ def test_corrnet_one_launch_matches_torch(case):
         assert torch.equal(wide[0, 33:], got[:, 0]) and torch.equal(wide2, wide) and float(wide[:, :33].abs().max()) == 0.0
     with pytest.raises(RuntimeError):
         ops().corrnet(torch.zeros((1, 8, 6, 8), device=DEV), packs[:1])
+
+
+def test_relu_dot_epilogue_is_conv_relu_conv1x1():
+    """act='relu_dot' (PixelViewWeight, itermvs.py:337-346): conv3x3 8 -> 16, ReLU and the 1x1 layer to one channel in
+    one launch, the 16-channel tensor never stored"""
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn((24, 8, 23, 37), generator=gen).to(DEV)
+    w0 = (torch.randn((16, 8, 3, 3), generator=gen) * 0.2).to(DEV)
+    w1 = torch.randn((1, 16, 1, 1), generator=gen).to(DEV)
+    b1 = torch.randn((1,), generator=gen).to(DEV)
+    want = F.conv2d(F.relu(F.conv2d(x, w0, padding=1)), w1, b1)
+    got = ops().conv2d(x, ops().MfmaWeight(w0), None, act="relu_dot", aux1=torch.cat([w1.reshape(-1), b1]))
+    assert got.shape == want.shape == (24, 1, 23, 37) and rel_err(got, want) <= 2e-6
+    with pytest.raises(RuntimeError):
+        ops().conv2d(x, ops().MfmaWeight(w0), None, act="relu_dot", aux1=w1.reshape(-1))

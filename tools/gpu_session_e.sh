@@ -2,7 +2,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 O=gpurun_out/r2e
-timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_kernels_gpu.py tests/test_teacher_forced_gpu.py tests/test_pipeline_gpu.py -q -s -k "corrnet or head or every_stage or seam or cfg1 or graph" > ${O}_t1.log 2>&1
+timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_kernels_gpu.py tests/test_teacher_forced_gpu.py tests/test_pipeline_gpu.py -q -s -k "corrnet or relu_dot or head or every_stage or seam or cfg1 or graph or pvw" > ${O}_t1.log 2>&1
 ITERMVS_CORRNET=layers timeout 300 python bench.py --steps 50 --minimal > ${O}_bench_layers.json 2> ${O}_bench_layers.err
 timeout 300 python bench.py --steps 50 --minimal > ${O}_bench_fused.json 2> ${O}_bench_fused.err
 cd /tmp && export TMPDIR=/tmp
