@@ -452,6 +452,27 @@ __global__ void view_aggregate_kernel(const float* __restrict__ corr, const floa
 }
 
 // out[m,p] = max_n softmax_n(x[m,n,p])                                        (itermvs.py:347-348)
+// N <= 32 (the reference's 32 initial hypotheses): all logits of a pixel are fetched in one round of loads and reduced in
+// registers; the generic form below walks the hypotheses twice.
+template <int NMAX>
+__global__ void softmax_max_small_kernel(const float* __restrict__ x, int M, int N, int P, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)M * P) return;
+    const int p = (int)(t % P);
+    const int m = (int)(t / P);
+    const float* xp = x + (size_t)m * N * P + p;
+    float v[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) v[n] = n < N ? xp[(size_t)n * P] : -INFINITY;
+    float mx = v[0];
+#pragma unroll
+    for (int n = 1; n < NMAX; ++n) mx = fmaxf(mx, v[n]);
+    float sum = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) sum += expf(v[n] - mx);      // exp(-inf) = 0 for the padding
+    out[t] = 1.0f / sum;       // the largest probability belongs to the largest logit: exp(0) / sum
+}
+
 __global__ void softmax_max_kernel(const float* __restrict__ x, int M, int N, int P, float* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)M * P) return;
@@ -655,7 +676,11 @@ extern "C" int itermvs_softmax_max(const float* x, int32_t M, int32_t N, int32_t
     ITERMVS_RETURN_IF(!x || !out, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(M < 1 || N < 1 || P < 1, ITERMVS_ERR_DIMS);
     const int64_t total = (int64_t)M * P;
-    hipLaunchKernelGGL(softmax_max_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, M,
-                       N, P, out);
+    if (N <= 32)    // 64-thread blocks: the M * P pixels spread over as many CUs as possible
+        hipLaunchKernelGGL(softmax_max_small_kernel<32>, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)stream, x,
+                           M, N, P, out);
+    else
+        hipLaunchKernelGGL(softmax_max_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, M,
+                           N, P, out);
     return itermvs_launch_status();
 }

@@ -145,6 +145,18 @@ __device__ __forceinline__ void up2_axis(int d, int n_in, int& i0, int& i1, floa
     l0 = 1.0f - l1;
 }
 
+// four consecutive channels of one position (16 bytes in fp32, 8 in 16-bit storage when the map is channels-last)
+template <int FT>
+__device__ __forceinline__ void ld4(const itermvs_fmap& f, int b, int c, int y, int x, float (&v)[4]) {
+    const int64_t off = b * f.sb + c * f.sc + y * f.sy + x * f.sx;
+    if (f.sc == 1) {
+        load_feat<4, FT>((const float*)f.data, (uint32_t)off, v);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ld_feat<FT>((const float*)f.data, off + k * f.sc);
+    }
+}
+
 template <int FT>
 __global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fmap r3, int B, float* __restrict__ out) {
     const int H = r2.H, W = r2.W;
@@ -161,23 +173,31 @@ __global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fma
     float v[4];
     if (c < r1.C) {
         // x0.5 bilinear == weights 0.5/0.5 on rows 2y,2y+1 and columns 2x,2x+1
+        float a00[4], a01[4], a10[4], a11[4];
+        ld4<FT>(r1, b, c, 2 * y, 2 * x, a00); ld4<FT>(r1, b, c, 2 * y, 2 * x + 1, a01);
+        ld4<FT>(r1, b, c, 2 * y + 1, 2 * x, a10); ld4<FT>(r1, b, c, 2 * y + 1, 2 * x + 1, a11);
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float top = ld<FT>(r1, b, c + k, 2 * y, 2 * x) * 0.5f + ld<FT>(r1, b, c + k, 2 * y, 2 * x + 1) * 0.5f;
-            const float bot = ld<FT>(r1, b, c + k, 2 * y + 1, 2 * x) * 0.5f + ld<FT>(r1, b, c + k, 2 * y + 1, 2 * x + 1) * 0.5f;
+            const float top = a00[k] * 0.5f + a01[k] * 0.5f;
+            const float bot = a10[k] * 0.5f + a11[k] * 0.5f;
             v[k] = top * 0.5f + bot * 0.5f;
         }
     } else if (c < r1.C + r2.C) {
         c -= r1.C;
-        for (int k = 0; k < 4; ++k) v[k] = ld<FT>(r2, b, c + k, y, x);
+        ld4<FT>(r2, b, c, y, x, v);
     } else {
         c -= r1.C + r2.C;
         int y0, y1, x0, x1;
         float hy0, hy1, hx0, hx1;
         up2_axis(y, r3.H, y0, y1, hy0, hy1);
         up2_axis(x, r3.W, x0, x1, hx0, hx1);
+        float a00[4], a01[4], a10[4], a11[4];
+        ld4<FT>(r3, b, c, y0, x0, a00); ld4<FT>(r3, b, c, y0, x1, a01);
+        ld4<FT>(r3, b, c, y1, x0, a10); ld4<FT>(r3, b, c, y1, x1, a11);
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float top = ld<FT>(r3, b, c + k, y0, x0) * hx0 + ld<FT>(r3, b, c + k, y0, x1) * hx1;
-            const float bot = ld<FT>(r3, b, c + k, y1, x0) * hx0 + ld<FT>(r3, b, c + k, y1, x1) * hx1;
+            const float top = a00[k] * hx0 + a01[k] * hx1;
+            const float bot = a10[k] * hx0 + a11[k] * hx1;
             v[k] = top * hy0 + bot * hy1;
         }
     }
