@@ -304,7 +304,7 @@ def main() -> None:
         pmc_file = os.path.join(ROOT, "profiles", PMC_SUMMARY)
         if os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
-            entry = pmc.get("kernels", {}).get(kernel_name)
+            entry = next((v for k, v in pmc.get("kernels", {}).items() if k.startswith(kernel_name + "<") or k == kernel_name), None)
             if entry and pmc.get("workload") == [args.views, args.height, args.width, args.batch] and "traffic_bytes_per_launch" in entry:
                 roofline["traffic"] = entry["traffic_bytes_per_launch"]
                 roofline["traffic_source"] = f"profiles/{PMC_SUMMARY}: " + pmc["source"]

@@ -32,7 +32,16 @@ constexpr int XS = 45, XP = 46;      // region size / LDS row pitch of x
 constexpr int C0S = 43, C0P = 44;    // c0 (later u0 in place, region rows / columns 6 .. 39)
 constexpr int C1S = 21, C1P = 22;    // c1 (later u1 in place, 2 .. 19), half resolution
 constexpr int C2S = 10, C2P = 11;    // c2, quarter resolution
-constexpr int kSzX = 8 * XS * XP, kSzC0 = 8 * C0S * C0P, kSzC1 = 16 * C1S * C1P, kSzC2 = 32 * C2S * C2P;
+// Channel-plane strides, padded against LDS bank conflicts of the B-operand reads (lane (q, l16) reads channel 4k + q at
+// position l16 * stride): a buffer read at stride 1 wants its planes 16 banks apart (q = 0 / 1 fill the 32 banks of a
+// ds_read_b32 lane group), a buffer read at stride 2 an ODD distance (q = 0 on the even banks, q = 1 on the odd ones).
+// Measured before the padding: 39 % of the kernel's LDS cycles were conflict cycles (profiles/r02_pmc_kernels.json).
+constexpr int XPL = XS * XP + 26;    // 2096 = 16 (mod 32): read at stride 1 by conv0
+constexpr int C0PL = C0S * C0P + 13; // 1905 = 17 (mod 32): read at stride 2 by conv1 (and at stride 1 by conv5)
+constexpr int C1PL = C1S * C1P + 3;  //  465 = 17 (mod 32): read at stride 2 by conv2, at stride 1 by conv4
+constexpr int C2PL = C2S * C2P + 2;  //  112 = 16 (mod 32): read at stride 1 by conv3
+static_assert(XPL % 32 == 16 && C0PL % 32 == 17 && C1PL % 32 == 17 && C2PL % 32 == 16, "plane strides");
+constexpr int kSzX = 8 * XPL, kSzC0 = 8 * C0PL, kSzC1 = 16 * C1PL, kSzC2 = 32 * C2PL;
 constexpr int kOffC0 = kSzX, kOffC1 = 0, kOffC2 = kSzC1;      // c1 / c2 reuse the x region once c0 is complete
 static_assert(kSzC1 + kSzC2 <= kSzX, "c1 + c2 must fit the x region");
 constexpr int kOffW = kSzX + kSzC0;                           // the current layer's weights
@@ -75,10 +84,10 @@ struct WeightStage {
     }
 };
 
-// 3x3 convolution LDS -> LDS on the matrix cores.  In: [CIN][INS][INP] region whose (0,0) is tap (0,0) of output (0,0)
-// (stride S); Out: [COUT][OUTS][OUTP]; Wl: [9][CIN/4][4][MB*16].  Output position (oy, ox) has image coordinates
+// 3x3 convolution LDS -> LDS on the matrix cores.  In: CIN planes of stride INPL, row pitch INP, whose (0,0) is tap (0,0) of
+// output (0,0) (stride S); Out: COUT planes of stride OUTPL, OUTS x OUTS positions at row pitch OUTP; Wl: [9][CIN/4][4][MB*16].  Output position (oy, ox) has image coordinates
 // (gy0 + oy, gx0 + ox) at this layer's resolution; outside [0,imgH) x [0,imgW) a zero is stored.
-template <int CIN, int COUT, int MB, int S, int INS, int INP, int OUTS, int OUTP>
+template <int CIN, int COUT, int MB, int S, int INPL, int INP, int OUTS, int OUTPL, int OUTP>
 __device__ __forceinline__ void conv_layer(const float* __restrict__ In, float* __restrict__ Out, const float* __restrict__ Wl,
                                            int gy0, int gx0, int imgH, int imgW, int wave, int lane) {
     constexpr int KS = CIN / 4, NPOS = OUTS * OUTS, GROUPS = (NPOS + 15) / 16;
@@ -96,13 +105,13 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ In, float* 
         f32x4 acc[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const float* __restrict__ bp = In + (q * INS + oy * S) * INP + ox * S;
+        const float* __restrict__ bp = In + q * INPL + oy * S * INP + ox * S;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const float b = bp[(ks * 4 * INS + ky) * INP + kx];
+                const float b = bp[ks * 4 * INPL + ky * INP + kx];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
                     acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[(tap * KS + ks) * MB + mb], b, acc[mb], 0, 0, 0);
@@ -116,7 +125,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ In, float* 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = mb * 16 + q * 4 + r;
-                    if (co < COUT) Out[(co * OUTS + oy) * OUTP + ox] = inside ? fmaxf(acc[mb][r], 0.0f) : 0.0f;
+                    if (co < COUT) Out[co * OUTPL + oy * OUTP + ox] = inside ? fmaxf(acc[mb][r], 0.0f) : 0.0f;
                 }
         }
     }
@@ -128,7 +137,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ In, float* 
 // i.e. parity class (py, px) is a small convolution on the input grid with (2 - py)(2 - px) taps.  NB x NB blocks; input
 // block (a, b) sits at In[..][a + IO][b + IO], output (o, p) at Skip[..][o + OO][p + OO] (holding the skip tensor, updated
 // in place).  Wl: [9][CIN/4][4][16].
-template <int CIN, int COUT, int NB, int IO, int INS, int INP, int OO, int OUTS, int OUTP>
+template <int CIN, int COUT, int NB, int IO, int INPL, int INP, int OO, int OUTPL, int OUTP>
 __device__ __forceinline__ void deconv_layer(const float* __restrict__ In, float* __restrict__ Skip, const float* __restrict__ Wl,
                                              int gy0, int gx0, int imgH, int imgW, int wave, int lane) {
     constexpr int KS = CIN / 4, NPOS = NB * NB, GROUPS = (NPOS + 15) / 16;
@@ -139,7 +148,7 @@ __device__ __forceinline__ void deconv_layer(const float* __restrict__ In, float
         const int pc = pos < NPOS ? pos : NPOS - 1;
         const int ba = pc / NB, bb = pc - ba * NB;
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float* __restrict__ bp = In + (q * INS + ba + IO) * INP + bb + IO;
+        const float* __restrict__ bp = In + q * INPL + (ba + IO) * INP + bb + IO;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -152,7 +161,7 @@ __device__ __forceinline__ void deconv_layer(const float* __restrict__ In, float
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[((tap * KS + ks) * 4 + q) * 16 + l16],
-                                                                   bp[(ks * 4 * INS + dy) * INP + dx], acc, 0, 0, 0);
+                                                                   bp[ks * 4 * INPL + dy * INP + dx], acc, 0, 0, 0);
                 }
             }
         const int o = 2 * ba + py, p = 2 * bb + px;
@@ -163,7 +172,7 @@ __device__ __forceinline__ void deconv_layer(const float* __restrict__ In, float
             for (int r = 0; r < 4; ++r) {
                 const int co = q * 4 + r;
                 if (co < COUT) {
-                    float* __restrict__ d = Skip + (co * OUTS + o + OO) * OUTP + p + OO;
+                    float* __restrict__ d = Skip + co * OUTPL + (o + OO) * OUTP + p + OO;
                     *d = inside ? *d + acc[r] : 0.0f;
                 }
             }
@@ -199,7 +208,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
             const int gy = Y0 - 8 + ry;
             const bool ok = okx && gy >= 0 && gy < H;
             const float v = ok ? xm[(int64_t)ci * H * W + gy * W + gx] : 0.0f;
-            if (lane < XP) X[r * XP + lane] = v;
+            if (lane < XP) X[ci * XPL + ry * XP + lane] = v;
         }
         for (int i = tid; i < kW1 - kW0; i += kCnThreads) WL[i] = wt[kW0 + i];
     }
@@ -207,7 +216,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
     {   // c0 = relu(conv(x)): 43 x 43
         WeightStage<kW2 - kW1> nw;
         nw.fetch(wt + kW1, tid);
-        conv_layer<8, 8, 1, 1, XS, XP, C0S, C0P>(X, C0, WL, Y0 - 7, X0 - 7, H, W, wave, lane);
+        conv_layer<8, 8, 1, 1, XPL, XP, C0S, C0PL, C0P>(X, C0, WL, Y0 - 7, X0 - 7, H, W, wave, lane);
         __syncthreads();
         nw.commit(WL, tid);
     }
@@ -215,7 +224,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
     {   // c1 = relu(conv s2 (c0)): 21 x 21 at half resolution (over the x region)
         WeightStage<kW3 - kW2> nw;
         nw.fetch(wt + kW2, tid);
-        conv_layer<8, 16, 1, 2, C0S, C0P, C1S, C1P>(C0, C1, WL, (Y0 >> 1) - 3, (X0 >> 1) - 3, H2, W2, wave, lane);
+        conv_layer<8, 16, 1, 2, C0PL, C0P, C1S, C1PL, C1P>(C0, C1, WL, (Y0 >> 1) - 3, (X0 >> 1) - 3, H2, W2, wave, lane);
         __syncthreads();
         nw.commit(WL, tid);
     }
@@ -223,7 +232,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
     {   // c2 = relu(conv s2 (c1)): 10 x 10 at quarter resolution
         WeightStage<kW4 - kW3> nw;
         nw.fetch(wt + kW3, tid);
-        conv_layer<16, 32, 2, 2, C1S, C1P, C2S, C2P>(C1, C2, WL, (Y0 >> 2) - 1, (X0 >> 2) - 1, H4, W4, wave, lane);
+        conv_layer<16, 32, 2, 2, C1PL, C1P, C2S, C2PL, C2P>(C1, C2, WL, (Y0 >> 2) - 1, (X0 >> 2) - 1, H4, W4, wave, lane);
         __syncthreads();
         nw.commit(WL, tid);
     }
@@ -231,13 +240,13 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
     {   // u1 = c1 + deconv(c2): 18 x 18 = c1 rows / columns 2 .. 19, in place
         WeightStage<kW5 - kW4> nw;
         nw.fetch(wt + kW4, tid);
-        deconv_layer<32, 16, 9, 0, C2S, C2P, 2, C1S, C1P>(C2, C1, WL, (Y0 >> 1) - 1, (X0 >> 1) - 1, H2, W2, wave, lane);
+        deconv_layer<32, 16, 9, 0, C2PL, C2P, 2, C1PL, C1P>(C2, C1, WL, (Y0 >> 1) - 1, (X0 >> 1) - 1, H2, W2, wave, lane);
         __syncthreads();
         nw.commit(WL, tid);
     }
     __syncthreads();
     // u0 = c0 + deconv(u1): 34 x 34 = c0 rows / columns 6 .. 39, in place
-    deconv_layer<16, 8, 17, 2, C1S, C1P, 6, C0S, C0P>(C1, C0, WL, Y0 - 1, X0 - 1, H, W, wave, lane);
+    deconv_layer<16, 8, 17, 2, C1PL, C1P, 6, C0PL, C0P>(C1, C0, WL, Y0 - 1, X0 - 1, H, W, wave, lane);
     __syncthreads();
 
     // ---- y = conv(u0, 8 -> 1) + bias on the vector ALUs: 32 x 32, a thread owns 2 neighbouring pixels; the 72 weights are
@@ -249,7 +258,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
         for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const float* __restrict__ row = C0 + (ci * C0S + oy + ky + 6) * C0P + ox + 6;
+                const float* __restrict__ row = C0 + ci * C0PL + (oy + ky + 6) * C0P + ox + 6;
                 const float in[4] = {row[0], row[1], row[2], row[3]};
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {

@@ -6,11 +6,14 @@ published checkpoints work unchanged.  What is inside is new:
 
 * parameters live in a name-addressed tree built from ``schema.state_dict_schema()`` (no
   per-layer Python classes);
-* test mode runs the MI355X engine of ``itermvs_amd.engine`` -- fused HIP kernels through the C
-  ABI for warp+correlation, probability regression, GRU gates and convex up-sampling, MIOpen
-  for the dense 2-D convolutions, BatchNorm folded at load time, all views batched;
-* train mode (``itermvs_amd.train_graph``) is differentiable: HIP warp forward/backward
-  kernels inside ``torch.autograd.Function`` + PyTorch-ROCm autograd for the dense layers.
+* test mode runs the MI355X engine of ``itermvs_amd.engine``: every kernel of a depth map is a
+  hand-written HIP kernel behind the C ABI (fused warp + correlation, matrix-core convolutions with
+  BatchNorm folded at load time and all views batched, CorrNet in one launch, ConvGRU gates in the conv
+  epilogues, the depth head + probability regression in one launch, convex up-sampling), optionally
+  replayed as one hipGraph per depth map;
+* train mode (``itermvs_amd.train_graph``) is differentiable: each ``Evaluation`` call is one
+  ``torch.autograd.Function`` on the fused correlation kernels (forward) and their scatter-add gradient
+  kernel (backward); the dense layers run on PyTorch-ROCm autograd.
 
 There is no CPU path: CPU tensors raise ``RuntimeError`` (the oracle under ``oracle/`` is test
 infrastructure and is never imported from here).
