@@ -363,6 +363,19 @@ int itermvs_corrnet(const float* x, int64_t x_sn, const float* const* weights, c
                     int32_t M, int32_t H, int32_t W, float* out, int64_t out_sn, float* out2, int64_t out2_sn, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * itermvs_stem -- the first two layers of FeatureNet in ONE launch (models/net.py:13-14,39-40; models/module.py:33-50):
+ * FeatureNet.conv1 (ConvBnReLU 3 -> 8) and, from its result without a round trip through HBM, layer1[0].conv1
+ * (ConvBnReLU 8 -> 16, stride 2) and layer1[0].downsample (ConvBn 8 -> 16, stride 2).  BatchNorm folded by the caller.
+ *   x [M,3,H,W] planes (batch stride x_sn);  y = relu(conv1 branch), sc = downsample branch: [M,16,H2,W2] planes at batch
+ *   stride out_sn, H2 = (H-1)/2+1;
+ *   w0: 224 floats = conv1 weight as [ci][ky][kx][co 8] then its 8 biases;
+ *   w1: 2336 floats = the two stride-2 layers' weights, output channels concatenated (conv1 branch first), in matrix-core
+ *   operand order [tap = ky*3+kx][k-step = ci/4][q = ci%4][co 32], then the 32 biases (itermvs_amd.ops.pack_stem_weights).
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
+                 float* y, float* sc, int64_t out_sn, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * itermvs_fuse_depth -- the filter that follows the depth-inference path:
  *   reproject_with_depth (eval.py:154-194), check_geometric_consistency (eval.py:197-212) and the per-reference
  *   arithmetic of filter_depth (eval.py:238-269) for ONE reference view against its S source views, one pass.

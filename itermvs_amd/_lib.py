@@ -109,6 +109,8 @@ PROTOTYPES = {
     "itermvs_conv2d": (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
     "itermvs_corrnet": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "itermvs_stem": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_int64, C.c_void_p]),
     "itermvs_image_pyramid": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] * 5),
     "itermvs_profile_enable": (C.c_int, [C.c_int32]),
     "itermvs_profile_set_mask": (C.c_int, [C.c_int32]),

@@ -17,6 +17,16 @@ static inline int itermvs_launch_status() {
     return hipGetLastError() == hipSuccess ? ITERMVS_OK : ITERMVS_ERR_LAUNCH;
 }
 
+// compute units of the current device (grid size of persistent kernels)
+static inline int itermvs_num_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    return cus;
+}
+
 // timing hooks (profile.cpp)
 void itermvs_profile_begin(int kind, hipStream_t stream);
 void itermvs_profile_end(int kind, hipStream_t stream);

@@ -610,11 +610,7 @@ extern "C" int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_
     // selects the one-tile-per-wave form for A/B measurements
     const char* form = getenv("ITERMVS_HEAD_FORM");
     if (!(form && form[0] == 'w')) {
-        static const int cus = [] {
-            int dev = 0, n = 256;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-            return n > 0 ? n : 256;
-        }();
+        const int cus = itermvs_num_cus();
         const int tiles = a.tiles_x * H * B;
         const int grid = tiles < 2 * cus ? tiles : 2 * cus;
         hipLaunchKernelGGL(head_coop_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles);

@@ -90,6 +90,7 @@ class InferenceEngine:
         self.profile_init = True         # whether the corr_init launch carries timing events (bench.py)
         import os
         self._corrnet_fused = os.environ.get("ITERMVS_CORRNET", "fused") != "layers"
+        self._stem_fused = os.environ.get("ITERMVS_STEM", "fused") != "layers"
         self.pk: Dict[str, object] = {}
         self._pack_weights()
 
@@ -112,6 +113,7 @@ class InferenceEngine:
                 pk[k] = pack(v)
         pv = "iter_mvs.evaluation.pixel_view_weight.conv.1."
         self.pvw_dot = torch.cat([w[pv + "weight"].reshape(-1), w[pv + "bias"].reshape(-1)]).float().contiguous()
+        self.stem_w = ops.pack_stem_weights(*self.cbr["conv1."], *self.cbr["layer1.0.conv1."], *self.cbr["layer1.0.downsample."])
         self.corrnet_w = {l: ops.pack_corrnet_weights(w, f"iter_mvs.evaluation.corr_conv1.{l - 1}.") for l in (1, 2, 3)}
         dh = "iter_mvs.update.depth_head."
         self.head_w1, self.head_w2 = ops.pack_head_weights(w[dh + "2.weight"], w[dh + "4.weight"])
@@ -150,8 +152,11 @@ class InferenceEngine:
                                       memory_format=torch.channels_last)
         o1, o2, o3 = cl(16, 2), cl(32, 4), cl(48, 8)
         self.o2_planar = torch.empty((m, 32, hh // 4, ww // 4), device=dev)
-        f0 = self._cbr(x, "conv1.", 1, "relu")
-        f1 = self._res(self._res(f0, "layer1.0.", 2), "layer1.1.", 1)
+        if self._stem_fused:     # conv1 + layer1[0].conv1 / .downsample in one launch, fea0 never leaves LDS
+            y, sc = ops.stem(x, *self.stem_w)
+            f1 = self._res(self._cbr(y, "layer1.0.conv2.", 1, "relu", add=sc), "layer1.1.", 1)
+        else:
+            f1 = self._res(self._res(self._cbr(x, "conv1.", 1, "relu"), "layer1.0.", 2), "layer1.1.", 1)
         f2 = self._res(self._res(f1, "layer2.0.", 2), "layer2.1.", 1)
         f3 = self._res(self._res(f2, "layer3.0.", 2), "layer3.1.", 1)
         self._conv(f3, p + "output3.", bias=True, channels_last_out=True, out=o3)

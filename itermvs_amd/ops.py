@@ -773,6 +773,40 @@ def pack_corrnet_weights(w: Dict[str, Tensor], prefix: str) -> Tensor:
     return flat.contiguous()
 
 
+STEM_W0_FLOATS, STEM_W1_FLOATS = 224, 2336
+
+
+def pack_stem_weights(w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor, wd: Tensor, bd: Tensor) -> Tuple[Tensor, Tensor]:
+    """weights of itermvs_stem (BatchNorm already folded): FeatureNet.conv1 (w0 [8,3,3,3], b0) as [ci][ky][kx][co] + biases;
+    layer1[0].conv1 (w1 [16,8,3,3], b1) and layer1[0].downsample (wd, bd), output channels concatenated, in matrix-core
+    operand order [tap][k-step][q][co 32] + the 32 biases"""
+    if tuple(w0.shape) != (8, 3, 3, 3) or tuple(w1.shape) != (16, 8, 3, 3) or tuple(wd.shape) != (16, 8, 3, 3):
+        raise RuntimeError("pack_stem_weights: expects conv1 [8,3,3,3] and two stride-2 layers [16,8,3,3]")
+    p0 = torch.cat([w0.float().permute(1, 2, 3, 0).reshape(-1), b0.float().reshape(-1)]).contiguous()
+    wc = torch.cat([w1, wd]).float()                                              # [32, 8, 3, 3]
+    p1 = torch.cat([_mfma_operand_order(wc.permute(2, 3, 1, 0).reshape(9, 8, 32), 32), b1.float().reshape(-1),
+                    bd.float().reshape(-1)]).contiguous()
+    assert p0.numel() == STEM_W0_FLOATS and p1.numel() == STEM_W1_FLOATS
+    return p0, p1
+
+
+def stem(x: Tensor, w0: Tensor, w1: Tensor) -> Tuple[Tensor, Tensor]:
+    """itermvs_stem: x [M,3,H,W] -> (relu(layer1[0].conv1(f0)), layer1[0].downsample(f0)) with f0 = FeatureNet.conv1(x)
+    kept in LDS; both [M,16,H2,W2].  ``w0`` / ``w1`` from pack_stem_weights."""
+    ptr, x_sn = _planes(x, "stem input")
+    m, c, h, w = x.shape
+    if c != 3:
+        raise RuntimeError("stem: expects [M,3,H,W]")
+    if w0.numel() != STEM_W0_FLOATS or w1.numel() != STEM_W1_FLOATS:
+        raise RuntimeError("stem: weights must come from pack_stem_weights")
+    h2, w2 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((m, 16, h2, w2), device=x.device, dtype=torch.float32)
+    sc = torch.empty_like(y)
+    check(_lib.load().itermvs_stem(ptr, x_sn, m, h, w, _dev(w0, "stem weights").data_ptr(), _dev(w1, "stem weights").data_ptr(),
+                             y.data_ptr(), sc.data_ptr(), 16 * h2 * w2, _stream()), "itermvs_stem")
+    return y, sc
+
+
 def corrnet(x: Tensor, weight_sets: Sequence[Tensor], seg_end: Sequence[int] = (), out: Optional[Tensor] = None,
             out2: Optional[Tensor] = None) -> Tensor:
     """itermvs_corrnet: x [M,8,H,W] -> [M,1,H,W]; ``weight_sets`` = 1..3 tensors from pack_corrnet_weights, ``seg_end`` the

@@ -274,3 +274,25 @@ def test_relu_dot_epilogue_is_conv_relu_conv1x1():
     assert got.shape == want.shape == (24, 1, 23, 37) and rel_err(got, want) <= 2e-6
     with pytest.raises(RuntimeError):
         ops().conv2d(x, ops().MfmaWeight(w0), None, act="relu_dot", aux1=w1.reshape(-1))
+
+
+@pytest.mark.parametrize("case", [(5, 512, 640), (2, 96, 160), (1, 50, 70), (3, 16, 64), (1, 7, 5)])
+def test_stem_one_launch_matches_torch(case):
+    """itermvs_stem (FeatureNet.conv1 + layer1[0].conv1 / .downsample, net.py:13-14,39-40, fea0 kept in LDS) against the
+    torch layer chain with BatchNorm folded: full cfg-1 size, ragged sizes (odd, not multiples of the 8 x 32 tile) and an
+    image smaller than a tile; zero padding of fea0 at the image border must be reproduced"""
+    from conftest import load_weights
+    from itermvs_amd.engine import fold_batchnorm
+    m, h, w = case
+    wts = {k: v.to(DEV) for k, v in load_weights("dtu").items() if k.startswith("feature_net.")}
+    (w0, b0), (w1, b1), (wd, bd) = [fold_batchnorm(wts, "feature_net." + n) for n in ("conv1.", "layer1.0.conv1.", "layer1.0.downsample.")]
+    gen = torch.Generator().manual_seed(h * w + m)
+    x = torch.randn((m, 3, h, w), generator=gen).to(DEV)
+    f0 = F.relu(F.conv2d(x, w0, b0, padding=1))
+    want_y = F.relu(F.conv2d(f0, w1, b1, stride=2, padding=1))
+    want_sc = F.conv2d(f0, wd, bd, stride=2, padding=1)
+    y, sc = ops().stem(x, *ops().pack_stem_weights(w0, b0, w1, b1, wd, bd))
+    assert y.shape == want_y.shape and sc.shape == want_sc.shape
+    assert rel_err(y, want_y) <= 3e-6 and rel_err(sc, want_sc) <= 3e-6, (rel_err(y, want_y), rel_err(sc, want_sc))
+    with pytest.raises(RuntimeError):
+        ops().stem(torch.zeros((1, 4, 8, 8), device=DEV), *ops().pack_stem_weights(w0, b0, w1, b1, wd, bd))
