@@ -72,13 +72,16 @@ def _ddp_worker(rank, world, port, q):
     lin(x).sum().backward()
     local = [p.grad.clone() for p in lin.parameters()]
     n = ddp.flat_allreduce_gradients(params)
-    q.put((rank, w0, local, [p.grad.clone() for p in lin.parameters()], n, unused.grad))
+    # numpy arrays travel by value; tensors would be shared through file descriptors that die with this process
+    q.put((rank, w0.numpy(), [g.numpy() for g in local], [p.grad.numpy().copy() for p in lin.parameters()], n, unused.grad))
     torch.distributed.destroy_process_group()
 
 
 def test_flat_gradient_allreduce_two_ranks():
     from conftest import run_ranks
     res = run_ranks(_ddp_worker, 2)
+    t = torch.from_numpy
+    res = [(r, t(w0), [t(g) for g in loc], [t(g) for g in red], n, un) for r, w0, loc, red, n, un in res]
     assert torch.equal(res[0][1], res[1][1])                                     # same start weights on both ranks
     for i in range(2):                                                           # weight and bias
         mean = (res[0][2][i] + res[1][2][i]) / 2

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-for m in 0 4 0 4; do echo -n "mode=$m "; STEM_MODE=$m timeout 120 python tools/stem_bench.py 300; done
+for m in 0 1 2 3 4 8 7 15; do FPN_MODE=$m timeout 120 python tools/fpn_bench.py 1 200; done
