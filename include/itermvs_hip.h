@@ -375,20 +375,6 @@ int itermvs_corrnet(const float* x, int64_t x_sn, const float* const* weights, c
 int itermvs_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
                  float* y, float* sc, int64_t out_sn, void* stream);
 
-/* ------------------------------------------------------------------------------------------
- * itermvs_fpn_level -- one level of FeatureNet's top-down path in ONE launch (models/net.py:46-49 / :60-63):
- *   t = F.interpolate(top, scale_factor=2, mode="bilinear") + inner(lat)   (1x1, CL -> 48)   then   out = output(t)   (3x3, 48 -> COUT)
- * with t kept in LDS (level 1 of cfg 1: 79 MB never written).  (CL, COUT) = (16, 16) [inner1 / output1] or (32, 32)
- * [inner2 / output2].
- *   lat [N,CL,H,W] and top [N,48,H/2,W/2] dense fp32 planes (H, W even);
- *   w_in : CL*48 + 48 floats = inner's weight as [ci][co 48] then its bias;
- *   w_out: 9*12*4*COUT + COUT floats = output's weight in matrix-core operand order [tap = ky*3+kx][k-step = ci/4][q = ci%4][co]
- *          then its bias (itermvs_amd.ops.pack_fpn_weights);
- *   out  : [N,H,W,COUT] channels-last in storage type out_dtype (itermvs_dtype; 16-bit types rounded to nearest even);
- *   out_planar (optional) [N,COUT,H,W] fp32 copy;  t_out (optional) [N,48,H,W] fp32 = t (the next level's `top`).
- * ------------------------------------------------------------------------------------------ */
-int itermvs_fpn_level(const float* lat, int32_t CL, const float* top, int32_t N, int32_t H, int32_t W, const float* w_in,
-                      const float* w_out, int32_t COUT, void* out, int32_t out_dtype, float* out_planar, float* t_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * itermvs_fuse_depth -- the filter that follows the depth-inference path:

@@ -111,8 +111,6 @@ PROTOTYPES = {
                                   C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "itermvs_stem": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_int64, C.c_void_p]),
-    "itermvs_fpn_level": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
-                                    C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "itermvs_image_pyramid": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] * 5),
     "itermvs_profile_enable": (C.c_int, [C.c_int32]),
     "itermvs_profile_set_mask": (C.c_int, [C.c_int32]),

@@ -91,7 +91,6 @@ class InferenceEngine:
         import os
         self._corrnet_fused = os.environ.get("ITERMVS_CORRNET", "fused") != "layers"
         self._stem_fused = os.environ.get("ITERMVS_STEM", "fused") != "layers"
-        self._fpn_fused = os.environ.get("ITERMVS_FPN", "layers") == "fused"   # measured equal to the layered form at cfg 1 (111 vs 106 us): opt-in
         self.pk: Dict[str, object] = {}
         self._pack_weights()
 
@@ -115,8 +114,6 @@ class InferenceEngine:
         pv = "iter_mvs.evaluation.pixel_view_weight.conv.1."
         self.pvw_dot = torch.cat([w[pv + "weight"].reshape(-1), w[pv + "bias"].reshape(-1)]).float().contiguous()
         self.stem_w = ops.pack_stem_weights(*self.cbr["conv1."], *self.cbr["layer1.0.conv1."], *self.cbr["layer1.0.downsample."])
-        fw = lambda n: (w["feature_net." + n + ".weight"], w["feature_net." + n + ".bias"])
-        self.fpn_w = {l: ops.pack_fpn_weights(*fw(f"inner{l}"), *fw(f"output{l}")) for l in (1, 2)}
         self.corrnet_w = {l: ops.pack_corrnet_weights(w, f"iter_mvs.evaluation.corr_conv1.{l - 1}.") for l in (1, 2, 3)}
         dh = "iter_mvs.update.depth_head."
         self.head_w1, self.head_w2 = ops.pack_head_weights(w[dh + "2.weight"], w[dh + "4.weight"])
@@ -163,11 +160,6 @@ class InferenceEngine:
         f2 = self._res(self._res(f1, "layer2.0.", 2), "layer2.1.", 1)
         f3 = self._res(self._res(f2, "layer3.0.", 2), "layer3.1.", 1)
         self._conv(f3, p + "output3.", bias=True, channels_last_out=True, out=o3)
-        if self._fpn_fused:      # inner + up-sampled add + output conv per level in one launch, the 48-channel map stays in LDS
-            t2 = torch.empty((m, 48, hh // 4, ww // 4), device=dev)
-            ops.fpn_level(f2, f3, *self.fpn_w[2], out=o2, out_planar=self.o2_planar, t_out=t2)      # net.py:46-47
-            ops.fpn_level(f1, t2, *self.fpn_w[1], out=o1)                                            # net.py:49-50
-            return {1: o1, 2: o2, 3: o3}
         mid = self._conv(f2, p + "inner2.", bias=True, ksize=1, pad=0, add=f3, add_up2=True)   # net.py:46 (fused F.interpolate)
         self._conv(mid, p + "output2.", bias=True, channels_last_out=True, out=o2, out2=self.o2_planar)
         mid = self._conv(f1, p + "inner1.", bias=True, ksize=1, pad=0, add=mid, add_up2=True)  # net.py:49

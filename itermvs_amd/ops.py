@@ -807,41 +807,6 @@ def stem(x: Tensor, w0: Tensor, w1: Tensor) -> Tuple[Tensor, Tensor]:
     return y, sc
 
 
-def pack_fpn_weights(w_in: Tensor, b_in: Tensor, w_out: Tensor, b_out: Tensor) -> Tuple[Tensor, Tensor]:
-    """weights of itermvs_fpn_level: inner (w_in [48,CL,1,1], b_in) as [ci][co] + bias; output (w_out [COUT,48,3,3], b_out) in
-    matrix-core operand order [tap][k-step][q][co] + bias"""
-    cl, cout = w_in.shape[1], w_out.shape[0]
-    if w_in.shape[0] != 48 or w_out.shape[1] != 48 or (cl, cout) not in ((16, 16), (32, 32)) or tuple(w_out.shape[2:]) != (3, 3):
-        raise RuntimeError("pack_fpn_weights: expects inner [48,CL,1,1] and output [COUT,48,3,3] with (CL, COUT) = (16,16) or (32,32)")
-    p_in = torch.cat([w_in.float().reshape(48, cl).t().reshape(-1), b_in.float().reshape(-1)]).contiguous()
-    p_out = torch.cat([_mfma_operand_order(w_out.float().permute(2, 3, 1, 0).reshape(9, 48, cout), cout), b_out.float().reshape(-1)]).contiguous()
-    return p_in, p_out
-
-
-def fpn_level(lat: Tensor, top: Tensor, w_in: Tensor, w_out: Tensor, out: Tensor, out_planar: Optional[Tensor] = None,
-              t_out: Optional[Tensor] = None) -> Tensor:
-    """itermvs_fpn_level: out = output(F.interpolate(top, x2, bilinear) + inner(lat)), the 48-channel intermediate kept in
-    LDS.  lat [N,CL,H,W], top [N,48,H/2,W/2] dense fp32; ``out`` [N,COUT,H,W] in channels-last memory format (fp32 / fp16 / bf16
-    storage); ``out_planar`` / ``t_out``: optional dense fp32 [N,COUT,H,W] / [N,48,H,W].  Weights from pack_fpn_weights."""
-    n, cl, h, w = lat.shape
-    cout = out.shape[1]
-    for t, nm, shp in ((lat, "lat", (n, cl, h, w)), (top, "top", (n, 48, h // 2, w // 2)), (out_planar, "out_planar", (n, cout, h, w)),
-                       (t_out, "t_out", (n, 48, h, w))):
-        if t is None:
-            continue
-        if _dev(t, "fpn " + nm).dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shp:
-            raise RuntimeError(f"fpn_level: {nm} must be a dense fp32 tensor of shape {shp}")
-    if tuple(out.shape) != (n, cout, h, w) or not out.is_contiguous(memory_format=torch.channels_last):
-        raise RuntimeError("fpn_level: out must be [N,COUT,H,W] in channels-last memory format")
-    if w_in.numel() != cl * 48 + 48 or w_out.numel() != 9 * 48 * cout + cout:
-        raise RuntimeError("fpn_level: weights must come from pack_fpn_weights")
-    ptr = lambda t: t.data_ptr() if t is not None else None
-    check(_lib.load().itermvs_fpn_level(lat.data_ptr(), cl, top.data_ptr(), n, h, w, _dev(w_in, "fpn weights").data_ptr(),
-                                        _dev(w_out, "fpn weights").data_ptr(), cout, out.data_ptr(), _feat(out, "fpn output"),
-                                        ptr(out_planar), ptr(t_out), _stream()), "itermvs_fpn_level")
-    return out
-
-
 def corrnet(x: Tensor, weight_sets: Sequence[Tensor], seg_end: Sequence[int] = (), out: Optional[Tensor] = None,
             out2: Optional[Tensor] = None) -> Tensor:
     """itermvs_corrnet: x [M,8,H,W] -> [M,1,H,W]; ``weight_sets`` = 1..3 tensors from pack_corrnet_weights, ``seg_end`` the

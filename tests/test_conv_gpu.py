@@ -296,33 +296,3 @@ def test_stem_one_launch_matches_torch(case):
     assert rel_err(y, want_y) <= 3e-6 and rel_err(sc, want_sc) <= 3e-6, (rel_err(y, want_y), rel_err(sc, want_sc))
     with pytest.raises(RuntimeError):
         ops().stem(torch.zeros((1, 4, 8, 8), device=DEV), *ops().pack_stem_weights(w0, b0, w1, b1, wd, bd))
-
-
-@pytest.mark.parametrize("case", [(5, 1, 256, 320, torch.float32), (5, 2, 128, 160, torch.float32), (2, 1, 40, 72, torch.bfloat16),
-                                  (1, 2, 22, 34, torch.float16), (3, 1, 8, 32, torch.float32), (1, 2, 6, 10, torch.float32)])
-def test_fpn_level_one_launch_matches_torch(case):
-    """itermvs_fpn_level (net.py:46-50: F.interpolate(top) + inner(lat) -> output conv, the 48-channel map kept in LDS)
-    against the torch ops at cfg-1 sizes, ragged sizes (not multiples of the 8 x 32 tile, smaller than a tile) and 16-bit
-    feature storage; the optional planar copy and the 48-channel map (level 2) must equal the torch intermediates"""
-    from conftest import load_weights
-    n, level, h, w, dt = case
-    wts = {k: v.to(DEV) for k, v in load_weights("dtu").items() if k.startswith("feature_net.")}
-    wi, bi = wts[f"feature_net.inner{level}.weight"], wts[f"feature_net.inner{level}.bias"]
-    wo, bo = wts[f"feature_net.output{level}.weight"], wts[f"feature_net.output{level}.bias"]
-    gen = torch.Generator().manual_seed(h * w + n)
-    lat = torch.randn((n, wi.shape[1], h, w), generator=gen).to(DEV)
-    top = torch.randn((n, 48, h // 2, w // 2), generator=gen).to(DEV)
-    t = F.interpolate(top, scale_factor=2, mode="bilinear") + F.conv2d(lat, wi, bi)
-    want = F.conv2d(t, wo, bo, padding=1)
-    out = torch.empty((n, wo.shape[0], h, w), device=DEV, dtype=dt, memory_format=torch.channels_last)
-    planar = torch.empty((n, wo.shape[0], h, w), device=DEV) if level == 2 else None
-    t_out = torch.empty((n, 48, h, w), device=DEV) if level == 2 else None
-    ops().fpn_level(lat, top, *ops().pack_fpn_weights(wi, bi, wo, bo), out=out, out_planar=planar, t_out=t_out)
-    tol = {torch.float32: 3e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dt]
-    assert rel_err(out.float(), want) <= tol, rel_err(out.float(), want)
-    if level == 2:
-        assert rel_err(planar, want) <= 3e-6 and rel_err(t_out, t) <= 3e-6, (rel_err(planar, want), rel_err(t_out, t))
-        if dt == torch.float32:
-            assert torch.equal(planar, out.contiguous())
-    with pytest.raises(RuntimeError):
-        ops().fpn_level(lat, top[:, :, :-1], *ops().pack_fpn_weights(wi, bi, wo, bo), out=out)
