@@ -202,15 +202,29 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
         const float* __restrict__ xm = a.x + (int64_t)m * a.x_sn;
         const int gx = X0 - 8 + lane;
         const bool okx = lane < XS && gx >= 0 && gx < W;
-#pragma unroll 4
-        for (int r = wave; r < 8 * XS; r += kCnWaves) {
+        // all of a wave's row loads (and conv0's weights) are issued before the first LDS write: one HBM round trip instead
+        // of one per batch
+        WeightStage<kW1 - kW0> w0s;
+        w0s.fetch(wt + kW0, tid);
+        constexpr int PER = (8 * XS + kCnWaves - 1) / kCnWaves;
+        float v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int r = min(wave + i * kCnWaves, 8 * XS - 1);
             const int ci = r / XS, ry = r - ci * XS;             // wave-uniform
             const int gy = Y0 - 8 + ry;
             const bool ok = okx && gy >= 0 && gy < H;
-            const float v = ok ? xm[(int64_t)ci * H * W + gy * W + gx] : 0.0f;
-            if (lane < XP) X[ci * XPL + ry * XP + lane] = v;
+            v[i] = ok ? xm[(int64_t)ci * H * W + gy * W + gx] : 0.0f;
         }
-        for (int i = tid; i < kW1 - kW0; i += kCnThreads) WL[i] = wt[kW0 + i];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int r = wave + i * kCnWaves;
+            if (r < 8 * XS && lane < XP) {
+                const int ci = r / XS, ry = r - ci * XS;
+                X[ci * XPL + ry * XP + lane] = v[i];
+            }
+        }
+        w0s.commit(WL, tid);
     }
     __syncthreads();
     {   // c0 = relu(conv(x)): 43 x 43
