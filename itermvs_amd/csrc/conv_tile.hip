@@ -133,11 +133,13 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
         const int rows = a.nchunk * 36;
         const int col = tid % VPR;
         constexpr int RPP = 256 / VPR;               // rows per pass of the workgroup
-        // four passes of loads in flight before their LDS stores (one L2 round trip per four passes)
-        for (int r0 = tid / VPR; r0 < rows; r0 += 4 * RPP) {
-            f32x4 t[4];
+        // kWPasses passes of loads in flight before their LDS stores (one L2 round trip per batch of passes; up to 48 input
+        // channels at MB = 1 are one batch)
+        constexpr int kWPasses = 6;
+        for (int r0 = tid / VPR; r0 < rows; r0 += kWPasses * RPP) {
+            f32x4 t[kWPasses];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < kWPasses; ++i) {
                 const int r = r0 + i * RPP;
                 const int cidx = r / 36, rem = r - cidx * 36;
                 const int tap = rem >> 2, qq = rem & 3;
@@ -145,7 +147,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
                 if (r < rows) t[i] = src[g];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < kWPasses; ++i) {
                 const int r = r0 + i * RPP;
                 if (r < rows) reinterpret_cast<f32x4*>(wlds)[r * VPR + col] = t[i];
             }

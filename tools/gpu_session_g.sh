@@ -2,7 +2,6 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 O=gpurun_out/r2g
-timeout 900 python -m pytest tests/test_conv_gpu.py -q -k "corrnet" 2>&1 | tail -1
 timeout 300 python bench.py --steps 60 --minimal > ${O}_bench.json 2> ${O}_bench.err
 python -c "
 import json
@@ -12,4 +11,4 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf $R/gpurun_out/r2g_prof
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r2g_prof -- python $R/bench.py --steps 20 --warmup 4 --minimal > $R/${O}_prof.log 2>&1
 cd $R
-python tools/step_timeline.py $(ls -t gpurun_out/r2g_prof/*/*kernel_trace.csv | head -1) > ${O}_timeline.txt 2>&1; grep -E "corrnet|busy" ${O}_timeline.txt | head -8
+python tools/step_timeline.py $(ls -t gpurun_out/r2g_prof/*/*kernel_trace.csv | head -1) > ${O}_timeline.txt 2>&1; grep -E "busy" ${O}_timeline.txt | head -8
