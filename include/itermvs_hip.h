@@ -355,9 +355,11 @@ int itermvs_conv2d(const itermvs_conv_params* p, void* stream);
  *   out_sn / out2_sn (the GRU input buffers take the scores in place);
  *   weights: host array of n_seg (1..3) device pointers to PACKED weight sets, batch items [0,seg_end[0]) use set 0,
  *   [seg_end[0],seg_end[1]) set 1, the rest set 2 (the three CorrNets of one GRU iteration in one launch).
- *   Packed set (fp32, 13904 floats, 16-byte aligned): the five matrix-core layers in operand order
- *   [tap = ky*3+kx][k-step = ci/4][q = ci%4][co, zero padded] -- conv0 (co 16) | conv1 (16) | conv2 (32) | conv3, transposed
- *   (16) | conv4, transposed (16) -- then conv5 as [ci 8][tap 9], the bias, 7 pad (itermvs_amd.ops.pack_corrnet_weights).
+ *   Packed set (fp32, 14288 floats, 16-byte aligned): the five matrix-core layers in operand order
+ *   [tap = ky*3+kx][k-step = ci/4][q = ci%4][co, zero padded] -- conv0 in its two-rows-per-tile form ([window row 4][kx 3]
+ *   [k-step][q][16]: columns 0..7 = channel co with tap row = window row, columns 8..15 = channel co - 8 with tap row =
+ *   window row - 1, zero where that is outside 0..2) | conv1 (16) | conv2 (32) | conv3, transposed (16) | conv4, transposed
+ *   (16) -- then conv5 as [ci 8][tap 9], the bias, 7 pad (itermvs_amd.ops.pack_corrnet_weights).
  * ------------------------------------------------------------------------------------------ */
 int itermvs_corrnet(const float* x, int64_t x_sn, const float* const* weights, const int32_t* seg_end, int32_t n_seg,
                     int32_t M, int32_t H, int32_t W, float* out, int64_t out_sn, float* out2, int64_t out2_sn, void* stream);

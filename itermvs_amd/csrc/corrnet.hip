@@ -49,8 +49,8 @@ constexpr int kSzW = 4608;
 constexpr int kCnLdsFloats = kOffW + kSzW;
 // packed weight set of one CorrNet (floats), every layer in MFMA operand order [tap][k-step][q][co padded to 16 / 32]:
 // see ops.pack_corrnet_weights
-constexpr int kW0 = 0;                         // conv0: 9 x 2 x 4 x 16
-constexpr int kW1 = kW0 + 9 * 2 * 4 * 16;      // conv1: 9 x 2 x 4 x 16
+constexpr int kW0 = 0;                         // conv0, two output rows per MFMA (conv0_layer): 12 x 2 x 4 x 16
+constexpr int kW1 = kW0 + 12 * 2 * 4 * 16;     // conv1: 9 x 2 x 4 x 16
 constexpr int kW2 = kW1 + 9 * 2 * 4 * 16;      // conv2: 9 x 4 x 4 x 32
 constexpr int kW3 = kW2 + 9 * 4 * 4 * 32;      // conv3 (transposed): 9 x 8 x 4 x 16
 constexpr int kW4 = kW3 + 9 * 8 * 4 * 16;      // conv4 (transposed): 9 x 4 x 4 x 16
@@ -127,6 +127,45 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ In, float* 
                     const int co = mb * 16 + q * 4 + r;
                     if (co < COUT) Out[co * OUTPL + oy * OUTP + ox] = inside ? fmaxf(acc[mb][r], 0.0f) : 0.0f;
                 }
+        }
+    }
+}
+
+// conv0 (8 -> 8 channels) would fill only half of the 16 MFMA rows.  Here one MFMA tile holds TWO output rows of 16
+// positions: rows m = 0..7 are the 8 channels of output row 2p, rows 8..15 those of output row 2p + 1, contracted over the
+// 4-row x 3-column window both need (K = 4 x 3 x 8 = 96 = 24 steps; the row a half does not use has zero weights) --
+// 24 MFMAs per 32 positions instead of 36.  Wl: [window row 4][kx 3][k-step 2][q 4][16] (ops.pack_corrnet_weights).
+template <int INPL, int INR, int INP, int OUTS, int OUTPL, int OUTP>
+__device__ __forceinline__ void conv0_layer(const float* __restrict__ In, float* __restrict__ Out, const float* __restrict__ Wl,
+                                            int gy0, int gx0, int imgH, int imgW, int wave, int lane) {
+    constexpr int PAIRS = (OUTS + 1) / 2, NPOS = PAIRS * OUTS, GROUPS = (NPOS + 15) / 16;
+    const int q = lane >> 4, l16 = lane & 15;
+    float aw[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) aw[i] = Wl[(i * 4 + q) * 16 + l16];
+    for (int g = wave; g < GROUPS; g += kCnWaves) {
+        const int pos = g * 16 + l16;
+        const int pc = pos < NPOS ? pos : NPOS - 1;
+        const int rp = pc / OUTS, ox = pc - rp * OUTS;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* __restrict__ bp = In + q * INPL + 2 * rp * INP + ox;
+        // window row 3 of the last pair lies past the region (only the unused second output row would read it): re-read the
+        // last row instead of whatever follows it in LDS -- its weights for the first output row are zero, 0 * NaN is not
+        const int w3 = (min(2 * rp + 3, INR - 1) - 2 * rp) * INP;
+#pragma unroll
+        for (int wr = 0; wr < 4; ++wr)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[(wr * 3 + kx) * 2 + ks],
+                                                               bp[ks * 4 * INPL + (wr < 3 ? wr * INP : w3) + kx], acc, 0, 0, 0);
+        const int oy = 2 * rp + (q >> 1);
+        const int gy = gy0 + oy, gx = gx0 + ox;
+        const bool inside = gy >= 0 && gy < imgH && gx >= 0 && gx < imgW;
+        if (pos < NPOS && oy < OUTS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Out[((q & 1) * 4 + r) * OUTPL + oy * OUTP + ox] = inside ? fmaxf(acc[r], 0.0f) : 0.0f;
         }
     }
 }
@@ -230,7 +269,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
     {   // c0 = relu(conv(x)): 43 x 43
         WeightStage<kW2 - kW1> nw;
         nw.fetch(wt + kW1, tid);
-        conv_layer<8, 8, 1, 1, XPL, XP, C0S, C0PL, C0P>(X, C0, WL, Y0 - 7, X0 - 7, H, W, wave, lane);
+        conv0_layer<XPL, XS, XP, C0S, C0PL, C0P>(X, C0, WL, Y0 - 7, X0 - 7, H, W, wave, lane);
         __syncthreads();
         nw.commit(WL, tid);
     }

@@ -747,7 +747,7 @@ def fuse_depth(depth_ref: Tensor, conf_ref: Tensor, depth_src: Sequence[Tensor],
     return avg, photo, geo, final, cnt
 
 
-CORRNET_WEIGHT_FLOATS = 13904
+CORRNET_WEIGHT_FLOATS = 14288
 
 
 def _mfma_operand_order(w_tap_ci_co: Tensor, co_pad: int) -> Tensor:
@@ -765,7 +765,13 @@ def pack_corrnet_weights(w: Dict[str, Tensor], prefix: str) -> Tensor:
     conv = lambda name, pad: _mfma_operand_order(w[prefix + name].float().permute(2, 3, 1, 0).reshape(9, w[prefix + name].shape[1], -1), pad)
     # ConvTranspose2d weights are [ci, co, ky, kx]
     dconv = lambda name, pad: _mfma_operand_order(w[prefix + name].float().permute(2, 3, 0, 1).reshape(9, w[prefix + name].shape[0], -1), pad)
-    parts = [conv("conv0.conv.weight", 16), conv("conv1.conv.weight", 16), conv("conv2.conv.weight", 32),
+    # conv0 computes two output rows per matrix-core tile: rows 0..7 = the 8 channels with the taps in window rows 0..2,
+    # rows 8..15 = the same channels with the taps in window rows 1..3 ([window row 4][kx 3][ci 8][16])
+    w0 = w[prefix + "conv0.conv.weight"].float()                                   # [co 8, ci 8, ky 3, kx 3]
+    two = torch.zeros((4, 3, 8, 16), device=w0.device, dtype=torch.float32)
+    two[0:3, :, :, 0:8] = w0.permute(2, 3, 1, 0)
+    two[1:4, :, :, 8:16] = w0.permute(2, 3, 1, 0)
+    parts = [_mfma_operand_order(two.reshape(12, 8, 16), 16), conv("conv1.conv.weight", 16), conv("conv2.conv.weight", 32),
              dconv("conv3.weight", 16), dconv("conv4.weight", 16),
              w[prefix + "conv5.weight"].float().permute(1, 2, 3, 0).reshape(-1), w[prefix + "conv5.bias"].float().reshape(-1)]
     flat = torch.cat(parts + [torch.zeros(7, device=parts[0].device)])
