@@ -181,40 +181,50 @@ __device__ __forceinline__ void deconv_layer(const float* __restrict__ In, float
                                              int gy0, int gx0, int imgH, int imgW, int wave, int lane) {
     constexpr int KS = CIN / 4, NPOS = NB * NB, GROUPS = (NPOS + 15) / 16;
     const int q = lane >> 4, l16 = lane & 15;
-    for (int u = wave; u < GROUPS * 4; u += kCnWaves) {      // unit = (group, parity class); classes of one group on different waves
-        const int g = u >> 2, py = (u >> 1) & 1, px = u & 1;
+    // unit = 16 input blocks with all four output parities: every input value is read once and feeds the 1 / 2 / 2 / 4
+    // parity classes that use it (9 MFMAs per k-step from 4 LDS reads of B)
+    for (int g = wave; g < GROUPS; g += kCnWaves) {
         const int pos = g * 16 + l16;
         const int pc = pos < NPOS ? pos : NPOS - 1;
         const int ba = pc / NB, bb = pc - ba * NB;
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 acc[4];                                        // class py * 2 + px
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const float* __restrict__ bp = In + q * INPL + (ba + IO) * INP + bb + IO;
+        const float* __restrict__ ap = Wl + q * 16 + l16;
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                // input (a + dy, b + dx) reaches output row parity py through ky: dy = 1 -> ky = py (0 or 1), dy = 0 -> ky = 2 (py = 0 only)
-                const bool used = (dy == 1 || py == 0) && (dx == 1 || px == 0);      // wave-uniform
-                if (used) {
-                    const int ky = dy == 1 ? py : 2, kx = dx == 1 ? px : 2;
-                    const int tap = ky * 3 + kx;
+            for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[((tap * KS + ks) * 4 + q) * 16 + l16],
-                                                                   bp[ks * 4 * INPL + dy * INP + dx], acc, 0, 0, 0);
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float b = bp[ks * 4 * INPL + dy * INP + dx];
+                    // input (a + dy, b + dx) reaches output row parity py through ky: dy = 1 -> ky = py (0 or 1), dy = 0 -> ky = 2 (py = 0 only)
+#pragma unroll
+                    for (int py = 0; py <= dy; ++py)
+#pragma unroll
+                        for (int px = 0; px <= dx; ++px) {
+                            const int ky = dy == 1 ? py : 2, kx = dx == 1 ? px : 2;
+                            acc[py * 2 + px] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[((ky * 3 + kx) * KS + ks) * 64], b, acc[py * 2 + px], 0, 0, 0);
+                        }
                 }
-            }
-        const int o = 2 * ba + py, p = 2 * bb + px;
-        const int gy = gy0 + o, gx = gx0 + p;
-        const bool inside = gy >= 0 && gy < imgH && gx >= 0 && gx < imgW;
         if (pos < NPOS) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = q * 4 + r;
-                if (co < COUT) {
-                    float* __restrict__ d = Skip + co * OUTPL + (o + OO) * OUTP + p + OO;
-                    *d = inside ? *d + acc[r] : 0.0f;
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    const int o = 2 * ba + py, p = 2 * bb + px;
+                    const int gy = gy0 + o, gx = gx0 + p;
+                    const bool inside = gy >= 0 && gy < imgH && gx >= 0 && gx < imgW;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = q * 4 + r;
+                        if (co < COUT) {
+                            float* __restrict__ d = Skip + co * OUTPL + (o + OO) * OUTP + p + OO;
+                            *d = inside ? *d + acc[py * 2 + px][r] : 0.0f;
+                        }
+                    }
                 }
-            }
         }
     }
 }
