@@ -118,6 +118,13 @@ int itermvs_warp_backward(const float* grad_out, const float* proj, const float*
  * ------------------------------------------------------------------------------------------ */
 int itermvs_ref_quarter(const itermvs_fmap* ref_l1, const itermvs_fmap* ref_l2,
                         const itermvs_fmap* ref_l3, int32_t B, float* out, void* stream);
+/* itermvs_ref_quarter_compose -- itermvs_ref_quarter and, in the SAME launch (a few extra threads), itermvs_compose_proj with
+ * its arguments (mats .. inv_max; Bd = batch size of the depth range): the two are independent and both precede the
+ * correlation kernels. */
+int itermvs_ref_quarter_compose(const itermvs_fmap* r1, const itermvs_fmap* r2, const itermvs_fmap* r3, int32_t B, float* out,
+                                const float* mats, int32_t n_sets, int32_t V, float* proj_out, int32_t* nan_flag,
+                                const float* depth_min, const float* depth_max, int32_t Bd, float* inv_min, float* inv_max,
+                                void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * itermvs_corr_iter -- models/itermvs.py:84-120 (Evaluation.forward, iteration branch, up to
@@ -196,6 +203,11 @@ int itermvs_corr_init_backward(const itermvs_corr_init_params* p, const float* g
  * corr [B,S,N,8,P], w [B,S,P] (PixelViewWeight output at 1/8 res), out [B,N,8,P]. */
 int itermvs_view_aggregate(const float* corr, const float* w, int32_t S, int32_t B, int32_t N,
                            int32_t P, float* out, void* stream);
+/* itermvs_view_aggregate_up -- the same, and in the SAME launch (extra blocks: two independent pieces of work that only
+ * read w) the x2 bilinear up-sampling of the view weights the iterations use (models/itermvs.py:56-57,71):
+ *   w [B,S,H3,W3] -> w_up [B,S,2*H3,2*W3]. */
+int itermvs_view_aggregate_up(const float* corr, const float* w, int32_t S, int32_t B, int32_t N, int32_t H3, int32_t W3,
+                              float* out, float* w_up, void* stream);
 
 /* itermvs_softmax_max -- models/itermvs.py:347-348 (PixelViewWeight tail)
  *   out[m,p] = max_n softmax_n(x[m,n,p]);  x [M,N,P] contiguous, out [M,P]. */
@@ -274,6 +286,11 @@ int itermvs_convex_upsample(const float* logits, int64_t sb, int64_t sc, int64_t
                             const float* nd, int64_t nd_sb, const float* inv_depth_min,
                             const float* inv_depth_max, int32_t B, int32_t H, int32_t W,
                             float* depth, float* norm_out, void* stream);
+/* itermvs_final_upsample -- itermvs_convex_upsample (depth, models/itermvs.py:321-322) and, in the SAME launch, the x4 bilinear
+ * up-sampling of the confidence (models/itermvs.py:323-324): conf [M,H,W] -> conf_up [M,4H,4W]. */
+int itermvs_final_upsample(const float* logits, int64_t sb, int64_t sc, int64_t sy, int64_t sx, const float* nd, int64_t nd_sb,
+                           const float* inv_depth_min, const float* inv_depth_max, int32_t B, int32_t H, int32_t W, float* depth,
+                           const float* conf, int32_t M, float* conf_up, void* stream);
 
 /* itermvs_bilinear_up -- F.interpolate(x, scale_factor=s, mode='bilinear') for integer s
  * (models/itermvs.py:56,161,323): x [M,H,W] -> out [M,s*H,s*W]; `act`: 0 none, 1 tanh

@@ -78,6 +78,13 @@ PROTOTYPES = {
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "itermvs_warp_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p, C.c_void_p]),
     "itermvs_ref_quarter": (C.c_int, [C.POINTER(FMap)] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
+    "itermvs_ref_quarter_compose": (C.c_int, [C.POINTER(FMap)] * 3 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "itermvs_view_aggregate_up": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "itermvs_final_upsample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                         C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                         C.c_void_p]),
     "itermvs_corr_iter": (C.c_int, [C.POINTER(CorrIterParams), C.c_void_p]),
     "itermvs_corr_init": (C.c_int, [C.POINTER(CorrInitParams), C.c_void_p]),
     "itermvs_corr_iter_backward": (C.c_int, [C.POINTER(CorrIterParams), C.POINTER(C.c_void_p * 3),

@@ -164,4 +164,32 @@ __device__ __forceinline__ float unnormalize_depth(float nd, float inv_min, floa
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// F.interpolate(x, scale_factor=s, 'bilinear') for integer s, optional tanh: output element t of [M, H*s, W*s]
+// (bilinear_up_kernel, and the launches that carry it beside another piece of work)
+__device__ __forceinline__ void bilinear_up_body(const float* __restrict__ x, int M, int H, int W, int scale, int act,
+                                                 float* __restrict__ out, int64_t t) {
+    const int OH = H * scale, OW = W * scale;
+    if (t >= (int64_t)M * OH * OW) return;
+    const int ox = (int)(t % OW);
+    const int oy = (int)((t / OW) % OH);
+    const int m = (int)(t / ((int64_t)OW * OH));
+    const float rs = 1.0f / (float)scale;
+    float sy = ((float)oy + 0.5f) * rs - 0.5f;
+    float sx = ((float)ox + 0.5f) * rs - 0.5f;
+    sy = sy < 0.0f ? 0.0f : sy;
+    sx = sx < 0.0f ? 0.0f : sx;
+    int y0 = (int)sy, x0 = (int)sx;
+    y0 = y0 > H - 1 ? H - 1 : y0;
+    x0 = x0 > W - 1 ? W - 1 : x0;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+    const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    const float* xm = x + (size_t)m * H * W;
+    const float top = xm[(size_t)y0 * W + x0] * lx0 + xm[(size_t)y0 * W + x1] * lx1;
+    const float bot = xm[(size_t)y1 * W + x0] * lx0 + xm[(size_t)y1 * W + x1] * lx1;
+    float v = top * ly0 + bot * ly1;
+    if (act == 1) v = tanhf(v);
+    out[t] = v;
+}
+
 }  // namespace itermvs

@@ -434,8 +434,14 @@ __global__ void __launch_bounds__(kThreads) corr_init_kernel(const InitArgs a) {
 }
 
 // out[b,n,g,p] = sum_s corr[b,s,n,g,p]*w[b,s,p] / (1e-5 + sum_s w[b,s,p])     (itermvs.py:59-69)
+// Blocks [0, n_agg) aggregate; the blocks after them (itermvs_view_aggregate_up) up-sample the view weights x2 for the
+// iterations (itermvs.py:56-57,71): both only read `w`, one launch instead of two.
 __global__ void view_aggregate_kernel(const float* __restrict__ corr, const float* __restrict__ w, int S, int B, int NG,
-                                      int P, float* __restrict__ out) {
+                                      int P, float* __restrict__ out, int n_agg, int H3, int W3, float* __restrict__ w_up) {
+    if ((int)blockIdx.x >= n_agg) {
+        bilinear_up_body(w, B * S, H3, W3, 2, 0, w_up, (int64_t)(blockIdx.x - n_agg) * blockDim.x + threadIdx.x);
+        return;
+    }
     const int64_t per = (int64_t)NG * P;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)B * per) return;
@@ -667,8 +673,21 @@ extern "C" int itermvs_view_aggregate(const float* corr, const float* w, int32_t
     ITERMVS_RETURN_IF(!corr || !w || !out, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(S < 1 || B < 1 || N < 1 || P < 1, ITERMVS_ERR_DIMS);
     const int64_t total = (int64_t)B * N * ITERMVS_GROUPS * P;
-    hipLaunchKernelGGL(view_aggregate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       corr, w, S, B, N * ITERMVS_GROUPS, P, out);
+    const int na = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(view_aggregate_kernel, dim3((unsigned)na), dim3(256), 0, (hipStream_t)stream,
+                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, 0, 0, (float*)nullptr);
+    return itermvs_launch_status();
+}
+
+extern "C" int itermvs_view_aggregate_up(const float* corr, const float* w, int32_t S, int32_t B, int32_t N, int32_t H3, int32_t W3,
+                                         float* out, float* w_up, void* stream) {
+    ITERMVS_RETURN_IF(!corr || !w || !out || !w_up, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(S < 1 || B < 1 || N < 1 || H3 < 1 || W3 < 1, ITERMVS_ERR_DIMS);
+    const int P = H3 * W3;
+    const int na = (int)(((int64_t)B * N * ITERMVS_GROUPS * P + 255) / 256);
+    const int nu = (int)(((int64_t)B * S * P * 4 + 255) / 256);
+    hipLaunchKernelGGL(view_aggregate_kernel, dim3((unsigned)(na + nu)), dim3(256), 0, (hipStream_t)stream,
+                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, H3, W3, w_up);
     return itermvs_launch_status();
 }
 

@@ -7,11 +7,26 @@ namespace itermvs {
 // compose_proj: out[set, s-1, 0:12] = rows of (src_s @ inverse(ref))[:3, :4]   (module.py:77-90)
 // One thread per (set, source view); 4x4 Gauss-Jordan with partial pivoting in fp64.
 // ---------------------------------------------------------------------------------------------
-__global__ void compose_proj_kernel(const float* __restrict__ mats, int n_sets, int V, float* __restrict__ out,
-                                    int* __restrict__ nan_flag, const float* __restrict__ depth_min,
-                                    const float* __restrict__ depth_max, int B, float* __restrict__ inv_min,
-                                    float* __restrict__ inv_max) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+struct ComposeArgs {
+    const float* mats;
+    float* out;
+    int* nan_flag;
+    const float* depth_min;
+    const float* depth_max;
+    float* inv_min;
+    float* inv_max;
+    int n_sets, V, B;
+};
+
+__device__ __forceinline__ void compose_proj_body(const ComposeArgs& c, int t) {
+    const float* __restrict__ mats = c.mats;
+    float* __restrict__ out = c.out;
+    int* __restrict__ nan_flag = c.nan_flag;
+    const float* __restrict__ depth_min = c.depth_min;
+    const float* __restrict__ depth_max = c.depth_max;
+    float* __restrict__ inv_min = c.inv_min;
+    float* __restrict__ inv_max = c.inv_max;
+    const int n_sets = c.n_sets, V = c.V, B = c.B;
     const int S = V - 1;
     // inverse depth range of the batch (1 / depth_min, 1 / depth_max: itermvs.py:240-241), IEEE division
     if (inv_min && t < B) {
@@ -62,6 +77,8 @@ __global__ void compose_proj_kernel(const float* __restrict__ mats, int n_sets, 
         }
     if (bad && nan_flag) atomicOr(nan_flag, 1);
 }
+
+__global__ void compose_proj_kernel(ComposeArgs c) { compose_proj_body(c, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // ---------------------------------------------------------------------------------------------
 // warp: thread per (b, n, y, x); loops over channels.  out[B,C,N,H,W]      (module.py:68-125)
@@ -157,8 +174,15 @@ __device__ __forceinline__ void ld4(const itermvs_fmap& f, int b, int c, int y, 
     }
 }
 
+// blocks [0, n_ref) resample the reference features; with `with_compose` the blocks after them evaluate compose_proj (an
+// independent piece of work of a few threads that would otherwise cost a launch of its own: itermvs_ref_quarter_compose)
 template <int FT>
-__global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fmap r3, int B, float* __restrict__ out) {
+__global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fmap r3, int B, float* __restrict__ out, int n_ref,
+                                   ComposeArgs comp) {
+    if ((int)blockIdx.x >= n_ref) {
+        compose_proj_body(comp, ((int)blockIdx.x - n_ref) * (int)blockDim.x + (int)threadIdx.x);
+        return;
+    }
     const int H = r2.H, W = r2.W;
     const int CQ = r1.C + r2.C + r3.C;
     const int quads = CQ / 4;
@@ -217,8 +241,8 @@ extern "C" int itermvs_compose_proj(const float* mats, int32_t n_sets, int32_t V
     ITERMVS_RETURN_IF(V < 2 || V - 1 > ITERMVS_MAX_SRC, ITERMVS_ERR_VIEWS);
     int total = n_sets * (V - 1);
     if (inv_min && B > total) total = B;
-    hipLaunchKernelGGL(compose_proj_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, mats, n_sets, V,
-                       out, nan_flag, depth_min, depth_max, B, inv_min, inv_max);
+    const ComposeArgs c{mats, out, nan_flag, depth_min, depth_max, inv_min, inv_max, n_sets, V, B};
+    hipLaunchKernelGGL(compose_proj_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, c);
     return itermvs_launch_status();
 }
 
@@ -244,8 +268,8 @@ extern "C" int itermvs_warp_backward(const float* grad_out, const float* proj, c
     return itermvs_launch_status();
 }
 
-extern "C" int itermvs_ref_quarter(const itermvs_fmap* r1, const itermvs_fmap* r2, const itermvs_fmap* r3, int32_t B,
-                                   float* out, void* stream) {
+static int launch_ref_quarter(const itermvs_fmap* r1, const itermvs_fmap* r2, const itermvs_fmap* r3, int32_t B, float* out,
+                              const ComposeArgs* comp, void* stream) {
     ITERMVS_RETURN_IF(!r1 || !r2 || !r3 || !r1->data || !r2->data || !r3->data || !out, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(B < 1 || r2->H < 1 || r2->W < 1, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(r1->H != 2 * r2->H || r1->W != 2 * r2->W || r2->H != 2 * r3->H || r2->W != 2 * r3->W,
@@ -254,12 +278,38 @@ extern "C" int itermvs_ref_quarter(const itermvs_fmap* r1, const itermvs_fmap* r
     ITERMVS_RETURN_IF(((uintptr_t)out) % 16, ITERMVS_ERR_ALIGN);
     const int64_t total = (int64_t)B * r2->H * r2->W * ((r1->C + r2->C + r3->C) / 4);
     ITERMVS_RETURN_IF(r1->dtype != r2->dtype || r1->dtype != r3->dtype, ITERMVS_ERR_DTYPE);
-    const dim3 grid((unsigned)((total + 255) / 256));
+    const int n_ref = (int)((total + 255) / 256);
+    ComposeArgs c{};
+    int extra = 0;
+    if (comp) {
+        c = *comp;
+        int ct = c.n_sets * (c.V - 1);
+        if (c.inv_min && c.B > ct) ct = c.B;
+        extra = (ct + 255) / 256;
+    }
+    const dim3 grid((unsigned)(n_ref + extra));
     switch (r1->dtype) {
-        case ITERMVS_F32: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F32>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out); break;
-        case ITERMVS_F16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out); break;
-        case ITERMVS_BF16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_BF16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out); break;
+        case ITERMVS_F32: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F32>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, n_ref, c); break;
+        case ITERMVS_F16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, n_ref, c); break;
+        case ITERMVS_BF16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_BF16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, n_ref, c); break;
         default: return ITERMVS_ERR_DTYPE;
     }
     return itermvs_launch_status();
+}
+
+extern "C" int itermvs_ref_quarter(const itermvs_fmap* r1, const itermvs_fmap* r2, const itermvs_fmap* r3, int32_t B,
+                                   float* out, void* stream) {
+    return launch_ref_quarter(r1, r2, r3, B, out, nullptr, stream);
+}
+
+extern "C" int itermvs_ref_quarter_compose(const itermvs_fmap* r1, const itermvs_fmap* r2, const itermvs_fmap* r3, int32_t B,
+                                           float* out, const float* mats, int32_t n_sets, int32_t V, float* proj_out,
+                                           int32_t* nan_flag, const float* depth_min, const float* depth_max, int32_t Bd,
+                                           float* inv_min, float* inv_max, void* stream) {
+    ITERMVS_RETURN_IF(!mats || !proj_out, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(inv_min && (!depth_min || !depth_max || !inv_max || Bd < 1), ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(n_sets < 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(V < 2 || V - 1 > ITERMVS_MAX_SRC, ITERMVS_ERR_VIEWS);
+    const ComposeArgs c{mats, proj_out, nan_flag, depth_min, depth_max, inv_min, inv_max, n_sets, V, Bd};
+    return launch_ref_quarter(r1, r2, r3, B, out, &c, stream);
 }

@@ -162,11 +162,10 @@ __global__ void pack_scores_kernel(const float* __restrict__ s0, const float* __
 // convex x4 up-sampling fused with the 9-tap soft-max and depth un-normalisation.
 // thread = (b, y, sub-row i, x): 36 logits + 9 neighbours in, one float4 (4 sub-columns) out.
 // ---------------------------------------------------------------------------------------------
-__global__ void convex_upsample_kernel(const float* __restrict__ logits, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
-                                       const float* __restrict__ nd, int64_t nd_sb, const float* __restrict__ inv_min,
-                                       const float* __restrict__ inv_max, int B, int H, int W,
-                                       float* __restrict__ depth, float* __restrict__ norm_out) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void convex_upsample_body(const float* __restrict__ logits, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                                                     const float* __restrict__ nd, int64_t nd_sb, const float* __restrict__ inv_min,
+                                                     const float* __restrict__ inv_max, int B, int H, int W,
+                                                     float* __restrict__ depth, float* __restrict__ norm_out, int64_t t) {
     if (t >= (int64_t)B * H * 4 * W) return;
     const int x = (int)(t % W);
     const int i = (int)((t / W) % 4);
@@ -209,32 +208,23 @@ __global__ void convex_upsample_kernel(const float* __restrict__ logits, int64_t
     if (norm_out) *reinterpret_cast<float4*>(norm_out + o) = make_float4(resn[0], resn[1], resn[2], resn[3]);
 }
 
-// F.interpolate(x, scale_factor=s, 'bilinear') for integer s, optional tanh
+// blocks [0, n_convex): convex up-sampling of the depth; blocks after them (if any): bilinear up-sampling of another map
+// (the confidence, itermvs.py:323-324) -- two independent pieces of work in one launch (itermvs_final_upsample)
+__global__ void convex_upsample_kernel(const float* __restrict__ logits, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                                       const float* __restrict__ nd, int64_t nd_sb, const float* __restrict__ inv_min,
+                                       const float* __restrict__ inv_max, int B, int H, int W,
+                                       float* __restrict__ depth, float* __restrict__ norm_out, int n_convex,
+                                       const float* __restrict__ x2, int M2, int scale2, float* __restrict__ out2) {
+    if ((int)blockIdx.x < n_convex)
+        convex_upsample_body(logits, sb, sc, sy, sx, nd, nd_sb, inv_min, inv_max, B, H, W, depth, norm_out,
+                             (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    else
+        bilinear_up_body(x2, M2, H, W, scale2, 0, out2, (int64_t)(blockIdx.x - n_convex) * blockDim.x + threadIdx.x);
+}
+
 __global__ void bilinear_up_kernel(const float* __restrict__ x, int M, int H, int W, int scale, int act,
                                    float* __restrict__ out) {
-    const int OH = H * scale, OW = W * scale;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)M * OH * OW) return;
-    const int ox = (int)(t % OW);
-    const int oy = (int)((t / OW) % OH);
-    const int m = (int)(t / ((int64_t)OW * OH));
-    const float rs = 1.0f / (float)scale;
-    float sy = ((float)oy + 0.5f) * rs - 0.5f;
-    float sx = ((float)ox + 0.5f) * rs - 0.5f;
-    sy = sy < 0.0f ? 0.0f : sy;
-    sx = sx < 0.0f ? 0.0f : sx;
-    int y0 = (int)sy, x0 = (int)sx;
-    y0 = y0 > H - 1 ? H - 1 : y0;
-    x0 = x0 > W - 1 ? W - 1 : x0;
-    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
-    const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
-    const float* xm = x + (size_t)m * H * W;
-    const float top = xm[(size_t)y0 * W + x0] * lx0 + xm[(size_t)y0 * W + x1] * lx1;
-    const float bot = xm[(size_t)y1 * W + x0] * lx0 + xm[(size_t)y1 * W + x1] * lx1;
-    float v = top * ly0 + bot * ly1;
-    if (act == 1) v = tanhf(v);
-    out[t] = v;
+    bilinear_up_body(x, M, H, W, scale, act, out, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // bilinear_up with up to two destinations addressed by batch strides (channel slices of wider buffers):
@@ -332,8 +322,25 @@ extern "C" int itermvs_convex_upsample(const float* logits, int64_t sb, int64_t 
     ITERMVS_RETURN_IF(B < 1 || H < 1 || W < 1, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(((uintptr_t)depth) % 16 || ((uintptr_t)norm_out) % 16, ITERMVS_ERR_ALIGN);
     const int64_t total = (int64_t)B * H * 4 * W;
-    hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       logits, sb, sc, sy, sx, nd, nd_sb, inv_depth_min, inv_depth_max, B, H, W, depth, norm_out);
+    const int nc = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)nc), dim3(256), 0, (hipStream_t)stream,
+                       logits, sb, sc, sy, sx, nd, nd_sb, inv_depth_min, inv_depth_max, B, H, W, depth, norm_out, nc,
+                       (const float*)nullptr, 0, 1, (float*)nullptr);
+    return itermvs_launch_status();
+}
+
+extern "C" int itermvs_final_upsample(const float* logits, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                                      const float* nd, int64_t nd_sb, const float* inv_depth_min,
+                                      const float* inv_depth_max, int32_t B, int32_t H, int32_t W, float* depth,
+                                      const float* conf, int32_t M, float* conf_up, void* stream) {
+    ITERMVS_RETURN_IF(!logits || !nd || !inv_depth_min || !inv_depth_max || !depth || !conf || !conf_up, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(B < 1 || H < 1 || W < 1 || M < 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(((uintptr_t)depth) % 16, ITERMVS_ERR_ALIGN);
+    const int nc = (int)(((int64_t)B * H * 4 * W + 255) / 256);
+    const int nb = (int)(((int64_t)M * H * W * 16 + 255) / 256);
+    hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)(nc + nb)), dim3(256), 0, (hipStream_t)stream,
+                       logits, sb, sc, sy, sx, nd, nd_sb, inv_depth_min, inv_depth_max, B, H, W, depth, (float*)nullptr, nc,
+                       conf, M, 4, conf_up);
     return itermvs_launch_status();
 }
 

@@ -241,8 +241,7 @@ class InferenceEngine:
         # 16-channel tensor is never stored), then softmax over the 32 hypotheses and its maximum
         logit = self._conv(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), pv + "conv.0.conv.", act="relu_dot", aux1=self.pvw_dot)
         vw = ops.softmax_max(logit.view(b * s, INIT_SAMPLES, h3, w3))
-        view_w = ops.bilinear_up(vw, 2).view(b, s, 2 * h3, 2 * w3)                                 # itermvs.py:56-57,71
-        agg0 = ops.view_aggregate(corr_v, vw.view(b, s, h3, w3))                                   # [B,32,8,h3,w3]
+        agg0, view_w = ops.view_aggregate_up(corr_v, vw.view(b, s, h3, w3))       # [B,32,8,h3,w3]; view weights x2: itermvs.py:56-57,71
         score0 = self.stage_score0(agg0)
         self.stage_hidden0(ws, score0)
         if trace is not None:
@@ -319,14 +318,14 @@ class InferenceEngine:
         ws = self._workspace(b, h, wd)
         hx = ws["hx"]
 
-        pstack = projs if torch.is_tensor(projs) else torch.stack([projs[1], projs[2], projs[3]])
-        proj, inv_min, inv_max = ops.compose_proj(pstack.reshape(3 * b, v, 4, 4), self.nan_flag, (depth_min, depth_max))
-        proj = proj.view(3, b, s, 12)
-
         f2p = self.o2_planar
         ref2_nchw = f2p[:1] if b == 1 else f2p.view(b, v, *f2p.shape[1:])[:, 0].contiguous()
         up_logits = self.upsample_logits(ref2_nchw, ws)                 # only needed by the final convex up-sampling
-        ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
+        # camera composition (+ inverse depth range) rides in the launch that packs the reference features
+        pstack = projs if torch.is_tensor(projs) else torch.stack([projs[1], projs[2], projs[3]])
+        ref_q, proj, inv_min, inv_max = ops.ref_quarter_compose(ref[1], ref[2], ref[3], pstack.reshape(3 * b, v, 4, 4), self.nan_flag,
+                                                                (depth_min, depth_max))
+        proj = proj.view(3, b, s, 12)
 
         view_w = self.stage_init(ws, src[3], ref[3], proj[2], inv_min, inv_max, trace)          # itermvs.py:270-276
         logits, best = self.stage_head(ws, trace is not None)
@@ -351,9 +350,8 @@ class InferenceEngine:
                                            hidden=ws["hidden"].clone(), logits=logits, best=best,
                                            nd=hx[:, HIDDEN:HIDDEN + 1].clone(), conf=conf))
 
-        depth_up = ops.convex_upsample(up_logits, hx, inv_min, inv_max, nd_channel=HIDDEN)      # itermvs.py:321-322
-        conf_up = ops.bilinear_up(conf, 4)                                                      # itermvs.py:323-324
-        return depth_up, conf_up
+        # convex up-sampling of the depth and bilinear up-sampling of the confidence: one launch     itermvs.py:321-324
+        return ops.final_upsample(up_logits, hx, inv_min, inv_max, conf, nd_channel=HIDDEN)
 
     def check_projection_finite(self) -> None:
         """Deferred form of the reference's NaN asserts (module.py:83,87) for every ``run`` / graph replay enqueued since

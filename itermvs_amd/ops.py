@@ -145,6 +145,24 @@ def ref_quarter(ref1: Tensor, ref2: Tensor, ref3: Tensor) -> Tensor:
     return out
 
 
+def ref_quarter_compose(ref1: Tensor, ref2: Tensor, ref3: Tensor, mats: Tensor, nan_flag: Optional[Tensor], depth_range):
+    """ref_quarter and compose_proj (with the inverse depth range) in ONE launch -- two independent pieces of work that both
+    precede the correlation kernels.  Returns (ref_q, proj, inv_min, inv_max)."""
+    b, _, h, w = ref2.shape
+    cq = ref1.shape[1] + ref2.shape[1] + ref3.shape[1]
+    out = torch.empty((b, h, w, cq), device=ref2.device, dtype=torch.float32)
+    f1, f2, f3 = fmap(ref1, "ref1"), fmap(ref2, "ref2"), fmap(ref3, "ref3")
+    mats = _dev(mats, "mats").contiguous()
+    n, v = mats.shape[0], mats.shape[1]
+    proj = torch.empty((n, v - 1, 12), device=mats.device, dtype=torch.float32)
+    dmin, dmax = (_dev(t, "depth range").contiguous() for t in depth_range)
+    imin, imax = torch.empty_like(dmin), torch.empty_like(dmax)
+    check(_lib.load().itermvs_ref_quarter_compose(C.byref(f1), C.byref(f2), C.byref(f3), b, out.data_ptr(), mats.data_ptr(), n, v,
+                                                  proj.data_ptr(), _ptr(nan_flag), dmin.data_ptr(), dmax.data_ptr(), dmin.numel(),
+                                                  imin.data_ptr(), imax.data_ptr(), _stream()), "itermvs_ref_quarter_compose")
+    return out, proj, imin, imax
+
+
 def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, view_w: Tensor,
               inv_min: Tensor, inv_max: Tensor, depth: Optional[Dict[int, Tensor]] = None,
               norm_depth: Optional[Tensor] = None, offsets: Optional[Dict[int, Sequence[float]]] = None,
@@ -371,6 +389,19 @@ def view_aggregate(corr: Tensor, w: Tensor) -> Tensor:
     return out
 
 
+def view_aggregate_up(corr: Tensor, w: Tensor) -> Tuple[Tensor, Tensor]:
+    """view_aggregate and, in the same launch, the x2 bilinear up-sampling of the view weights (itermvs.py:56-57,71):
+    corr [B,S,N,8,H,W], w [B,S,H,W] -> ([B,N,8,H,W], [B,S,2H,2W])."""
+    b, s, n, g, h, wd = corr.shape
+    corr = _dev(corr, "corr").contiguous()
+    w = _dev(w, "w").contiguous()
+    out = torch.empty((b, n, g, h, wd), device=corr.device, dtype=torch.float32)
+    w_up = torch.empty((b, s, 2 * h, 2 * wd), device=corr.device, dtype=torch.float32)
+    check(_lib.load().itermvs_view_aggregate_up(corr.data_ptr(), w.data_ptr(), s, b, n, h, wd, out.data_ptr(), w_up.data_ptr(),
+                                                _stream()), "itermvs_view_aggregate_up")
+    return out, w_up
+
+
 def pvw_tail(x: Tensor, weight: Tensor, bias: Optional[Tensor], n_hyp: int) -> Tensor:
     """itermvs.py:343-348 fused: x [M*N,16,h,w] (after the 3x3 layer + ReLU), weight [1,16,1,1] -> [M,1,h,w]."""
     _dev(x, "x")
@@ -539,6 +570,24 @@ def convex_upsample(logits: Tensor, nd: Tensor, inv_min: Tensor, inv_max: Tensor
                                               _dev(inv_max, "inv_max").data_ptr(), b, h, w, depth.data_ptr(),
                                               _ptr(norm), _stream()), "itermvs_convex_upsample")
     return (depth, norm) if want_norm else depth
+
+
+def final_upsample(logits: Tensor, nd: Tensor, inv_min: Tensor, inv_max: Tensor, conf: Tensor, nd_channel: int = 0):
+    """convex_upsample (depth) and the x4 bilinear up-sampling of the confidence (itermvs.py:321-324) in ONE launch:
+    logits [B,144,H,W], nd buffer [B,Ct,H,W], conf [B,1,H,W] -> (depth [B,1,4H,4W], confidence [B,1,4H,4W])."""
+    _dev(logits, "logits"); _dev(nd, "nd")
+    conf = _dev(conf, "conf").contiguous()
+    b, k, h, w = logits.shape
+    assert k == 144 and nd.is_contiguous() and tuple(conf.shape[-2:]) == (h, w)
+    sb, sc, sy, sx = logits.stride()
+    depth = torch.empty((b, 1, 4 * h, 4 * w), device=logits.device, dtype=torch.float32)
+    m = conf.numel() // (h * w)
+    conf_up = torch.empty(tuple(conf.shape[:-2]) + (4 * h, 4 * w), device=logits.device, dtype=torch.float32)
+    check(_lib.load().itermvs_final_upsample(logits.data_ptr(), sb, sc, sy, sx, nd.data_ptr() + 4 * nd_channel * h * w,
+                                             nd.shape[1] * h * w, _dev(inv_min, "inv_min").data_ptr(),
+                                             _dev(inv_max, "inv_max").data_ptr(), b, h, w, depth.data_ptr(), conf.data_ptr(), m,
+                                             conf_up.data_ptr(), _stream()), "itermvs_final_upsample")
+    return depth, conf_up
 
 
 def bilinear_up_into(x: Tensor, scale: int, out: Tensor, out2: Optional[Tensor] = None, act: str = "none") -> Tensor:

@@ -626,3 +626,38 @@ def test_error_codes_on_gpu_tensors():
     y = torch.zeros((1, 48, 4, 4), device=DEV)                                                  # NCHW -> layout error
     with pytest.raises(RuntimeError, match="channels-last"):
         o.corr_init([y], y, torch.zeros((1, 1, 12), device=DEV), torch.ones(1, device=DEV), torch.ones(1, device=DEV))
+
+
+@pytest.mark.gpu
+def test_launches_that_carry_a_second_piece_of_work_equal_the_separate_ones():
+    """ref_quarter_compose / view_aggregate_up / final_upsample run two independent kernels' work in one launch (extra
+    blocks): results must be bit-identical to the separate entry points, incl. the NaN flag of compose_proj"""
+    gen = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(s, generator=gen).to(DEV)
+    b, v, h, w = 2, 4, 24, 40
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    r1, r2, r3 = cl(r(b, 16, 2 * h, 2 * w)), cl(r(b, 32, h, w)), cl(r(b, 48, h // 2, w // 2))
+    mats = torch.eye(4).repeat(3 * b, v, 1, 1).to(DEV) + 0.1 * r(3 * b, v, 4, 4)
+    dmin, dmax = torch.tensor([400.0, 425.0], device=DEV), torch.tensor([900.0, 935.0], device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    proj, imin, imax = ops().compose_proj(mats, flag, (dmin, dmax))
+    rq, proj2, imin2, imax2 = ops().ref_quarter_compose(r1, r2, r3, mats, flag, (dmin, dmax))
+    assert torch.equal(rq, ops().ref_quarter(r1, r2, r3)) and torch.equal(proj, proj2)
+    assert torch.equal(imin, imin2) and torch.equal(imax, imax2) and int(flag.item()) == 0
+    bad = mats.clone()
+    bad[1, 0] = 0.0                                                   # singular reference camera
+    ops().ref_quarter_compose(r1, r2, r3, bad, flag, (dmin, dmax))
+    assert int(flag.item()) == 1
+
+    s, n, h3, w3 = 3, 32, 12, 20
+    corr, vw = r(b, s, n, 8, h3, w3), torch.rand((b, s, h3, w3), generator=gen).to(DEV)
+    agg, up = ops().view_aggregate_up(corr, vw)
+    assert torch.equal(agg, ops().view_aggregate(corr, vw))
+    assert torch.equal(up, ops().bilinear_up(vw.view(b * s, 1, h3, w3), 2).view(b, s, 2 * h3, 2 * w3))
+
+    logits, nd = r(b, 144, h, w), torch.rand((b, 43, h, w), generator=gen).to(DEV)
+    conf = torch.rand((b, 1, h, w), generator=gen).to(DEV)
+    inv_min, inv_max = 1.0 / dmin, 1.0 / dmax
+    depth, conf_up = ops().final_upsample(logits, nd, inv_min, inv_max, conf, nd_channel=32)
+    assert torch.equal(depth, ops().convex_upsample(logits, nd, inv_min, inv_max, nd_channel=32))
+    assert torch.equal(conf_up, ops().bilinear_up(conf, 4))
