@@ -126,6 +126,11 @@ int itermvs_ref_quarter_compose(const itermvs_fmap* r1, const itermvs_fmap* r2, 
                                 const float* depth_min, const float* depth_max, int32_t Bd, float* inv_min, float* inv_max,
                                 void* stream);
 
+/* itermvs_copy_multi -- n (<= 8) device-to-device copies of bytes[i] bytes in ONE launch: the staging of a sample (images +
+ * cameras + depth range) into the static input buffers a captured hipGraph reads (engine.GraphedRunner).  src / dst / bytes
+ * are HOST arrays. */
+int itermvs_copy_multi(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * itermvs_corr_iter -- models/itermvs.py:84-120 (Evaluation.forward, iteration branch, up to
  * but excluding CorrNet) fused with module.py:68-125 and, optionally, the hypothesis

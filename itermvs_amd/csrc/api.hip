@@ -175,3 +175,46 @@ extern "C" int itermvs_profile_collect(int32_t* kind, float* ms, int32_t max_sam
     g_used = 0;
     return n;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// itermvs_copy_multi: up to 8 device-to-device copies in ONE launch (the staging of a sample into the static inputs of a
+// captured graph: 20 MB of images + five small tensors would otherwise be a memcpy and a multi-tensor kernel)
+// ---------------------------------------------------------------------------------------------
+namespace itermvs {
+struct CopyMultiArgs {
+    const char* src[8];
+    char* dst[8];
+    int64_t bytes[8];
+};
+__global__ void __launch_bounds__(256) copy_multi_kernel(CopyMultiArgs a) {
+    const int k = blockIdx.y;
+    const int64_t n = a.bytes[k];
+    const char* __restrict__ s = a.src[k];
+    char* __restrict__ d = a.dst[k];
+    const int64_t n16 = (((uintptr_t)s | (uintptr_t)d) & 15) == 0 ? n / 16 : 0;       // 16-byte pieces when both are aligned
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+        reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+    for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) d[i] = s[i];
+}
+}  // namespace itermvs
+
+extern "C" int itermvs_copy_multi(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream) {
+    using namespace itermvs;
+    ITERMVS_RETURN_IF(!src || !dst || !bytes, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(n < 1 || n > 8, ITERMVS_ERR_DIMS);
+    CopyMultiArgs a{};
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        ITERMVS_RETURN_IF(bytes[i] < 0, ITERMVS_ERR_DIMS);
+        ITERMVS_RETURN_IF(bytes[i] > 0 && (!src[i] || !dst[i]), ITERMVS_ERR_NULL);
+        a.src[i] = (const char*)src[i]; a.dst[i] = (char*)dst[i]; a.bytes[i] = bytes[i];
+        most = bytes[i] > most ? bytes[i] : most;
+    }
+    if (most == 0) return ITERMVS_OK;
+    int64_t blocks = (most / 16 + 256 * 4 - 1) / (256 * 4);          // four 16-byte pieces per thread of the largest tensor
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(copy_multi_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+    return itermvs_launch_status();
+}

@@ -174,20 +174,21 @@ __device__ __forceinline__ void ld4(const itermvs_fmap& f, int b, int c, int y, 
     }
 }
 
-// blocks [0, n_ref) resample the reference features; with `with_compose` the blocks after them evaluate compose_proj (an
-// independent piece of work of a few threads that would otherwise cost a launch of its own: itermvs_ref_quarter_compose)
+// The first n_comp blocks (itermvs_ref_quarter_compose; otherwise 0) evaluate compose_proj -- an independent piece of work
+// of a few threads that would otherwise cost a launch of its own; its fp64 elimination is a long dependent chain, so it is
+// dispatched FIRST and runs beside the blocks that resample the reference features.
 template <int FT>
-__global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fmap r3, int B, float* __restrict__ out, int n_ref,
+__global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fmap r3, int B, float* __restrict__ out, int n_comp,
                                    ComposeArgs comp) {
-    if ((int)blockIdx.x >= n_ref) {
-        compose_proj_body(comp, ((int)blockIdx.x - n_ref) * (int)blockDim.x + (int)threadIdx.x);
+    if ((int)blockIdx.x < n_comp) {
+        compose_proj_body(comp, (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x);
         return;
     }
     const int H = r2.H, W = r2.W;
     const int CQ = r1.C + r2.C + r3.C;
     const int quads = CQ / 4;
     const int64_t total = (int64_t)B * H * W * quads;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = (int64_t)((int)blockIdx.x - n_comp) * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int q = (int)(t % quads);
     const int x = (int)((t / quads) % W);
@@ -289,9 +290,9 @@ static int launch_ref_quarter(const itermvs_fmap* r1, const itermvs_fmap* r2, co
     }
     const dim3 grid((unsigned)(n_ref + extra));
     switch (r1->dtype) {
-        case ITERMVS_F32: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F32>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, n_ref, c); break;
-        case ITERMVS_F16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, n_ref, c); break;
-        case ITERMVS_BF16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_BF16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, n_ref, c); break;
+        case ITERMVS_F32: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F32>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, extra, c); break;
+        case ITERMVS_F16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, extra, c); break;
+        case ITERMVS_BF16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_BF16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, extra, c); break;
         default: return ITERMVS_ERR_DTYPE;
     }
     return itermvs_launch_status();

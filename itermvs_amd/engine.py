@@ -410,10 +410,12 @@ class GraphedRunner:
             if t is not d:
                 dst.append(d)
                 src.append(t)
-        if dst and dst[0] is self.imgs:             # the images: a plain copy (the multi-tensor kernel is 2x slower on 20 MB)
-            dst[0].copy_(src[0], non_blocking=True)
-            dst, src = dst[1:], src[1:]
         if dst:
-            torch._foreach_copy_(dst, src)          # cameras + depth range: one multi-tensor launch instead of five copies
+            ok = all(t.is_cuda and t.is_contiguous() and t.dtype == d.dtype and t.shape == d.shape for d, t in zip(dst, src))
+            if ok:
+                ops.copy_multi(dst, src)            # images + cameras + depth range: ONE launch
+            else:
+                for d, t in zip(dst, src):
+                    d.copy_(t, non_blocking=True)
         self.graph.replay()
         return self.out

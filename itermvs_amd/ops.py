@@ -145,6 +145,24 @@ def ref_quarter(ref1: Tensor, ref2: Tensor, ref3: Tensor) -> Tensor:
     return out
 
 
+def copy_multi(dst: Sequence[Tensor], src: Sequence[Tensor]) -> None:
+    """dst[i].copy_(src[i]) for up to 8 dense tensor pairs of equal dtype and shape in ONE launch (itermvs_copy_multi)"""
+    n = len(dst)
+    if n == 0:
+        return
+    if n > 8 or len(src) != n:
+        raise RuntimeError("copy_multi: 1..8 tensor pairs")
+    for d, t in zip(dst, src):
+        if not (isinstance(d, torch.Tensor) and isinstance(t, torch.Tensor) and d.is_cuda and t.is_cuda):
+            raise RuntimeError("copy_multi: expected CUDA/ROCm tensors - the IterMVS HIP engine has no CPU path")
+        if d.dtype != t.dtype or d.shape != t.shape or not d.is_contiguous() or not t.is_contiguous():
+            raise RuntimeError("copy_multi: pairs must be dense tensors of equal dtype and shape")
+    sp = (C.c_void_p * n)(*[t.data_ptr() for t in src])
+    dp = (C.c_void_p * n)(*[d.data_ptr() for d in dst])
+    nb = (C.c_int64 * n)(*[d.numel() * d.element_size() for d in dst])
+    check(_lib.load().itermvs_copy_multi(sp, dp, nb, n, _stream()), "itermvs_copy_multi")
+
+
 def ref_quarter_compose(ref1: Tensor, ref2: Tensor, ref3: Tensor, mats: Tensor, nan_flag: Optional[Tensor], depth_range):
     """ref_quarter and compose_proj (with the inverse depth range) in ONE launch -- two independent pieces of work that both
     precede the correlation kernels.  Returns (ref_q, proj, inv_min, inv_max)."""

@@ -661,3 +661,18 @@ def test_launches_that_carry_a_second_piece_of_work_equal_the_separate_ones():
     depth, conf_up = ops().final_upsample(logits, nd, inv_min, inv_max, conf, nd_channel=32)
     assert torch.equal(depth, ops().convex_upsample(logits, nd, inv_min, inv_max, nd_channel=32))
     assert torch.equal(conf_up, ops().bilinear_up(conf, 4))
+
+
+@pytest.mark.gpu
+def test_copy_multi_stages_a_sample_in_one_launch():
+    """itermvs_copy_multi (GraphedRunner's staging of images + cameras + depth range): sizes from 4 bytes to 20 MB, a
+    source that is not 16-byte aligned, a dtype other than float"""
+    gen = torch.Generator().manual_seed(5)
+    src = [torch.randn((1, 5, 3, 512, 640), generator=gen).to(DEV), torch.randn((3, 1, 5, 4, 4), generator=gen).to(DEV),
+           torch.randn((1,), generator=gen).to(DEV), torch.randn((1027,), generator=gen).to(DEV)[1:],
+           torch.randint(0, 255, (7, 13), generator=gen, dtype=torch.uint8).to(DEV)]
+    dst = [torch.zeros_like(t) for t in src]
+    ops().copy_multi(dst, src)
+    assert all(torch.equal(d, t) for d, t in zip(dst, src))
+    with pytest.raises(RuntimeError):
+        ops().copy_multi(dst[:1], [src[0].double()])

@@ -2,7 +2,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 O=gpurun_out/r2g
-timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_pipeline_gpu.py tests/test_teacher_forced_gpu.py -q -k "carry or seam or cfg1 or graph or every_stage or nan or compose or ref_quarter or upsample" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_pipeline_gpu.py tests/test_teacher_forced_gpu.py -q -k "carry or copy_multi or seam or cfg1 or graph or every_stage or nan or compose or ref_quarter or upsample" 2>&1 | tail -3
 timeout 300 python bench.py --steps 60 --minimal > ${O}_bench.json 2> ${O}_bench.err
 python -c "
 import json

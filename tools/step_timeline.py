@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-kernel timeline of one bench step from a rocprofv3 --kernel-trace CSV (steps are delimited by
-compose_proj_kernel launches).  usage: step_timeline.py <kernel_trace.csv> [step_index]"""
+"""Per-kernel timeline of one bench step from a rocprofv3 --kernel-trace CSV (steps are delimited by the first kernel of
+FeatureNet, stem_kernel; traces of older builds by compose_proj_kernel).  usage: step_timeline.py <kernel_trace.csv> [step_index]"""
 import collections
 import csv
 import sys
@@ -9,7 +9,9 @@ import sys
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "compose_proj" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if "stem_kernel" in r["Kernel_Name"]]
+    if len(idx) < 2:
+        idx = [i for i, r in enumerate(rows) if "compose_proj" in r["Kernel_Name"]]
     k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
     s, e = idx[k], idx[k + 1]
     t0 = int(rows[s]["Start_Timestamp"])
