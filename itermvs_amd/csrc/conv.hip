@@ -142,10 +142,10 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     ITERMVS_RETURN_IF(!p->in || !p->out || !p->weight[0], ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->N < 1 || p->Cin < 1 || p->Cout < 1 || p->Hin < 1 || p->Win < 1, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(p->ksize != 1 && p->ksize != 3, ITERMVS_ERR_DIMS);
-    ITERMVS_RETURN_IF(p->n_seg < 1 || p->n_seg > 3 || p->act < 0 || p->act > 6, ITERMVS_ERR_DIMS);
-    ITERMVS_RETURN_IF(p->act == 6 && (!p->aux1 || p->add || p->out2 || p->out_layout != 0 || p->Cout != 16 || p->weight_format != 2 ||
+    ITERMVS_RETURN_IF(p->n_seg < 1 || p->n_seg > 3 || p->act < 0 || p->act > 7, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF((p->act == 6 || p->act == 7) && (!p->aux1 || p->add || p->out2 || p->out_layout != 0 || (p->Cout != 16 && p->Cout != 32) || p->weight_format != 2 || p->ksize != 3 ||
                                       p->split_cout != 0 || p->transposed || p->n_seg != 1), ITERMVS_ERR_DIMS);
-    ITERMVS_RETURN_IF((p->act == 4 || p->act == 5 || p->act == 6) && !p->aux1, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF((p->act == 4 || p->act == 5 || p->act == 6 || p->act == 7) && !p->aux1, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->act == 5 && !p->aux2, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->act >= 2 && p->add, ITERMVS_ERR_DIMS);   // residual add only with none / relu
     ITERMVS_RETURN_IF(p->add_mode < 0 || p->add_mode > 1, ITERMVS_ERR_DIMS);

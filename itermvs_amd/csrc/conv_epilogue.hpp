@@ -237,19 +237,27 @@ __device__ __forceinline__ void conv_epilogue_nhwc(const EpilogueArgs& e, const 
 template <int MB, int NB>
 __device__ __forceinline__ void conv_epilogue_dot(const EpilogueArgs& e, const f32x4 (&acc)[MB][NB], int q,
                                                   const uint32_t (&pix_off)[NB]) {
+    // the wave holds ALL MB*16 channels of its pixels (the launcher forces the channel blocking for act 6 / 7):
+    // aux1 = {w[0 .. 16*MB-1], bias}; act 7 applies a sigmoid to the result (the confidence head, itermvs.py:147-151,198)
     const __amdgpu_buffer_rsrc_t ro = epi_rsrc(e.out, (uint32_t)e.P * 4u);
-    float wv[4];
+    float wv[MB][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) wv[r] = e.aux1[q * 4 + r];
-    const float bias = e.aux1[16];
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wv[mb][r] = e.aux1[mb * 16 + q * 4 + r];
+    const float bias = e.aux1[16 * MB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         float s = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s = fmaf(fmaxf(acc[0][nb][r], 0.0f), wv[r], s);
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s = fmaf(fmaxf(acc[mb][nb][r], 0.0f), wv[mb][r], s);
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        epi_store(s + bias, ro, q == 0 ? pix_off[nb] : kEpiOob, 0);
+        s += bias;
+        if (e.act == 7) s = sigmoidf_(s);
+        epi_store(s, ro, q == 0 ? pix_off[nb] : kEpiOob, 0);
     }
 }
 
@@ -260,7 +268,7 @@ template <int MB, int NB>
 __device__ __forceinline__ void conv_epilogue(const EpilogueArgs& e, const f32x4 (&acc)[MB][NB], int m0, int q,
                                               const uint32_t (&pix_off)[NB], const int (&py)[NB], const int (&px)[NB]) {
     if (e.out_nhwc) return conv_epilogue_nhwc<MB, NB>(e, acc, m0, q, pix_off);
-    if (e.act == 6) return conv_epilogue_dot<MB, NB>(e, acc, q, pix_off);
+    if (e.act == 6 || e.act == 7) return conv_epilogue_dot<MB, NB>(e, acc, q, pix_off);
     const int key = e.act * 3 + (e.add ? 1 + e.add_mode : 0);
     switch (key) {
         case 0: conv_epilogue_act<0, 0, MB, NB>(e, acc, m0, q, pix_off, py, px); break;

@@ -632,9 +632,15 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
         mb = force[2] - '0';
         if (shape < 0 || shape > 2 || mb < 1 || mb > 3 || mt % mb != 0) return 1;
     }
+    const bool dot = p->act == 6 || p->act == 7;     // the epilogue contracts over ALL output channels: one block per wave
+    if (dot) {
+        mb = mt;
+        if (mt == 2) shape = 0;                      // two blocks per wave run as 4x16 tiles
+    }
     // the weights of the channel block must fit LDS next to at least one input stage: narrow the block
     int rc = 1;
     for (; rc == 1 && mb >= 1; --mb) {
+        if (dot && mb != mt) return 1;
         if (mt % mb != 0 || (p->split_cout && (p->split_cout / 16) % mb != 0)) continue;
         if (S == 1) {
             if (!s1d1) return 1;

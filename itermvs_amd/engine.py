@@ -112,6 +112,8 @@ class InferenceEngine:
             else:
                 pk[k] = pack(v)
         pv = "iter_mvs.evaluation.pixel_view_weight.conv.1."
+        cf = "iter_mvs.update.confidence_head.2."
+        self.conf_dot = torch.cat([w[cf + "weight"].reshape(-1), w[cf + "bias"].reshape(-1)]).float().contiguous()
         self.pvw_dot = torch.cat([w[pv + "weight"].reshape(-1), w[pv + "bias"].reshape(-1)]).float().contiguous()
         self.stem_w = ops.pack_stem_weights(*self.cbr["conv1."], *self.cbr["layer1.0.conv1."], *self.cbr["layer1.0.downsample."])
         self.corrnet_w = {l: ops.pack_corrnet_weights(w, f"iter_mvs.evaluation.corr_conv1.{l - 1}.") for l in (1, 2, 3)}
@@ -192,8 +194,9 @@ class InferenceEngine:
     def confidence(self, hidden: Tensor, mid: Tensor = None, out: Tensor = None) -> Tensor:
         """itermvs.py:147-151 + sigmoid (:198)"""
         p = "iter_mvs.update.confidence_head."
-        x = self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu", out=mid)
-        return self._conv(x, p + "2.", bias=True, ksize=1, pad=0, act="sigmoid", out=out)
+        # the 1x1 layer to one channel and the sigmoid are the epilogue of the dilated 3x3 layer (one launch, the 32-channel
+        # tensor is never stored)
+        return self._conv(hidden, p + "0.", pad=2, dilation=2, act="relu_dot_sigmoid", aux1=self.conf_dot, out=out)
 
     def upsample_logits(self, ref2_nchw: Tensor, ws: dict) -> Tensor:
         """itermvs.py:262-263 (the softmax over the 9 taps is part of convex_upsample)"""

@@ -634,7 +634,7 @@ def bilinear_up(x: Tensor, scale: int, act: str = "none") -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------
-ACT = {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "gru_rh": 4, "gru_out": 5, "relu_dot": 6}
+ACT = {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "gru_rh": 4, "gru_out": 5, "relu_dot": 6, "relu_dot_sigmoid": 7}
 
 
 def pack_conv_weight(w: Tensor, transposed: bool = False) -> Tensor:
@@ -723,9 +723,11 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
         hout, wout = (hin + 2 * pad - span) // stride + 1, (win + 2 * pad - span) // stride + 1
     cout_total = cout
     dot = None
-    if act == "relu_dot":      # ReLU + a 1x1 convolution to one channel in the epilogue: aux1 = 17 floats {w[16], bias}
-        if not (mfma and tiled and cout == 16 and aux1 is not None and aux1.numel() == 17 and add is None and out2 is None and split is None):
-            raise RuntimeError("conv2d: act='relu_dot' needs a 16-channel 3x3 matrix-core layer and aux1 = 17 floats")
+    if act in ("relu_dot", "relu_dot_sigmoid"):
+        # ReLU + a 1x1 convolution to ONE channel (+ sigmoid) in the epilogue: aux1 = Cout + 1 floats {w[Cout], bias}
+        if not (mfma and tiled and cout in (16, 32) and aux1 is not None and aux1.numel() == cout + 1 and add is None and out2 is None
+                and split is None):
+            raise RuntimeError("conv2d: act='relu_dot' needs a 16- or 32-channel 3x3 matrix-core layer and aux1 = Cout + 1 floats")
         dot, aux1, cout = _dev(aux1, "aux1").contiguous(), None, 1
     if split is not None:
         if not (mfma and ksize == 3 and not transposed):

@@ -274,6 +274,13 @@ def test_relu_dot_epilogue_is_conv_relu_conv1x1():
     assert got.shape == want.shape == (24, 1, 23, 37) and rel_err(got, want) <= 2e-6
     with pytest.raises(RuntimeError):
         ops().conv2d(x, ops().MfmaWeight(w0), None, act="relu_dot", aux1=w1.reshape(-1))
+    # 32 channels, dilation 2, sigmoid: the confidence head (itermvs.py:147-151,198) in one launch
+    h = torch.randn((2, 32, 37, 50), generator=gen).to(DEV)
+    c0 = (torch.randn((32, 32, 3, 3), generator=gen) * 0.1).to(DEV)
+    c1 = torch.randn((1, 32, 1, 1), generator=gen).to(DEV)
+    want = torch.sigmoid(F.conv2d(F.relu(F.conv2d(h, c0, padding=2, dilation=2)), c1, b1))
+    got = ops().conv2d(h, ops().MfmaWeight(c0), None, pad=2, dilation=2, act="relu_dot_sigmoid", aux1=torch.cat([c1.reshape(-1), b1]))
+    assert got.shape == want.shape == (2, 1, 37, 50) and float((got - want).abs().max()) <= 2e-6
 
 
 @pytest.mark.parametrize("case", [(5, 512, 640), (2, 96, 160), (1, 50, 70), (3, 16, 64), (1, 7, 5)])
