@@ -327,9 +327,11 @@ int itermvs_bilinear_up2(const float* x, int32_t B, int32_t C, int32_t H, int32_
  * (the three CorrNets of one iteration in one launch).
  * Epilogue `act`: 0 v+add | 1 relu(v+add) | 2 sigmoid | 3 tanh | 4 sigmoid(v)*aux1 (r*h) |
  *                 5 (1-aux2)*aux1 + aux2*tanh(v)  (GRU state update; aux1 = h, aux2 = z) |
- *                 6 sum_co relu(v[co]) * aux1[co] + aux1[16]: a following 1x1 convolution to ONE channel folded into the
- *                   epilogue (PixelViewWeight, models/itermvs.py:337-346); Cout = 16, weight_format 2, `out` is the single
- *                   plane [N,1,H,W] (batch stride out_sn), aux1 = 17 floats shared by all batch items (aux1_sn = 0).
+ *                 6 sum_co relu(v[co]) * aux1[co] + aux1[Cout]: a following 1x1 convolution to ONE channel folded into the
+ *                   epilogue (PixelViewWeight, models/itermvs.py:337-346); Cout = 16 or 32, 3x3, weight_format 2, `out` is the
+ *                   single plane [N,1,H,W] (batch stride out_sn), aux1 = Cout + 1 floats shared by all batch items
+ *                   (aux1_sn = 0) |
+ *                 7 sigmoid of 6 (the confidence head, models/itermvs.py:147-151,198).
  * `add_mode` 0: `add` has the output's shape; 1: `add` is [N,Cout,Hout/2,Wout/2] and its x2 bilinear
  *   up-sampling (F.interpolate(scale_factor=2, mode='bilinear'), models/net.py:46,49) is evaluated
  *   in the epilogue (matrix-core formats only, Hout and Wout even).
