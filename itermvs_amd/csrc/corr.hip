@@ -379,9 +379,14 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
             y = p / a.W; x = p - y * a.W;
         }
         float refv[K::VEC];
+        if (a.ref.sc == 1) {       // channels-last reference (the engine's layout): the chunk is VEC/4 vector loads off one address
+            load_feat<K::VEC, FT>(feat_base<FT>((const float*)a.ref.data, (int64_t)b * a.ref.sb),
+                                  (uint32_t)(y * (int)a.ref.sy + x * (int)a.ref.sx) + (uint32_t)(j * 4), refv);
+        } else {
 #pragma unroll
-        for (int c = 0; c < K::VEC; ++c)
-            refv[c] = ld_feat<FT>((const float*)a.ref.data, b * a.ref.sb + chunk_channel<K::VEC>(j, c) * a.ref.sc + y * a.ref.sy + x * a.ref.sx);
+            for (int c = 0; c < K::VEC; ++c)
+                refv[c] = ld_feat<FT>((const float*)a.ref.data, b * a.ref.sb + chunk_channel<K::VEC>(j, c) * a.ref.sc + y * a.ref.sy + x * a.ref.sx);
+        }
         // lane j projects hypothesis grp*LPT + j once; the group then walks its LPT hypotheses and
         // every lane reads the footprint of hypothesis k from lane k (wavefront shuffles)
         const int nl_mine = grp * K::LPT + j;
