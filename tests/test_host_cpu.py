@@ -98,6 +98,48 @@ def test_ops_refuse_cpu_tensors():
         ops.bilinear_up(torch.zeros(1, 1, 4, 4), 2)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.compose_proj(torch.eye(4).repeat(1, 2, 1, 1))
+    # the round-2 entry points: CPU tensors are refused before anything is launched
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.stem(torch.zeros(1, 3, 8, 8), torch.zeros(ops.STEM_W0_FLOATS), torch.zeros(ops.STEM_W1_FLOATS))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.corrnet(torch.zeros(1, 8, 8, 8), [torch.zeros(ops.CORRNET_WEIGHT_FLOATS)])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.copy_multi([torch.zeros(4)], [torch.ones(4)])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.view_aggregate_up(torch.zeros(1, 2, 4, 8, 4, 4), torch.zeros(1, 2, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.final_upsample(torch.zeros(1, 144, 4, 4), torch.zeros(1, 43, 4, 4), torch.ones(1), torch.ones(1), torch.zeros(1, 1, 4, 4))
+
+
+def test_weight_packings_of_the_fused_kernels():
+    """pack_stem_weights / pack_corrnet_weights lay the weights out as include/itermvs_hip.h documents (CPU, no launch)"""
+    from itermvs_amd import ops
+    g = torch.Generator().manual_seed(2)
+    w0, b0 = torch.randn((8, 3, 3, 3), generator=g), torch.randn((8,), generator=g)
+    w1, b1 = torch.randn((16, 8, 3, 3), generator=g), torch.randn((16,), generator=g)
+    wd, bd = torch.randn((16, 8, 3, 3), generator=g), torch.randn((16,), generator=g)
+    p0, p1 = ops.pack_stem_weights(w0, b0, w1, b1, wd, bd)
+    assert p0.numel() == ops.STEM_W0_FLOATS and p1.numel() == ops.STEM_W1_FLOATS
+    ci, ky, kx, co = 2, 1, 2, 5
+    assert p0[((ci * 3 + ky) * 3 + kx) * 8 + co] == w0[co, ci, ky, kx] and torch.equal(p0[216:], b0)
+    tap, ks, q = ky * 3 + kx, 1, 3                       # ci = 4 * ks + q = 7
+    assert p1[((tap * 2 + ks) * 4 + q) * 32 + co] == w1[co, 7, ky, kx]
+    assert p1[((tap * 2 + ks) * 4 + q) * 32 + 16 + co] == wd[co, 7, ky, kx]
+    assert torch.equal(p1[2304:2320], b1) and torch.equal(p1[2320:], bd)
+    with pytest.raises(RuntimeError):
+        ops.pack_stem_weights(w0[:4], b0, w1, b1, wd, bd)
+    # CorrNet: conv0 in its two-rows-per-tile form
+    names = {"conv0.conv.weight": (8, 8, 3, 3), "conv1.conv.weight": (16, 8, 3, 3), "conv2.conv.weight": (32, 16, 3, 3),
+             "conv3.weight": (32, 16, 3, 3), "conv4.weight": (16, 8, 3, 3), "conv5.weight": (1, 8, 3, 3), "conv5.bias": (1,)}
+    w = {"p." + k: torch.randn(v, generator=g) for k, v in names.items()}
+    pk = ops.pack_corrnet_weights(w, "p.")
+    assert pk.numel() == ops.CORRNET_WEIGHT_FLOATS
+    c0 = w["p.conv0.conv.weight"]
+    wr, kx, ks, q, co = 2, 1, 1, 2, 3                    # window row 2: tap row 2 of the first output row, tap row 1 of the second
+    idx = (((wr * 3 + kx) * 2 + ks) * 4 + q) * 16
+    assert pk[idx + co] == c0[co, 4 * ks + q, 2, kx] and pk[idx + 8 + co] == c0[co, 4 * ks + q, 1, kx]
+    idx0 = (((0 * 3 + kx) * 2 + ks) * 4 + q) * 16       # window row 0 is outside the second output row's taps
+    assert pk[idx0 + co] == c0[co, 4 * ks + q, 0, kx] and pk[idx0 + 8 + co] == 0
 
 
 def test_product_package_never_imports_the_oracle():
