@@ -442,12 +442,29 @@ __global__ void __launch_bounds__(kThreads) corr_init_kernel(const InitArgs a) {
 // Blocks [0, n_agg) aggregate; the blocks after them (itermvs_view_aggregate_up) up-sample the view weights x2 for the
 // iterations (itermvs.py:56-57,71): both only read `w`, one launch instead of two.
 __global__ void view_aggregate_kernel(const float* __restrict__ corr, const float* __restrict__ w, int S, int B, int NG,
-                                      int P, float* __restrict__ out, int n_agg, int H3, int W3, float* __restrict__ w_up) {
+                                      int P, float* __restrict__ out, int n_agg, int H3, int W3, float* __restrict__ w_up, int vec4) {
     if ((int)blockIdx.x >= n_agg) {
         bilinear_up_body(w, B * S, H3, W3, 2, 0, w_up, (int64_t)(blockIdx.x - n_agg) * blockDim.x + threadIdx.x);
         return;
     }
     const int64_t per = (int64_t)NG * P;
+    if (vec4) {                    // four consecutive pixels per thread: 16-byte loads and stores (same arithmetic per element)
+        const int64_t t4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const int64_t t = t4 * 4;
+        if (t >= (int64_t)B * per) return;
+        const int p = (int)(t % P);
+        const int b = (int)(t / per);
+        const int64_t r = t - (int64_t)b * per;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wsum[4] = {1e-5f, 1e-5f, 1e-5f, 1e-5f};
+        for (int s = 0; s < S; ++s) {
+            const float4 ws = *reinterpret_cast<const float4*>(w + ((size_t)b * S + s) * P + p);
+            const float4 c = *reinterpret_cast<const float4*>(corr + ((size_t)b * S + s) * per + r);
+            acc[0] = acc[0] + c.x * ws.x; acc[1] = acc[1] + c.y * ws.y; acc[2] = acc[2] + c.z * ws.z; acc[3] = acc[3] + c.w * ws.w;
+            wsum[0] = wsum[0] + ws.x; wsum[1] = wsum[1] + ws.y; wsum[2] = wsum[2] + ws.z; wsum[3] = wsum[3] + ws.w;
+        }
+        *reinterpret_cast<float4*>(out + t) = make_float4(acc[0] / wsum[0], acc[1] / wsum[1], acc[2] / wsum[2], acc[3] / wsum[3]);
+        return;
+    }
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)B * per) return;
     const int p = (int)(t % P);
@@ -677,10 +694,11 @@ extern "C" int itermvs_view_aggregate(const float* corr, const float* w, int32_t
                                       float* out, void* stream) {
     ITERMVS_RETURN_IF(!corr || !w || !out, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(S < 1 || B < 1 || N < 1 || P < 1, ITERMVS_ERR_DIMS);
-    const int64_t total = (int64_t)B * N * ITERMVS_GROUPS * P;
+    const int vec4 = (P & 3) == 0 && ((((uintptr_t)corr) | ((uintptr_t)w) | ((uintptr_t)out)) & 15) == 0;
+    const int64_t total = ((int64_t)B * N * ITERMVS_GROUPS * P) / (vec4 ? 4 : 1);
     const int na = (int)((total + 255) / 256);
     hipLaunchKernelGGL(view_aggregate_kernel, dim3((unsigned)na), dim3(256), 0, (hipStream_t)stream,
-                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, 0, 0, (float*)nullptr);
+                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, 0, 0, (float*)nullptr, vec4);
     return itermvs_launch_status();
 }
 
@@ -689,10 +707,11 @@ extern "C" int itermvs_view_aggregate_up(const float* corr, const float* w, int3
     ITERMVS_RETURN_IF(!corr || !w || !out || !w_up, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(S < 1 || B < 1 || N < 1 || H3 < 1 || W3 < 1, ITERMVS_ERR_DIMS);
     const int P = H3 * W3;
-    const int na = (int)(((int64_t)B * N * ITERMVS_GROUPS * P + 255) / 256);
+    const int vec4 = (P & 3) == 0 && ((((uintptr_t)corr) | ((uintptr_t)w) | ((uintptr_t)out)) & 15) == 0;
+    const int na = (int)(((int64_t)B * N * ITERMVS_GROUPS * P / (vec4 ? 4 : 1) + 255) / 256);
     const int nu = (int)(((int64_t)B * S * P * 4 + 255) / 256);
     hipLaunchKernelGGL(view_aggregate_kernel, dim3((unsigned)(na + nu)), dim3(256), 0, (hipStream_t)stream,
-                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, H3, W3, w_up);
+                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, H3, W3, w_up, vec4);
     return itermvs_launch_status();
 }
 
