@@ -106,6 +106,20 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
     }
     __syncthreads();
     const int rows = N * ITERMVS_GROUPS;
+    if constexpr (TILE % 4 == 0) {
+        // 16-byte stores where the rows allow it (a wave-level store costs the CU about the same whatever its width:
+        // tools/ubench/tile_read.hip): P a multiple of 4 keeps every quad of a tile row inside one plane row and aligned
+        if ((P & 3) == 0 && ((uintptr_t)L.out & 15) == 0) {
+            for (int idx = threadIdx.x; idx < rows * (TILE / 4); idx += kThreads) {
+                const int row = idx / (TILE / 4), px = (idx - row * (TILE / 4)) * 4;
+                if (p0 + px < P) {
+                    const float* __restrict__ l = lds + row * LS + px;
+                    *reinterpret_cast<float4*>(L.out + ((size_t)b * rows + row) * P + p0 + px) = make_float4(l[0], l[1], l[2], l[3]);
+                }
+            }
+            return;
+        }
+    }
     for (int idx = threadIdx.x; idx < rows * TILE; idx += kThreads) {
         const int row = idx / TILE, px = idx - row * TILE;
         if (p0 + px < P) L.out[((size_t)b * rows + row) * P + p0 + px] = lds[row * LS + px];
@@ -420,6 +434,18 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
     __syncthreads();
     const int rows = nb * ITERMVS_GROUPS;
     float* o = a.out + (((size_t)b * a.S + s) * a.N + n0) * ITERMVS_GROUPS * P;
+    if constexpr (TILE % 4 == 0) {
+        if ((P & 3) == 0 && ((uintptr_t)a.out & 15) == 0) {      // 16-byte stores (see corr_iter_level)
+            for (int idx = threadIdx.x; idx < rows * (TILE / 4); idx += kThreads) {
+                const int row = idx / (TILE / 4), px = (idx - row * (TILE / 4)) * 4;
+                if (p0 + px < P) {
+                    const float* __restrict__ l = lds + row * LS + px;
+                    *reinterpret_cast<float4*>(o + (size_t)row * P + p0 + px) = make_float4(l[0], l[1], l[2], l[3]);
+                }
+            }
+            return;
+        }
+    }
     for (int idx = threadIdx.x; idx < rows * TILE; idx += kThreads) {
         const int row = idx / TILE, px = idx - row * TILE;
         if (p0 + px < P) o[(size_t)row * P + p0 + px] = lds[row * LS + px];
