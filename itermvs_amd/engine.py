@@ -191,7 +191,7 @@ class InferenceEngine:
         x = self._conv(x, p + "2.", ksize=1, pad=0, act="relu")
         return self._conv(x, p + "4.", bias=True, ksize=1, pad=0)
 
-    def confidence(self, hidden: Tensor, mid: Tensor = None, out: Tensor = None) -> Tensor:
+    def confidence(self, hidden: Tensor, out: Tensor = None) -> Tensor:
         """itermvs.py:147-151 + sigmoid (:198)"""
         p = "iter_mvs.update.confidence_head."
         # the 1x1 layer to one channel and the sigmoid are the epilogue of the dilated 3x3 layer (one launch, the 32-channel
@@ -218,7 +218,6 @@ class InferenceEngine:
                 "zbuf": torch.empty((b, HIDDEN, h, w), device=dev),
                 "up_mid": torch.empty((b, 64, h, w), device=dev),
                 "up_logits": torch.empty((b, 144, h, w), device=dev),
-                "conf_mid": torch.empty((b, HIDDEN, h, w), device=dev),
                 "conf": torch.empty((b, 1, h, w), device=dev),
             }
             o, views = 0, []
@@ -346,7 +345,7 @@ class InferenceEngine:
             score = hx[:, HIDDEN + 1:].clone() if trace is not None else None
             self.stage_gru(ws)
             if it == self.iteration - 1:                                                         # itermvs.py:197-199
-                conf = self.confidence(ws["hidden"], ws["conf_mid"], ws["conf"])
+                conf = self.confidence(ws["hidden"], ws["conf"])
             logits, best = self.stage_head(ws, trace is not None)
             if trace is not None:
                 trace["iters"].append(dict(nd_in=nd_in, aggs=[a.clone() for a in aggs], score=score,

@@ -61,7 +61,7 @@ class MiopenEngine(InferenceEngine):
         x = F.relu_(F.conv2d(x, w[p + "2.weight"]))
         return F.conv2d(x, w[p + "4.weight"], w[p + "4.bias"])
 
-    def confidence(self, hidden, mid=None, out=None):
+    def confidence(self, hidden, out=None):
         w, p = self.w, "iter_mvs.update.confidence_head."
         x = F.relu_(F.conv2d(hidden, w[p + "0.weight"], padding=2, dilation=2))
         y = torch.sigmoid_(F.conv2d(x, w[p + "2.weight"], w[p + "2.bias"]))

@@ -152,7 +152,7 @@ def test_every_stage_on_the_oracles_inputs(wtag, kind, views, height, width, ite
             need(torch.equal(hx[:, :HID], ws["hidden"]), f"it{it}: hidden copies differ")
             if ti["conf"] is not None:
                 ws["hidden"].copy_(cu(ti["hidden"]))
-                conf = eng.confidence(ws["hidden"], ws["conf_mid"], ws["conf"])
+                conf = eng.confidence(ws["hidden"], ws["conf"])
                 lim("conf", rel_err(conf, ti["conf"]), 1e-4)
             report[f"it{it}.head"], _ = check_head(eng, ws, w_cpu, ti["hidden"], ti["best"], ti["nd"], f"iter {it}")
             hidden_in = ti["hidden"]
