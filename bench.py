@@ -28,7 +28,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
-PMC_SUMMARY = "r02_pmc_kernels.json"   # written by tools/pmc_kernels.sh on the GPU box, committed per round
+
+
+def pmc_summary_file():
+    """newest profiles/rNN_pmc_kernels.json (written by tools/pmc_kernels.sh on the GPU box, committed per round)"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_kernels.json")))
+    return found[-1] if found else None
 
 
 def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int, e: int = 4):
@@ -44,6 +50,29 @@ def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int, e: int = 4
     init = batch * (s * 48 * p3 * e + 48 * p3 * e           # level-3 source + reference features
                     + s * 8 * 32 * p3 * 4)                  # per-view correlation volume out
     return it, init, (init + iters * it) / batch
+
+
+def workload_name(views: int, height: int, width: int, iters: int) -> str:
+    """which BASELINE.json config the shape is (the bench line must name what actually ran)"""
+    key = (views, height, width, iters)
+    if key == (5, 512, 640, 4):
+        return "BASELINE cfg 2 (= cfg 1 on 1xMI355X)"
+    if key in ((5, 1152, 1600, 4), (6, 1152, 1600, 4)):
+        return "BASELINE cfg 3 shape (1600x1152: the reference crops 1200 to a multiple of 32)"
+    if key == (11, 1280, 1920, 8):
+        return "BASELINE cfg 5 shape"
+    return "custom shape (not a BASELINE config)"
+
+
+def self_launch_command(n_gpus: int, argv):
+    """the torch.distributed.run command line `python bench.py --gpus N` turns itself into when no launcher set
+    WORLD_SIZE: one process per GPU over RCCL, rendezvous on 127.0.0.1 (the container hostname may not resolve)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def cpu_baseline(args, target_seconds: float = 15.0):
@@ -155,7 +184,8 @@ def transfers_leg(args, dev, samples, world, u8: bool = False):
             ev_out[k].record(s_out)
         started[k] = True
 
-    elapsed = shard.timed_steps(step, args.steps, max(args.warmup, 4))
+    regions = shard.timed_regions(step, args.steps, max(args.warmup, 4), args.repeats)
+    elapsed = shard.median(regions)
     eng.check_projection_finite()
     if trace:
         base = trace[-8][1][0]
@@ -165,6 +195,7 @@ def transfers_leg(args, dev, samples, world, u8: bool = False):
     h2d = sum(t.numel() * t.element_size() for t in host_in[0])
     d2h = sum(t.numel() * t.element_size() for t in host_out[0])
     return {"value": world * args.steps * args.batch / elapsed, "unit": "depth-maps/s", "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
             "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h,
             "images": "uint8 RGB, normalised on the GPU (itermvs_image_pyramid)" if u8 else "float32 level_0 tensor",
             "note": "pinned host inputs -> H2D on a copy stream into the static inputs of two alternating hipGraph runners, "
@@ -184,6 +215,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=1, help="reference views per step and GPU")
     ap.add_argument("--feature-dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
                     help="storage type of the feature pyramids (BASELINE cfg 4 bf16 / cfg 5 fp16); arithmetic stays fp32")
+    ap.add_argument("--repeats", type=int, default=9,
+                    help="the --steps long timed region (barrier + device synchronise on both sides) is run this many times back "
+                         "to back; `value` / `ms_per_step` are the MEDIAN region, min / max are reported beside them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-transfers", action="store_true", help="skip the host-buffers-in / host-buffers-out leg")
     ap.add_argument("--minimal", action="store_true",
@@ -198,13 +232,18 @@ def main() -> None:
         args.no_cpu_baseline = args.no_transfers = True
         args.pipeline_streams = 0
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same flags>`
+        sys.stdout.flush()
+        os.execv(sys.executable, self_launch_command(args.gpus, sys.argv[1:]))
+
     import torch
     from itermvs_amd import ops, shard, synthetic
     from itermvs_amd.net import Pipeline
 
     rank, local_rank, world = shard.init_distributed()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -258,7 +297,8 @@ def main() -> None:
     per_step = args.iters + 1
     # (graph mode: an event-record node costs ~5-6 us of graph time on either side of the launch it brackets, so each replay
     # carries ONE timed launch: runner A a corr_iter (GRU iteration 1), runner B the corr_init)
-    ops.profile_enable((args.steps + args.warmup) * per_step + 8 * per_step, mask=0x3)
+    total_steps = args.steps * args.repeats
+    ops.profile_enable((total_steps + args.warmup) * per_step + 8 * per_step, mask=0x3)
     for k in range(n_models):                          # set-up, not a step: capture every runner's hipGraph
         with torch.cuda.stream(streams[k]):
             if ab == 2:
@@ -266,18 +306,19 @@ def main() -> None:
                 # runner B on 1, 3, ... -- every iteration position is sampled in every second replay
                 from itermvs_amd.engine import InferenceEngine
                 models[k]._engine = InferenceEngine(models[k].weights(), models[k].iteration, args.feature_dtype)
-                models[k]._engine.profile_iterations = {min(1, args.iters - 1)} if k % 2 == 0 else set()
+                models[k]._engine.profile_iterations = {0} if k % 2 == 0 else {min(2, args.iters - 1)}
                 models[k]._engine.profile_init = (k % 2 == 1)
             models[k](*samples[0])
     torch.cuda.synchronize()
     ops.profile_collect(max_samples=4096)              # drop the set-up launches' samples
 
-    elapsed = shard.timed_steps(step, args.steps, args.warmup)
+    regions = shard.timed_regions(step, args.steps, args.warmup, args.repeats)
+    elapsed = shard.median(regions)                    # the contract's K-step region; median of --repeats of them
     if ab == 2:
-        read_pairs(args.warmup + args.steps - 1)
+        read_pairs(args.warmup + total_steps - 1)
         prof = graph_prof
     else:
-        prof = ops.profile_collect(max_samples=(args.steps + args.warmup) * per_step + 8 * per_step)[-args.steps * per_step:]
+        prof = ops.profile_collect(max_samples=(total_steps + args.warmup) * per_step + 8 * per_step)[-total_steps * per_step:]
     ops.profile_enable(0)
     maps = world * args.steps * args.batch
     value = maps / elapsed
@@ -295,19 +336,22 @@ def main() -> None:
         roofline = {"bound": "hbm", "kernel": f"itermvs_corr_iter ({kernel_name})", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": b_iter, "avg_launch_ms": avg_ms, "launches_timed": len(t_iter),
+                    "iterations_sampled": sorted({0, min(2, args.iters - 1)}) if ab == 2 else list(range(args.iters)),
                     "timing": ("external hipEvent record nodes around the launch inside the replayed hipGraph, read for every replay "
-                               "of the timed region; of the two alternating runners one brackets the corr_iter launch of GRU "
-                               "iteration 1, the other the corr_init launch (one timed launch per replay keeps the ~12 us a "
-                               "bracket costs out of most of the step)" if ab == 2 else "hipEvent pairs on the launch stream inside the timed region")}
+                               "of the timed regions; of the two alternating runners one brackets the corr_iter launch of GRU "
+                               "iteration 0 (hypotheses around the first, noisy depth map), the other the launch of iteration 2 "
+                               "(smooth depth map, like iterations 1 and 3) and the corr_init launch; avg_launch_ms is the mean over "
+                               "both positions (a bracket costs ~6 us of graph time, included in `value`)"
+                               if ab == 2 else "hipEvent pairs on the launch stream inside the timed region, every iteration")}
         # HBM bytes per launch: rocprofv3 --pmc passes of THIS command (tools/pmc_kernels.sh -> tools/pmc_summary.py ->
         # profiles/<round>_pmc_kernels.json); taken only if the summary names the kernel that ran here and the same workload
-        pmc_file = os.path.join(ROOT, "profiles", PMC_SUMMARY)
-        if os.path.exists(pmc_file):
+        pmc_file = pmc_summary_file()
+        if pmc_file:
             pmc = json.load(open(pmc_file))
             entry = next((v for k, v in pmc.get("kernels", {}).items() if k.startswith(kernel_name + "<") or k == kernel_name), None)
             if entry and pmc.get("workload") == [args.views, args.height, args.width, args.batch] and "traffic_bytes_per_launch" in entry:
                 roofline["traffic"] = entry["traffic_bytes_per_launch"]
-                roofline["traffic_source"] = f"profiles/{PMC_SUMMARY}: " + pmc["source"]
+                roofline["traffic_source"] = f"profiles/{os.path.basename(pmc_file)}: " + pmc["source"]
         if t_init:
             init_ms = sum(t_init) / len(t_init)
             roofline["corr_init"] = {"kernel": "itermvs_corr_init (corr_init_kernel<32>)", "avg_launch_ms": init_ms,
@@ -386,15 +430,22 @@ def main() -> None:
 
     if rank == 0:
         result = {
-            "metric": "depth-maps/sec (ref-views/s) at 5-view 640x512, 4 iters",
+            "metric": f"depth-maps/sec (ref-views/s) at {args.views}-view {args.width}x{args.height}, {args.iters} iters",
             "value": value, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "repeats": args.repeats, "ms_per_step_min": min(regions) / args.steps * 1e3,
+            "ms_per_step_max": max(regions) / args.steps * 1e3,
+            # SURVEY 8(d) / eval.py:130-137 form of the same metric: pinned host buffers in (uint8 images as decoded from
+            # disk, cameras, depth range), pinned host buffers out (depth + confidence), copies overlapped with compute
+            "value_with_transfers": None,
             "vs_baseline": None, "dtype": "f32" if args.feature_dtype == "fp32" else f"f32 arithmetic, {args.feature_dtype} feature storage",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE cfg 2 (= cfg 1 on 1xMI355X): 1 ref + {s_views} src views, "
+            "config": {"workload": f"{workload_name(args.views, args.height, args.width, args.iters)}: 1 ref + {s_views} src views, "
                                    f"{args.width}x{args.height}, {args.iters} GRU iterations, test mode, "
                                    f"random-init weights, {args.batch} ref view(s) per step and GPU",
                        "views": args.views, "height": args.height, "width": args.width, "iterations": args.iters,
+                       "value_is": "inputs resident in HBM when the timed region starts, outputs left in HBM (the bench contract); "
+                                   "`value_with_transfers` = host buffers in / host buffers out",
                        "batch_per_gpu": args.batch, "streams_per_gpu": args.streams, "feature_dtype": args.feature_dtype,
                        "launch": "eager" if args.eager else "one hipGraph per depth map",
                        "parallelism": f"ref-view sharding x{world}, no collective",
@@ -404,6 +455,8 @@ def main() -> None:
             "pipelined": pipelined,
             "with_transfers": with_transfers,
         }
+        if with_transfers is not None:
+            result["value_with_transfers"] = with_transfers.get("uint8_images", with_transfers)["value"]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
             result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]

@@ -51,6 +51,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--outdir", default="./outputs")
     p.add_argument("--display", action="store_true")
     p.add_argument("--iteration", type=int, default=4)
+    p.add_argument("--feature_dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
+                   help="storage type of the feature pyramids (BASELINE cfg 5: fp16); arithmetic stays fp32")
     p.add_argument("--geo_pixel_thres", type=float, default=1)
     p.add_argument("--geo_depth_thres", type=float, default=0.01)
     p.add_argument("--photo_thres", type=float, default=0.3)
@@ -116,6 +118,7 @@ def tocuda(x, dev):
 
 def load_model(args, dev) -> Pipeline:
     model = Pipeline(iteration=args.iteration, test=True)
+    model.feature_dtype = getattr(args, "feature_dtype", "fp32")
     if args.loadckpt:
         print("loading model {}".format(args.loadckpt))
         state = torch.load(args.loadckpt, map_location="cpu", weights_only=False)

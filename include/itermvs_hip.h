@@ -115,6 +115,8 @@ int itermvs_warp_backward(const float* grad_out, const float* proj, const float*
  * Reference-view features of the three pyramid levels resampled onto the 1/4 grid and packed
  * channels-last: out[B,H,W,C1+C2+C3] (level 1: x0.5 bilinear == 2x2 mean; level 2: copy;
  * level 3: x2 bilinear, align_corners=False).  H,W = size of level 2.
+ * Any element strides; a channels-last map (sc == 1) is read four channels per load and must then have its data
+ * pointer 16-byte (fp32) / 8-byte (16-bit) aligned and sx, sy, sb multiples of 4 (ITERMVS_ERR_ALIGN otherwise).
  * ------------------------------------------------------------------------------------------ */
 int itermvs_ref_quarter(const itermvs_fmap* ref_l1, const itermvs_fmap* ref_l2,
                         const itermvs_fmap* ref_l3, int32_t B, float* out, void* stream);
@@ -143,11 +145,7 @@ int itermvs_copy_multi(const void* const* src, void* const* dst, const int64_t* 
 typedef struct itermvs_corr_iter_params {
     int32_t B, S, H, W;                        /* sample grid = level-2 size              */
     int32_t N[3];                              /* hypotheses per level (reference: 4,4,2) */
-    int32_t impl;                              /* kernel form: 0 = default.  impl % 10: 1 = source views walked inside the lane
-                                                  (default), 2 = views across waves (all hypotheses' taps in flight, footprints
-                                                  shared by DPP quad broadcasts, views reduced in order through LDS), 3 = 2 held
-                                                  to 128 registers; impl / 10 = 0 / 1 / 2: 32x1 / 16x2 / 8x4 pixel tiles of
-                                                  forms 2 / 3.  All forms give the same results (tests/test_kernels_gpu.py). */
+    int32_t impl;                              /* reserved, must be 0 (one kernel form)   */
     itermvs_level_src src[3];                  /* [level-1]; channels-last (sc == 1)      */
     const float* ref_q;                        /* [B,H,W,C1+C2+C3] from itermvs_ref_quarter */
     const float* proj;                         /* [3,B,S,12] from itermvs_compose_proj    */

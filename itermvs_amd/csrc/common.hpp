@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "itermvs_hip.h"
 
@@ -15,6 +16,18 @@
 
 static inline int itermvs_launch_status() {
     return hipGetLastError() == hipSuccess ? ITERMVS_OK : ITERMVS_ERR_LAUNCH;
+}
+
+// Tile shapes, persistence and kernel forms are compile-time choices of the shipped library (each one measured, DESIGN.md
+// section 4).  Only a library built with `make TUNING=1` (-DITERMVS_TUNING; the sweeps of tools/conv_bench.py) reads the
+// ITERMVS_* environment overrides; in the product build this is a constant nullptr and the overrides do not exist.
+static inline const char* itermvs_tuning_env(const char* name) {
+#ifdef ITERMVS_TUNING
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
 }
 
 // compute units of the current device (grid size of persistent kernels)

@@ -262,7 +262,7 @@ int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStr
         if (waves > best_waves) { pick = c; best_waves = waves; }   // otherwise: the most waves available
     }
     // too few tiles even at 16x16 and a k-loop long enough to split: four waves per tile (split-K)
-    static const bool no_splitk = [] { const char* e = getenv("ITERMVS_CONV_SPLITK"); return e && e[0] == '0'; }();
+    static const bool no_splitk = [] { const char* e = itermvs_tuning_env("ITERMVS_CONV_SPLITK"); return e && e[0] == '0'; }();
     const int ksteps = p->ksize * p->ksize * (a.CinPad / 4);
     const int64_t tiles16 = (int64_t)p->N * ((P + 15) / 16) * mt;       // waves of the <1,1> configuration
     if (!no_splitk && tiles16 < 8192 && ksteps >= 16) {

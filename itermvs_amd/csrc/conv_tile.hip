@@ -374,7 +374,7 @@ static int launch_tile(TileArgs& a, int mt, hipStream_t stream) {
     // 2 / 3 / 4 / 8, bounded by what fits a CU) workgroups per CU in total, each walking the
     // tile list of its channel block (one tile each when there are fewer tiles than that); never more than
     // are resident at once -- a persistent workgroup queued behind another would serialise its tile list
-    static const int want = [] { const char* e = getenv("ITERMVS_TILE_PERSIST"); const int v = e ? atoi(e) : 4; return v < 1 ? 4 : v; }();
+    static const int want = [] { const char* e = itermvs_tuning_env("ITERMVS_TILE_PERSIST"); const int v = e ? atoi(e) : 4; return v < 1 ? 4 : v; }();
     int fit = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS>, 256, lds) != hipSuccess || fit < 1)
         fit = 1;
@@ -589,9 +589,9 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
     // (only for layers of a few hundred tiles, where the per-tile chain of barriers and weight copies is what
     //  bounds the launch; large layers amortise it over big tiles)
     const bool deep = a.nchunk >= 2 && a.nchunk <= 4 && blocks(2, 1) < 1024;
-    const char* force = getenv("ITERMVS_TILE_FORCE");             // "shape,mb" (tools/conv_bench.py --sweep)
-    static const bool tuned = [] { const char* e = getenv("ITERMVS_TILE_TUNED"); return !e || e[0] != '0'; }();
-    static const int min_work = [] { const char* e = getenv("ITERMVS_TILE_MINWORK"); return e ? atoi(e) : 1024; }();   // work items wanted: 4 workgroups per CU
+    const char* force = itermvs_tuning_env("ITERMVS_TILE_FORCE");             // "shape,mb" (tools/conv_bench.py --sweep)
+    static const bool tuned = [] { const char* e = itermvs_tuning_env("ITERMVS_TILE_TUNED"); return !e || e[0] != '0'; }();
+    static const int min_work = [] { const char* e = itermvs_tuning_env("ITERMVS_TILE_MINWORK"); return e ? atoi(e) : 1024; }();   // work items wanted: 4 workgroups per CU
     int shape = 0, mb = 1;
     int64_t best = -1;
     bool found = false;

@@ -139,201 +139,6 @@ __global__ void __launch_bounds__(kThreads) corr_iter_kernel(const IterArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// iteration branch, "views across waves" form (the default)
-//
-// The form above walks the S source views inside the lane: S dependent rounds of {footprint shuffle, 4 tap loads,
-// wait, blend} per item, 70 such rounds per SIMD at cfg 1 -- the launch is bound by memory latency x rounds.
-// Here a lane group owns one (pixel, view) and keeps ALL hypotheses of the level in registers:
-//   * wave-rounds are (view, block of 64/LPT pixels): the view is wave-uniform, so the source base stays in SGPRs;
-//   * quad lane u projects hypothesis u and builds its footprint ONCE; the four lanes of the quad exchange the four
-//     tap offsets and four weights with DPP quad_perm moves (no LDS shuffles, no redundant projections);
-//   * the 4 x N tap loads of the item are all issued before the first blend: one latency round per item;
-//   * per-view group correlations go to LDS [view][hypothesis*8 + group][pixel]; after a barrier each thread owns one
-//     (group, pixel) column, walks the views IN ORDER and applies the view weights with the arithmetic of
-//     itermvs.py:115-120 (acc = acc + corr * w; wsum = wsum + w; acc / wsum) -- the results equal the in-lane form's
-//     bit for bit -- and writes the [B,N,8,H,W] planes.
-// S > 4 runs in chunks of 4 views with the accumulators carried in registers.
-// ---------------------------------------------------------------------------------------------
-template <int CPG>
-__device__ __forceinline__ void blend_corr_vw(const TapData<2 * CPG>& t, const Footprint& tp, const float (&refv)[2 * CPG],
-                                              float (&corr)[2]) {
-    constexpr int VEC = 2 * CPG;
-    float w[VEC];
-#pragma unroll
-    for (int c = 0; c < VEC; ++c)
-        w[c] = fmaf(tp.se, t.v11[c], fmaf(tp.sw, t.v10[c], fmaf(tp.ne, t.v01[c], tp.nw * t.v00[c])));
-    if constexpr (CPG == 2) {
-        corr[0] = fmaf(w[1], refv[1], w[0] * refv[0]) * 0.5f;
-        corr[1] = fmaf(w[3], refv[3], w[2] * refv[2]) * 0.5f;
-    } else if constexpr (CPG == 4) {   // channels 4j..4j+3 = group j, 16+4j.. = group 4+j
-        corr[0] = fmaf(w[3], refv[3], fmaf(w[2], refv[2], fmaf(w[1], refv[1], w[0] * refv[0]))) * 0.25f;
-        corr[1] = fmaf(w[7], refv[7], fmaf(w[6], refv[6], fmaf(w[5], refv[5], w[4] * refv[4]))) * 0.25f;
-    } else {   // see blend_corr<6>: partial sums re-grouped inside the quad
-        float lo[3], hi[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            lo[i] = fmaf(w[4 * i + 1], refv[4 * i + 1], w[4 * i] * refv[4 * i]);
-            hi[i] = fmaf(w[4 * i + 3], refv[4 * i + 3], w[4 * i + 2] * refv[4 * i + 2]);
-        }
-        const float s0 = lo[0] + hi[0], s1 = lo[1] + hi[1], s2 = lo[2] + hi[2];
-        const int j = threadIdx.x & 3;
-        const float ta = (j == 0 || j == 3) ? s0 : (j == 2 ? s1 : s2);
-        const float tb = (j == 1) ? lo[0] : (j == 2 ? lo[2] : lo[1]);
-        const float tc = (j == 1) ? hi[0] : (j == 2 ? hi[2] : hi[1]);
-        const float tdd = (j == 2) ? s0 : (j == 1 ? s1 : s2);
-        const float g_first = quad_perm<ITERMVS_QP(0, 3, 2, 1)>(ta) + quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tb);
-        const float g_second = quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tc) + quad_perm<ITERMVS_QP(2, 1, 0, 3)>(tdd);
-        corr[0] = div_rcp(g_first, 6.0f, 1.0f / 6.0f);   // mean over the 6 channels of the group (itermvs.py:103-104)
-        corr[1] = div_rcp(g_second, 6.0f, 1.0f / 6.0f);
-    }
-}
-
-template <int CPG, int NB>
-__device__ __forceinline__ void corr_iter_vw_level(const IterArgs& a, const IterLevel& L, int lvl, float* __restrict__ lds,
-                                                   int tw_log2) {
-    using K = VwChunk<CPG>;
-    constexpr int TILE = kVwTile, LS = TILE + 1;
-    constexpr int PPW = 16;            // pixels per wave-round (one quad each)
-    constexpr int RPV = TILE / PPW;    // wave-rounds per view
-    const int N = L.N;
-    const int VROWS = N * ITERMVS_GROUPS;    // LDS: [kVwViews][VROWS][LS] per-view correlations, then (S > 4 only) the
-    float* carry = lds + kVwViews * VROWS * LS;   // accumulators [VROWS][LS] and weight sums [8][LS] carried between chunks
-    const int b = blockIdx.z;
-    const int P = a.H * a.W;
-    const int TW = 1 << tw_log2, TH = TILE >> tw_log2;
-    const int tiles_x = (a.W + TW - 1) >> tw_log2, tiles_y = (a.H + TH - 1) / TH;
-    const int tile = xcd_tile(tiles_x * tiles_y);
-    if (tile >= tiles_x * tiles_y) return;   // padding blocks of the XCD-aligned grid (uniform per block)
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int x0 = tx << tw_log2, y0 = ty * TH;
-    const WarpGeom g = make_geom(a.W, a.H, L.W1, L.H1);
-    const WarpRcp rc = make_rcp(g);
-    const float inv_min = a.inv_min[b], inv_max = a.inv_max[b];
-    const float* proj = a.proj + ((size_t)(lvl * a.B + b) * a.S) * 12;
-    const uint32_t sy = (uint32_t)L.sy, sx = (uint32_t)L.sx;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int j = lane & 3;
-    const uint32_t joff = (uint32_t)(j * 4);
-
-    // second phase: this thread owns correlation group r2 of pixel px2, for every hypothesis
-    const int px2 = threadIdx.x & (TILE - 1), r2 = threadIdx.x >> 5;
-    const int xx2 = x0 + (px2 & (TW - 1)), yy2 = y0 + (px2 >> tw_log2);
-    const bool live2 = xx2 < a.W && yy2 < a.H;
-    const int p2 = yy2 * a.W + xx2;
-
-    for (int s0 = 0; s0 < a.S; s0 += kVwViews) {
-        const int sbc = min(kVwViews, a.S - s0);
-#pragma unroll 1
-        for (int r = wave; r < sbc * RPV; r += kThreads / 64) {
-            const int v = r / RPV, pb = r - v * RPV;   // wave-uniform
-            const float* fb = L.src[s0 + v] + (int64_t)b * L.sb;
-            const float* m = proj + (s0 + v) * 12;
-            const int px = pb * PPW + (lane >> 2);
-            const int x = x0 + (px & (TW - 1)), y = y0 + (px >> tw_log2);
-            if (x < a.W && y < a.H) {   // whole quads drop out together
-                const int p = y * a.W + x;
-                float refv[K::VEC];
-                load_vec<K::VEC>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff + j * 4, refv);
-                float rx, ry, rz;
-                ray_dir(m, (float)x * g.xr, (float)y * g.yr, rx, ry, rz);
-                const float nd_p = L.depth ? 0.0f : a.nd[b * a.nd_sb + p];
-#pragma unroll 1
-                for (int hb = 0; hb < N; hb += 4) {
-                    // quad lane u projects hypothesis hb + u (surplus lanes repeat the last one) and builds its footprint
-                    const int n_own = min(hb + j, N - 1);
-                    float d;
-                    if (L.depth) {
-                        d = L.depth[((size_t)b * N + n_own) * P + p];
-                    } else {   // itermvs.py:291-293
-                        float off = L.offs[0];
-#pragma unroll
-                        for (int k = 1; k < ITERMVS_MAX_HYP; ++k) off = (n_own == k) ? L.offs[k] : off;
-                        float ns = nd_p + off;
-                        ns = fminf(fmaxf(ns, 0.0f), 1.0f);
-                        d = unnormalize_depth(ns, inv_min, inv_max);
-                    }
-                    float ix, iy;
-                    project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
-                    const Footprint f = make_footprint(ix, iy, L.W1, L.H1, sy, sx);
-                    const uint32_t o00 = f.r0 + f.c0, o01 = f.r0 + f.c1, o10 = f.r1 + f.c0, o11 = f.r1 + f.c1;
-#pragma unroll
-                    for (int lb = 0; lb < 4; lb += NB) {   // NB hypotheses' taps in flight at a time
-                        if (hb + lb < N) {                 // uniform
-                            TapData<K::VEC> td[NB];
-                            Footprint wt[NB];
-#pragma unroll
-                            for (int u = 0; u < NB; ++u) {
-                                load_vec<K::VEC>(fb + (quad_bcast(o00, lb + u) + joff), td[u].v00);
-                                load_vec<K::VEC>(fb + (quad_bcast(o01, lb + u) + joff), td[u].v01);
-                                load_vec<K::VEC>(fb + (quad_bcast(o10, lb + u) + joff), td[u].v10);
-                                load_vec<K::VEC>(fb + (quad_bcast(o11, lb + u) + joff), td[u].v11);
-                                wt[u].nw = quad_bcast(f.nw, lb + u); wt[u].ne = quad_bcast(f.ne, lb + u);
-                                wt[u].sw = quad_bcast(f.sw, lb + u); wt[u].se = quad_bcast(f.se, lb + u);
-                            }
-#pragma unroll
-                            for (int u = 0; u < NB; ++u) {
-                                float corr[2];
-                                blend_corr_vw<CPG>(td[u], wt[u], refv, corr);
-                                const int n = hb + lb + u;
-                                if (n < N) {
-                                    lds[(v * VROWS + n * ITERMVS_GROUPS + K::group(j, 0)) * LS + px] = corr[0];
-                                    lds[(v * VROWS + n * ITERMVS_GROUPS + K::group(j, 1)) * LS + px] = corr[1];
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (live2) {
-            // (views in order, the arithmetic of itermvs.py:115-120; between chunks the partial sums rest in LDS so that no
-            // register stays live across the gather phase)
-            float acc[ITERMVS_MAX_HYP];
-            float wsum = 1e-5f;   // itermvs.py:88
-#pragma unroll
-            for (int i = 0; i < ITERMVS_MAX_HYP; ++i) acc[i] = 0.0f;
-            if (s0 > 0) {
-                wsum = carry[(VROWS + r2) * LS + px2];
-#pragma unroll
-                for (int i = 0; i < ITERMVS_MAX_HYP; ++i)
-                    if (i < N) acc[i] = carry[(i * ITERMVS_GROUPS + r2) * LS + px2];
-            }
-            for (int v = 0; v < sbc; ++v) {
-                const float w = a.view_w[((size_t)b * a.S + s0 + v) * P + p2];
-#pragma unroll
-                for (int i = 0; i < ITERMVS_MAX_HYP; ++i)
-                    if (i < N) acc[i] = acc[i] + lds[(v * VROWS + i * ITERMVS_GROUPS + r2) * LS + px2] * w;   // itermvs.py:115
-                wsum = wsum + w;                                                                              // itermvs.py:116
-            }
-            if (s0 + kVwViews < a.S) {
-                carry[(VROWS + r2) * LS + px2] = wsum;
-#pragma unroll
-                for (int i = 0; i < ITERMVS_MAX_HYP; ++i)
-                    if (i < N) carry[(i * ITERMVS_GROUPS + r2) * LS + px2] = acc[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < ITERMVS_MAX_HYP; ++i)
-                    if (i < N) L.out[((size_t)b * VROWS + i * ITERMVS_GROUPS + r2) * P + p2] = acc[i] / wsum;
-            }
-        }
-        if (s0 + kVwViews < a.S) __syncthreads();
-    }
-}
-
-template <int NBA, int NBB, int NBC, int WAVES>
-__global__ void __launch_bounds__(kThreads, WAVES) corr_iter_vw_kernel(const IterArgs a, const int tw_log2) {
-    extern __shared__ float lds[];   // see corr_iter_vw_level; sized by the launch for the level with most hypotheses
-    const int lvl = blockIdx.y;
-    const IterLevel& L = a.lv[lvl];
-    switch (L.C) {
-        case 16: corr_iter_vw_level<2, NBA>(a, L, lvl, lds, tw_log2); break;
-        case 32: corr_iter_vw_level<4, NBB>(a, L, lvl, lds, tw_log2); break;
-        default: corr_iter_vw_level<6, NBC>(a, L, lvl, lds, tw_log2); break;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // initialisation branch: per-view correlation volume for PixelViewWeight (itermvs.py:48-53)
 // grid = (pixel tiles, S * hypothesis blocks, B)
 // ---------------------------------------------------------------------------------------------
@@ -606,16 +411,6 @@ extern "C" int itermvs_pvw_tail(const float* x, const float* w, const float* bia
     return itermvs_launch_status();
 }
 
-// defaults of itermvs_corr_iter's kernel choice (see the launch below); the environment overrides are for experiments
-static int default_impl() {
-    static const int v = [] {
-        const char* e = getenv("ITERMVS_CORR_ITER_IMPL");
-        const int n = e ? atoi(e) : 0;
-        return n > 0 ? n : 1;
-    }();
-    return v;
-}
-
 extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream) {
     ITERMVS_RETURN_IF(!p, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->B < 1 || p->H < 1 || p->W < 1, ITERMVS_ERR_DIMS);
@@ -645,23 +440,13 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
     a.ref_q = p->ref_q; a.proj = p->proj; a.view_w = p->view_w; a.nd = p->norm_depth; a.nd_sb = p->norm_depth_sb;
     a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max;
     a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.CQ = coff;
-    // impl % 10: 0 = default (ITERMVS_CORR_ITER_IMPL=<number> overrides), 1 = views walked in the lane (default), 2 = views
-    // across waves with (4, 2, 1) hypotheses' taps in flight on the (C=16, 32, 48) levels, 3 = 2 held to 128 registers
-    // (4 waves per SIMD); impl / 10 = log2 narrowing of the 32-pixel tile of forms 2 / 3 (0: 32x1 strips, 1: 16x2, 2: 8x4).
-    // Measured on MI355X (profiles/r02): both forms sit at the same 24-34 us per launch at cfg 1 -- the launch is bound by
-    // the rate at which a CU's vector L1 gets its misses served (1.2-1.6 M 128-byte requests per launch, ~4800 per CU),
-    // the second form issues 14 % fewer vector instructions but misses the L1 31 % more often.
-    int variant = p->impl % 10, narrow = p->impl / 10;
-    if (variant == 0) {
-        variant = default_impl() % 10;
-        narrow = default_impl() / 10;
-    }
-    ITERMVS_RETURN_IF(variant < 1 || variant > 3 || narrow < 0 || narrow > 2, ITERMVS_ERR_DIMS);
+    // One form: source views walked inside the lane.  (A views-across-waves form issued 14 % fewer vector instructions but
+    // missed the vector L1 31 % more often -- 33.4 vs 28.9 us, profiles/r02 -- and was removed; `impl` is reserved.)
+    ITERMVS_RETURN_IF(p->impl != 0, ITERMVS_ERR_DIMS);
     const int dtype = p->src[0].dtype;
     ITERMVS_RETURN_IF(p->src[1].dtype != dtype || p->src[2].dtype != dtype, ITERMVS_ERR_DTYPE);
-    if (dtype != ITERMVS_F32) variant = 1;   // 16-bit feature storage: the in-lane form
     itermvs_profile_begin(1, (hipStream_t)stream);
-    if (variant == 1) {
+    {
         constexpr int TILE = 32;
         const int P = p->H * p->W;
         const dim3 grid((((P + TILE - 1) / TILE + 7) / 8) * 8, 3, p->B);
@@ -670,17 +455,6 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
             case ITERMVS_BF16: hipLaunchKernelGGL((corr_iter_kernel<TILE, ITERMVS_BF16>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
             default: hipLaunchKernelGGL((corr_iter_kernel<TILE, ITERMVS_F32>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
         }
-    } else {
-        const int tw_log2 = 5 - narrow, tw = 1 << tw_log2, th = kVwTile / tw;
-        const int tiles = ((p->W + tw - 1) / tw) * ((p->H + th - 1) / th);
-        const dim3 grid(((tiles + 7) / 8) * 8, 3, p->B);
-        const int nmax = max(p->N[0], max(p->N[1], p->N[2]));
-        const size_t shmem = (size_t)((kVwViews + (p->S > kVwViews ? 1 : 0)) * nmax * ITERMVS_GROUPS + (p->S > kVwViews ? ITERMVS_GROUPS : 0)) *
-                             (kVwTile + 1) * sizeof(float);
-        if (variant == 3)
-            hipLaunchKernelGGL((corr_iter_vw_kernel<4, 2, 1, 4>), grid, dim3(kThreads), shmem, (hipStream_t)stream, a, tw_log2);
-        else
-            hipLaunchKernelGGL((corr_iter_vw_kernel<4, 2, 1, 3>), grid, dim3(kThreads), shmem, (hipStream_t)stream, a, tw_log2);
     }
     itermvs_profile_end(1, (hipStream_t)stream);
     return itermvs_launch_status();

@@ -208,7 +208,7 @@ struct IterArgs {
     int B, S, H, W, CQ;
 };
 
-constexpr int kVwTile = 32;   // pixels per block: TW x (32 / TW)
+constexpr int kVwTile = 32;   // pixels per block of the gradient kernel (corr_bwd.hip)
 constexpr int kVwViews = 4;   // views per chunk (= waves per block)
 
 __device__ __forceinline__ float quad_bcast(float x, int u) {   // u is a constant after unrolling
@@ -223,7 +223,7 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t x, int u) {
     return (uint32_t)__float_as_int(quad_bcast(__int_as_float((int)x), u));
 }
 
-// Every level uses 4 lanes (one quad) per (pixel, view): lane j owns the float4 at channel 4j of every 16-channel block
+// Gradient kernel (corr_bwd.hip): every level uses 4 lanes (one quad) per (pixel, view): lane j owns the float4 at channel 4j of every 16-channel block
 // (C=16: 1 block, C=32: 2, C=48: 3), so each load instruction of the quad covers one contiguous 64-byte run and one tap
 // address serves VEC/4 loads.  Two correlation groups are finalised per lane.
 template <int CPG>

@@ -277,6 +277,15 @@ static int launch_ref_quarter(const itermvs_fmap* r1, const itermvs_fmap* r2, co
                       ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF((r1->C % 4) || (r2->C % 4) || (r3->C % 4), ITERMVS_ERR_CHANNELS);
     ITERMVS_RETURN_IF(((uintptr_t)out) % 16, ITERMVS_ERR_ALIGN);
+    // channels-last maps (sc == 1) take the vector path of ld4: four channels per 16-byte (fp32) / 8-byte (16-bit) load at a
+    // 32-bit element offset -> base pointer, pixel / row / batch strides and extent must allow it (other layouts: scalar loads)
+    for (const itermvs_fmap* f : {r1, r2, r3}) {
+        if (f->sc != 1) continue;
+        const uintptr_t need = f->dtype == ITERMVS_F32 ? 16 : 8;
+        ITERMVS_RETURN_IF(((uintptr_t)f->data) % need || (f->sx % 4) || (f->sy % 4) || (f->sb % 4), ITERMVS_ERR_ALIGN);
+        ITERMVS_RETURN_IF((int64_t)(B - 1) * f->sb + (int64_t)(f->H - 1) * f->sy + (int64_t)(f->W - 1) * f->sx + f->C > 0x7fffffffLL,
+                          ITERMVS_ERR_DIMS);
+    }
     const int64_t total = (int64_t)B * r2->H * r2->W * ((r1->C + r2->C + r3->C) / 4);
     ITERMVS_RETURN_IF(r1->dtype != r2->dtype || r1->dtype != r3->dtype, ITERMVS_ERR_DTYPE);
     const int n_ref = (int)((total + 255) / 256);

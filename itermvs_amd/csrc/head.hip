@@ -221,18 +221,9 @@ __global__ void __launch_bounds__(256) head_regress_kernel(const HeadArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// itermvs_head_fused: the WHOLE depth head in one launch -- its dilated 3x3 layer (32 -> 32, ReLU) computed from an
-// LDS tile of the hidden state like conv_tile.hip does, then chained in registers into the two 1x1 layers and the
-// regression above (the 3x3 accumulators of a lane are exactly the B operands GEMM 1 needs).  A workgroup owns a
-// 4 x 16 pixel tile (one row per wave); W2 (64 KB) is read from global memory (L2-resident, one 16-byte load per
-// four MFMAs) so that two workgroups fit a CU.
+// itermvs_head_fused: the WHOLE depth head in one launch -- its dilated 3x3 layer (32 -> 32, ReLU), the two 1x1 layers and
+// the regression above (head_coop_kernel below; a one-tile-per-wave form measured 27.8 vs 20 us and was removed).
 // ---------------------------------------------------------------------------------------------
-constexpr int kFIn = 8 * 20;                                  // staged pixels: 4 x 16 tile + dilation-2 halo
-constexpr int kFPl = (kFIn * 4 + 63) / 64 * 64;               // floats per k-slot plane
-constexpr int kFStage = 2 * 4 * kFPl;                         // two chunks of 16 channels
-constexpr int kFW0 = 2 * 9 * 4 * 32 * 4;                      // conv weights [chunk][tap][q][32 co][4]
-constexpr int kFusedLds = (kFStage + kFW0 + kW1Floats + 4 * kHeadWin * 16) * 4;
-
 struct FusedArgs {
     const float* hidden;     // [B,32,H,W] planes
     int64_t h_sb;
@@ -244,108 +235,11 @@ struct FusedArgs {
     int H, W, tiles_x;
 };
 
-__global__ void __launch_bounds__(256) head_fused_kernel(const FusedArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* __restrict__ tile = smem;
-    float* __restrict__ w0 = smem + kFStage;
-    float* __restrict__ w1 = w0 + kFW0;
-    float* __restrict__ win = w1 + kW1Floats;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = lane >> 4, l16 = lane & 15;
-    const int b = blockIdx.y;
-    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
-    const int oy0 = ty * 4, ox0 = tx * 16;
-    const uint32_t plane = (uint32_t)(a.H * a.W);
-
-    // stage the hidden-state tile (both chunks) and the weights
-    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.hidden + (int64_t)b * a.h_sb), 0, (int)(32u * plane * 4u), 0x00020000);
-    constexpr int ITEMS = (4 * kFIn + 255) / 256;
-    f32x4 st[2][ITEMS];
-    int loff[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int item = tid + j * 256;
-        const int iq = item / kFIn, px = item - iq * kFIn;
-        const int y = px / 20, x = px - y * 20;
-        const int gy = oy0 - 2 + y, gx = ox0 - 2 + x;
-        const bool ok = item < 4 * kFIn && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const uint32_t goff = ok ? ((uint32_t)(iq * 4) * plane + (uint32_t)(gy * a.W + gx)) * 4u : 0x7fffffffu;
-        loff[j] = iq * kFPl + px * 4;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-                st[c][j][s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ir, goff, (uint32_t)(c * 16 + s2) * plane * 4u, 0));
-    }
-    {
-        // conv weights: global rows [tap][chunk][q] of 32*4 floats -> LDS rows [chunk][tap][q]; 72 rows x 32 float4
-        const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.w0t);
-        f32x4 t[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int e = tid + i * 256, r = e >> 5, col = e & 31;       // LDS row r = (c*9 + tap)*4 + q
-            const int c = r / 36, rem = r - c * 36;
-            t[i] = src[(((rem >> 2) * 2 + c) * 4 + (rem & 3)) * 32 + col];
-        }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) reinterpret_cast<f32x4*>(w0)[tid + i * 256] = t[i];
-        const f32x4* __restrict__ s1 = reinterpret_cast<const f32x4*>(a.w1p);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) reinterpret_cast<f32x4*>(w1)[tid + i * 256] = s1[tid + i * 256];
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j)
-            if (j < ITEMS - 1 || tid + j * 256 < 4 * kFIn) *reinterpret_cast<f32x4*>(tile + c * 4 * kFPl + loff[j]) = st[c][j];
-    __syncthreads();
-
-    // dilated 3x3 layer, 32 -> 32: same operand order as conv_tile_kernel (chunk, tap, step)
-    f32x4 acc0[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
-    const float* __restrict__ bbase = tile + q * kFPl + (wave * 20 + l16) * 4;
-    const float* __restrict__ abase = w0 + (q * 32 + l16) * 4;
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bbase + c * 4 * kFPl + (ky * 2 * 20 + kx * 2) * 4);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(abase + (c * 9 + tap) * (4 * 32 * 4) + mb * 64);
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) acc0[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv[s2], acc0[mb], 0, 0, 0);
-            }
-        }
-    // GEMM 1 (32 -> 64, ReLU), chained: k-step (mb0, r) takes channel mb0*16 + q*4 + r = relu(acc0[mb0][r])
-    f32x4 acc1[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) acc1[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(w1 + (((mb * 2 + u) * 4 + q) * 16 + l16) * 4);
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-                acc1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], fmaxf(acc0[u][s2], 0.0f), acc1[mb], 0, 0, 0);
-        }
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc1[mb][r] = fmaxf(acc1[mb][r], 0.0f);
-
-    const int oy = oy0 + wave, ox = ox0 + l16;
-    const bool live = oy < a.H && ox < a.W;
-    head_tail(acc1, a.w2p, a.bias2, win, wave, q, l16, live, b, live ? oy * a.W + ox : 0, a.out);
-}
-
 // ---------------------------------------------------------------------------------------------
-// itermvs_head_fused, cooperative form (the default): ONE 16-pixel tile is shared by the four waves of a workgroup.
+// itermvs_head_fused, cooperative form: ONE 16-pixel tile is shared by the four waves of a workgroup.
 //
-// The per-wave form above gives every wave a whole tile (432 MFMAs): at cfg 1 that is 1280 tiles for 1024 SIMDs, so a
-// quarter of the SIMDs run two tiles back to back while the others wait -- 27 us for 6.6 us of matrix work per tile.
+// A form with one whole tile per wave (432 MFMAs) ran 1280 tiles on 1024 SIMDs at cfg 1, so a quarter of the SIMDs ran
+// two tiles back to back while the others waited -- 27 us for 6.6 us of matrix work per tile.
 // Here a persistent workgroup walks tiles (row segments of 16 pixels) and splits each layer over its four waves, one
 // wave per SIMD, so every SIMD of a CU carries the same 108 MFMAs per tile:
 //   3x3 dilated conv 32 -> 32   wave (mb0 = w & 1, ch = w >> 1): output block mb0 over input chunk ch, 9 taps x 4 steps;
@@ -599,23 +493,14 @@ extern "C" int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_
                                   float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream) {
     ITERMVS_RETURN_IF(!hidden || !w0_tile || !w1_packed || !w2_packed || !bias2, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(B < 1 || H < 1 || W < 1, ITERMVS_ERR_DIMS);
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(head_fused_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds) == hipSuccess;
-    ITERMVS_RETURN_IF(!attr_ok, ITERMVS_ERR_LAUNCH);
     FusedArgs a;
     a.hidden = hidden; a.h_sb = hidden_sb; a.w0t = w0_tile; a.w1p = w1_packed; a.w2p = w2_packed; a.bias2 = bias2;
     a.out.nd0 = nd_out0; a.out.nd1 = nd_out1; a.out.nd_sb0 = nd_sb0; a.out.nd_sb1 = nd_sb1; a.out.best = best; a.out.P = H * W;
     a.H = H; a.W = W; a.tiles_x = (W + 15) / 16;
-    // default: the cooperative form (one tile shared by the four waves of a persistent workgroup); ITERMVS_HEAD_FORM=wave
-    // selects the one-tile-per-wave form for A/B measurements
-    const char* form = getenv("ITERMVS_HEAD_FORM");
-    if (!(form && form[0] == 'w')) {
-        const int cus = itermvs_num_cus();
-        const int tiles = a.tiles_x * H * B;
-        const int grid = tiles < 2 * cus ? tiles : 2 * cus;
-        hipLaunchKernelGGL(head_coop_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles);
-        return itermvs_launch_status();
-    }
-    hipLaunchKernelGGL(head_fused_kernel, dim3(a.tiles_x * ((H + 3) / 4), B), dim3(256), kFusedLds, (hipStream_t)stream, a);
+    // one tile shared by the four waves of a persistent workgroup, two workgroups per CU
+    const int cus = itermvs_num_cus();
+    const int tiles = a.tiles_x * H * B;
+    const int grid = tiles < 2 * cus ? tiles : 2 * cus;
+    hipLaunchKernelGGL(head_coop_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles);
     return itermvs_launch_status();
 }

@@ -217,12 +217,12 @@ extern "C" int itermvs_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, 
     a.x_sn = x_sn; a.out_sn = out_sn;
     a.M = M; a.H = H; a.W = W;
     a.H2 = (H - 1) / 2 + 1; a.W2 = (W - 1) / 2 + 1;
-    static const int th = [] { const char* e = getenv("ITERMVS_STEM_TH"); return e && atoi(e) == 4 ? 4 : 8; }();
+    static const int th = [] { const char* e = itermvs_tuning_env("ITERMVS_STEM_TH"); return e && atoi(e) == 4 ? 4 : 8; }();
     a.tiles_x = (a.W2 + kStTW - 1) / kStTW; a.tiles_y = (a.H2 + th - 1) / th;
     const int64_t tiles = (int64_t)M * a.tiles_x * a.tiles_y;
     if (tiles > 0x7fffffff) return ITERMVS_ERR_DIMS;
     // persistent workgroups, tiles round-robin: as many as stay resident (LDS 51 / 28 KB per workgroup)
-    static const int wg_per_cu = [] { const char* e = getenv("ITERMVS_STEM_WGS"); return e ? atoi(e) : 0; }();
+    static const int wg_per_cu = [] { const char* e = itermvs_tuning_env("ITERMVS_STEM_WGS"); return e ? atoi(e) : 0; }();
     const int resident = itermvs_num_cus() * (wg_per_cu > 0 ? wg_per_cu : (th == 4 ? 4 : 3));
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     if (th == 4) hipLaunchKernelGGL(stem_kernel<4>, dim3(grid), dim3(kStThreads), 0, (hipStream_t)stream, a, (int)tiles);

@@ -26,7 +26,13 @@ def flat_allreduce_gradients(params: Iterable[torch.nn.Parameter], world_size: i
     if not grads or world == 1:
         return 0
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        # test rigs without RCCL between the ranks (two processes on one GPU): stage the 1.37 MB bucket through the host
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.div_(world)
     off = 0
     for g in grads:
@@ -40,5 +46,11 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
     """Make every rank start from rank ``src``'s weights and BatchNorm statistics."""
     if not (dist.is_available() and dist.is_initialized()):
         return
+    via_host = dist.get_backend() == "gloo"
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src)
+        if via_host and t.is_cuda:
+            host = t.data.cpu()
+            dist.broadcast(host, src)
+            t.data.copy_(host)
+        else:
+            dist.broadcast(t.data, src)

@@ -83,14 +83,12 @@ class InferenceEngine:
         self.b_zr = torch.cat([w[g + "convz.bias"], w[g + "convr.bias"]], 0).contiguous()
         self.offsets = sample_offsets()
         self._ws: Dict[tuple, dict] = {}
+        self._ws_owner = None
         # OR-ed with 1 by itermvs_compose_proj when a composed projection is NaN (module.py:83,87 assert on the host);
         # read and cleared by check_projection_finite()
         self.nan_flag = torch.zeros((1,), device=dev, dtype=torch.int32)
         self.profile_iterations = None   # set of iteration indices whose corr_iter launch carries timing events (None = all)
         self.profile_init = True         # whether the corr_init launch carries timing events (bench.py)
-        import os
-        self._corrnet_fused = os.environ.get("ITERMVS_CORRNET", "fused") != "layers"
-        self._stem_fused = os.environ.get("ITERMVS_STEM", "fused") != "layers"
         self.pk: Dict[str, object] = {}
         self._pack_weights()
 
@@ -154,11 +152,8 @@ class InferenceEngine:
                                       memory_format=torch.channels_last)
         o1, o2, o3 = cl(16, 2), cl(32, 4), cl(48, 8)
         self.o2_planar = torch.empty((m, 32, hh // 4, ww // 4), device=dev)
-        if self._stem_fused:     # conv1 + layer1[0].conv1 / .downsample in one launch, fea0 never leaves LDS
-            y, sc = ops.stem(x, *self.stem_w)
-            f1 = self._res(self._cbr(y, "layer1.0.conv2.", 1, "relu", add=sc), "layer1.1.", 1)
-        else:
-            f1 = self._res(self._res(self._cbr(x, "conv1.", 1, "relu"), "layer1.0.", 2), "layer1.1.", 1)
+        y, sc = ops.stem(x, *self.stem_w)     # conv1 + layer1[0].conv1 / .downsample in one launch, fea0 never leaves LDS
+        f1 = self._res(self._cbr(y, "layer1.0.conv2.", 1, "relu", add=sc), "layer1.1.", 1)
         f2 = self._res(self._res(f1, "layer2.0.", 2), "layer2.1.", 1)
         f3 = self._res(self._res(f2, "layer3.0.", 2), "layer3.1.", 1)
         self._conv(f3, p + "output3.", bias=True, channels_last_out=True, out=o3)
@@ -171,18 +166,8 @@ class InferenceEngine:
     # -- small stacks ---------------------------------------------------------------------------
     def corr_nets(self, x: Tensor, levels, seg_end=(), out: Tensor = None, out2: Tensor = None) -> Tensor:
         """itermvs.py:352-381 for one or three levels: x [M,8,h,w] whose batch items [0,seg_end[0]) / [seg_end[0],seg_end[1]) /
-        rest belong to levels[0..2] -> [M,1,h,w].  ONE launch (itermvs_corrnet: the whole U-Net per 32 x 32 tile in LDS);
-        ITERMVS_CORRNET=layers evaluates it layer by layer (six itermvs_conv2d launches) for A/B measurements."""
-        if self._corrnet_fused:
-            return ops.corrnet(x, [self.corrnet_w[l] for l in levels], seg_end, out=out, out2=out2)
-        ps = [f"iter_mvs.evaluation.corr_conv1.{l - 1}." for l in levels]
-        wl = lambda n: [self.pk[p + n] for p in ps]
-        c0 = ops.conv2d(x, wl("conv0.conv.weight"), None, act="relu", seg_end=seg_end)
-        c1 = ops.conv2d(c0, wl("conv1.conv.weight"), None, stride=2, act="relu", seg_end=seg_end)
-        c2 = ops.conv2d(c1, wl("conv2.conv.weight"), None, stride=2, act="relu", seg_end=seg_end)
-        u1 = ops.conv2d(c2, wl("conv3.weight"), None, transposed=True, stride=2, add=c1, seg_end=seg_end)
-        u0 = ops.conv2d(u1, wl("conv4.weight"), None, transposed=True, stride=2, add=c0, seg_end=seg_end)
-        return ops.conv2d(u0, wl("conv5.weight"), [self.w[p + "conv5.bias"] for p in ps], seg_end=seg_end, out=out, out2=out2)
+        rest belong to levels[0..2] -> [M,1,h,w].  ONE launch (itermvs_corrnet: the whole U-Net per 32 x 32 tile in LDS)."""
+        return ops.corrnet(x, [self.corrnet_w[l] for l in levels], seg_end, out=out, out2=out2)
 
     def depth_head(self, hidden: Tensor) -> Tensor:
         """itermvs.py:139-145 layer by layer -> logits [B,256,h,w] (traced / teacher-forced runs only)"""
@@ -205,7 +190,10 @@ class InferenceEngine:
 
     # -- workspace ------------------------------------------------------------------------------
     def _workspace(self, b: int, h: int, w: int) -> dict:
-        key = (b, h, w)
+        # one workspace per (shape, owner): eager calls share the engine's; every GraphedRunner captures onto its OWN
+        # (``_ws_owner`` is set while a runner warms up / captures), so runners replayed on different streams never
+        # share GRU buffers
+        key = (b, h, w, self._ws_owner)
         ws = self._ws.get(key)
         if ws is None:
             dev = self.device
@@ -385,16 +373,20 @@ class GraphedRunner:
         self.depth_min, self.depth_max = depth_min.clone(), depth_max.clone()
         self.key = (tuple(imgs.shape), tuple(depth_min.shape))
         self.stream.wait_stream(torch.cuda.current_stream(imgs.device))
-        with torch.cuda.stream(self.stream):
-            for _ in range(2):                                  # warm-up: allocates the workspaces, primes caches
-                engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max)
-            torch.cuda.synchronize(imgs.device)
-            first = ops.profile_graph_count()
-            self.graph = torch.cuda.CUDAGraph()
-            self.graph.capture_begin()
-            self.out = engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max)
-            self.graph.capture_end()
-            self.profile_pairs = (first, ops.profile_graph_count() - first)
+        engine._ws_owner = id(self)                             # this runner's private workspace (see _workspace)
+        try:
+            with torch.cuda.stream(self.stream):
+                for _ in range(2):                              # warm-up: allocates the workspaces, primes caches
+                    engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max)
+                torch.cuda.synchronize(imgs.device)
+                first = ops.profile_graph_count()
+                self.graph = torch.cuda.CUDAGraph()
+                self.graph.capture_begin()
+                self.out = engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max)
+                self.graph.capture_end()
+                self.profile_pairs = (first, ops.profile_graph_count() - first)
+        finally:
+            engine._ws_owner = None
         torch.cuda.synchronize(imgs.device)
 
     @property

@@ -79,21 +79,32 @@ class Pipeline(nn.Module):
             _attach(self, name, _default_init(name, shape), is_buffer)
         self._engine = None
         self._runners = {}
+        self._engine_version = None
         self.use_graphs = False        # test mode: replay one hipGraph per depth map instead of launching kernel by kernel
         # module.py:83,87 assert on NaN projections inside every forward.  Eager test mode does the same (one 4-byte read
         # after the launches are enqueued); the graph mode never stalls the host: call check_projection_finite() when the
         # outputs are fetched (eval.py does, per batch).  None = follow that default.
         self.check_nan = None
-        # storage type of the feature pyramids in test mode: "fp32" (reference numerics), "bf16" / "fp16" (BASELINE cfg 4 / 5:
-        # half the gathered bytes, fp32 arithmetic); set before the first forward (or call invalidate())
+        # storage type of the feature pyramids the correlation kernels gather from, in test AND train mode: "fp32" (reference
+        # numerics), "bf16" / "fp16" (BASELINE cfg 4 / 5: half the gathered bytes, fp32 arithmetic, fp32 gradients); set before
+        # the first forward (or call invalidate())
         self.feature_dtype = "fp32"
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     # -- weights ----------------------------------------------------------------------------
     def invalidate(self) -> None:
-        """Drop the folded / re-laid-out inference weights (after any parameter change)."""
+        """Drop the folded / re-laid-out inference weights and the captured hipGraphs.  Test mode folds BatchNorm, packs
+        every weight into matrix-core operand order and captures graphs ONCE; they are rebuilt automatically after
+        ``load_state_dict``, ``.to()`` / ``.cuda()``, a train/eval mode change, and whenever an autograd-visible in-place
+        update of a parameter or buffer is detected at the next forward (optimizer steps, ``p.copy_()`` under ``no_grad``:
+        the tensors' version counters).  Edits that bypass the version counter (``p.data.copy_(...)``, raw pointer writes,
+        an EMA swap through ``.data``) must be followed by an explicit ``invalidate()``."""
         self._engine = None
         self._runners = {}
+        self._engine_version = None
+
+    def _weights_version(self) -> int:
+        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
 
     def load_checkpoint_state(self, state: Mapping[str, torch.Tensor], strict: bool = True):
         """Load a reference checkpoint's ``state_dict['model']`` (keys may carry ``module.``)."""
@@ -133,8 +144,11 @@ class Pipeline(nn.Module):
         depth_max = depth_max.float()
         if self.test:
             from .engine import InferenceEngine
+            if self._engine is not None and self._engine_version != self._weights_version():
+                self.invalidate()                 # parameters were updated in place since the weights were packed
             if self._engine is None:
                 self._engine = InferenceEngine(self.weights(), self.iteration, self.feature_dtype)
+                self._engine_version = self._weights_version()
             with torch.no_grad():
                 if self.use_graphs:
                     from .engine import GraphedRunner
@@ -150,7 +164,7 @@ class Pipeline(nn.Module):
             return {"depths_upsampled": depth_up, "confidence_upsampled": conf_up}
         from .train_graph import train_forward
         return train_forward(self.weights(), x.float(), projs, depth_min, depth_max, self.iteration,
-                             bn_training=self.training)
+                             bn_training=self.training, feature_dtype=self.feature_dtype)
 
 
 def full_loss(depths, depths_upsampled, confidences, depths_gt, mask, depth_min, depth_max, regress=True):

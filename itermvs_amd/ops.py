@@ -184,7 +184,7 @@ def ref_quarter_compose(ref1: Tensor, ref2: Tensor, ref3: Tensor, mats: Tensor, 
 def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, view_w: Tensor,
               inv_min: Tensor, inv_max: Tensor, depth: Optional[Dict[int, Tensor]] = None,
               norm_depth: Optional[Tensor] = None, offsets: Optional[Dict[int, Sequence[float]]] = None,
-              out: Optional[List[Tensor]] = None, impl: int = 0, timed: bool = True) -> List[Tensor]:
+              out: Optional[List[Tensor]] = None, timed: bool = True) -> List[Tensor]:
     """itermvs.py:84-120 fused (see include/itermvs_hip.h).  ``src[l]`` = S channels-last maps of
     level l; ``proj`` [3,B,S,12]; ``view_w`` [B,S,H,W]; hypotheses either explicit
     ``depth[l]`` [B,N_l,H,W] or generated from ``norm_depth`` [B,1,H,W] + ``offsets[l]``.
@@ -193,7 +193,6 @@ def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, vie
     s = len(src[1])
     p = CorrIterParams()
     p.B, p.S, p.H, p.W = b, s, h, w
-    p.impl = impl          # kernel form (include/itermvs_hip.h): 0 default, 1 views in the lane, 2 views across waves
     keep = []
     outs: List[Tensor] = []
     for i, l in enumerate((1, 2, 3)):
@@ -236,12 +235,11 @@ def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, vie
     return outs
 
 
-def _corr_iter_params(src, ref_q, proj, view_w, inv_min, inv_max, norm_depth, offsets, outs, impl=0):
+def _corr_iter_params(src, ref_q, proj, view_w, inv_min, inv_max, norm_depth, offsets, outs):
     """parameter block of itermvs_corr_iter for hypotheses generated from ``norm_depth`` + ``offsets``; returns (block, keep-alive)"""
     b, h, w, _ = ref_q.shape
     p = CorrIterParams()
     p.B, p.S, p.H, p.W = b, len(src[1]), h, w
-    p.impl = impl
     for i, l in enumerate((1, 2, 3)):
         p.src[i] = level_src(src[l], f"src level {l}")
         p.depth[i] = None
@@ -273,10 +271,14 @@ class _CorrIterFn(torch.autograd.Function):
     """itermvs.py:84-120 as one differentiable op: forward = itermvs_corr_iter, backward = itermvs_corr_iter_backward.
     Inputs: ref_q [B,H,W,96], proj, view_w (detached by the caller, itermvs.py:295), inverse depth range, normalised
     depth (no gradient, module.py:77), and the three channels-last pyramid levels [B*V,C_l,H_l,W_l] whose views 1..V-1 are
-    the sources.  The gradient w.r.t. each level is one dense tensor the kernel scatter-adds into (view 0 stays zero)."""
+    the sources.  The gradient w.r.t. each level is one dense tensor the kernel scatter-adds into (view 0 stays zero).
+    ``f1..f3`` are the fp32 tensors the gradient is routed to; ``s1..s3`` the tensors the kernels GATHER from -- the same
+    objects for fp32 storage, their bf16 / fp16 roundings for 16-bit feature storage (BASELINE cfg 4): the gradient is
+    taken at the stored values and handed to the fp32 tensors in fp32 (straight-through rounding, no 16-bit gradient)."""
 
     @staticmethod
-    def forward(ctx, ref_q, proj, view_w, inv_min, inv_max, norm_depth, offsets, b, v, f1, f2, f3):
+    def forward(ctx, ref_q, proj, view_w, inv_min, inv_max, norm_depth, offsets, b, v, f1, f2, f3, s1, s2, s3):
+        f1, f2, f3 = s1, s2, s3
         src = {l: _views(f, b, v)[1] for l, f in ((1, f1), (2, f2), (3, f3))}
         _, h, w, _ = ref_q.shape
         outs = [torch.empty((b, len(offsets[l]), 8, h, w), device=ref_q.device, dtype=torch.float32) for l in (1, 2, 3)]
@@ -302,16 +304,21 @@ class _CorrIterFn(torch.autograd.Function):
         gs = (C.POINTER(C.c_void_p) * 3)(*[C.cast(a, C.POINTER(C.c_void_p)) for a in lv])
         check(_lib.load().itermvs_corr_iter_backward(C.byref(p), C.byref(go), C.byref(gs), gref.data_ptr(), _stream()),
               "itermvs_corr_iter_backward")
-        return (gref, None, None, None, None, None, None, None, None) + tuple(g.to(f.dtype) for g, f in zip(gfeat, feats))
+        return (gref, None, None, None, None, None, None, None, None) + tuple(gfeat) + (None, None, None)
 
 
 def corr_iter_train(feats: Dict[int, Tensor], b: int, v: int, ref_q: Tensor, proj: Tensor, view_w: Tensor, inv_min: Tensor,
-                    inv_max: Tensor, norm_depth: Tensor, offsets: Dict[int, Sequence[float]]) -> Tuple[Tensor, ...]:
-    """differentiable itermvs_corr_iter: ``feats[l]`` = dense channels-last [B*V,C_l,H_l,W_l] (gradient to the source views)
-    and ``ref_q`` [B,H,W,96] (gradient) -> three [B,N_l,8,H,W] tensors"""
-    f = [_need_cl(feats[l], f"feature level {l}") for l in (1, 2, 3)]
+                    inv_max: Tensor, norm_depth: Tensor, offsets: Dict[int, Sequence[float]],
+                    stored: Optional[Dict[int, Tensor]] = None) -> Tuple[Tensor, ...]:
+    """differentiable itermvs_corr_iter: ``feats[l]`` = dense channels-last fp32 [B*V,C_l,H_l,W_l] (gradient to the source
+    views) and ``ref_q`` [B,H,W,96] (gradient) -> three [B,N_l,8,H,W] tensors.  ``stored[l]``: the 16-bit copies the kernels
+    gather from (feature storage bf16 / fp16); default: ``feats`` themselves."""
+    f = [_need_cl(_dev(feats[l], f"feature level {l}"), f"feature level {l}") for l in (1, 2, 3)]
+    st = f if stored is None else [_need_cl(stored[l].detach(), f"stored feature level {l}") for l in (1, 2, 3)]
+    if any(a.shape != c.shape for a, c in zip(f, st)):
+        raise RuntimeError("corr_iter_train: stored features must have the shapes of the fp32 features")
     return _CorrIterFn.apply(_dev(ref_q, "ref_q").contiguous(), _dev(proj, "proj").contiguous(), _dev(view_w, "view_w").contiguous(),
-                             inv_min, inv_max, norm_depth.detach(), {l: tuple(offsets[l]) for l in (1, 2, 3)}, b, v, *f)
+                             inv_min, inv_max, norm_depth.detach(), {l: tuple(offsets[l]) for l in (1, 2, 3)}, b, v, *f, *st)
 
 
 def _corr_init_params(src3, ref3, proj, inv_min, inv_max, n, out):
@@ -332,7 +339,8 @@ class _CorrInitFn(torch.autograd.Function):
     per-view group correlation [B,S,N,8,H,W]; gradient = one dense tensor (reference view gathered, sources scattered)"""
 
     @staticmethod
-    def forward(ctx, f3, proj, inv_min, inv_max, n, b, v):
+    def forward(ctx, f3, proj, inv_min, inv_max, n, b, v, s3):
+        f3 = s3                 # the tensor the kernel reads (f3 itself, or its 16-bit rounding); gradient goes to f3 in fp32
         ref3, src3 = _views(f3, b, v)
         out = torch.empty((b, v - 1, n, 8) + tuple(f3.shape[2:]), device=f3.device, dtype=torch.float32)
         p = _corr_init_params(src3, ref3, proj, inv_min, inv_max, n, out)
@@ -353,18 +361,21 @@ class _CorrInitFn(torch.autograd.Function):
         ptrs = (C.c_void_p * (v - 1))(*[t.data_ptr() for t in gsrc])
         check(_lib.load().itermvs_corr_init_backward(C.byref(p), gout.data_ptr(), ptrs, gref.data_ptr(), _stream()),
               "itermvs_corr_init_backward")
-        return gf.to(f3.dtype), None, None, None, None, None, None
+        return gf, None, None, None, None, None, None, None
 
 
-def corr_init_train(f3: Tensor, b: int, v: int, proj: Tensor, inv_min: Tensor, inv_max: Tensor, num_samples: int = 32) -> Tensor:
-    """differentiable itermvs_corr_init on the dense channels-last level-3 features [B*V,48,H,W]: -> [B,S,N,8,H,W]"""
-    return _CorrInitFn.apply(_need_cl(f3, "feature level 3"), _dev(proj, "proj").contiguous(), inv_min, inv_max, num_samples, b, v)
+def corr_init_train(f3: Tensor, b: int, v: int, proj: Tensor, inv_min: Tensor, inv_max: Tensor, num_samples: int = 32,
+                    stored: Optional[Tensor] = None) -> Tensor:
+    """differentiable itermvs_corr_init on the dense channels-last fp32 level-3 features [B*V,48,H,W]: -> [B,S,N,8,H,W];
+    ``stored``: the bf16 / fp16 copy the kernel reads (16-bit feature storage), default ``f3`` itself"""
+    f3 = _need_cl(_dev(f3, "feature level 3"), "feature level 3")
+    s3 = f3 if stored is None else _need_cl(stored.detach(), "stored feature level 3")
+    return _CorrInitFn.apply(f3, _dev(proj, "proj").contiguous(), inv_min, inv_max, num_samples, b, v, s3)
 
 
 def corr_iter_kernel_name() -> str:
-    """name of the device kernel itermvs_corr_iter launches by default (rocprofv3's Kernel_Name contains it)"""
-    form = os.environ.get("ITERMVS_CORR_ITER_IMPL", "1")
-    return "corr_iter_kernel" if (int(form) if form.isdigit() else 1) % 10 == 1 else "corr_iter_vw_kernel"
+    """name of the device kernel itermvs_corr_iter launches (rocprofv3's Kernel_Name contains it)"""
+    return "corr_iter_kernel"
 
 
 def corr_init(src3: Sequence[Tensor], ref3: Tensor, proj: Tensor, inv_min: Tensor, inv_max: Tensor,
@@ -676,7 +687,7 @@ _TILE_SHAPES = {(1, 1), (2, 1), (1, 2)}   # (stride, dilation) instantiated in c
 
 
 def _use_tile(wt: "MfmaWeight", stride: int, dilation: int) -> bool:
-    if wt.tile is None or os.environ.get("ITERMVS_CONV_TILE", "1") == "0":
+    if wt.tile is None:
         return False
     return (stride, dilation) in _TILE_SHAPES and (wt.cin > 4 or (stride, dilation) == (1, 1))
 

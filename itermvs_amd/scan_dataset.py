@@ -115,39 +115,80 @@ def to_device(sample: dict, dev, all_levels: bool = False) -> Tuple[dict, dict, 
 
 
 class Prefetcher:
-    """Iterates a ScanFolderDataset shard: a host thread decodes the images of the next ``depth`` samples into pinned
-    memory, the upload + pyramid kernel are enqueued on a side HIP stream, and each item is handed to the consumer with an
-    event its compute stream waits on -- decode, H2D and the previous depth map's kernels overlap."""
+    """Iterates a ScanFolderDataset shard with ONE sample always staged ahead on the device: a host thread decodes the
+    images of the next ``depth`` samples into pinned memory; before item n is handed to the consumer, the upload and the
+    pyramid kernel of item n+1 are already enqueued on a side HIP stream (their ``ready`` event recorded), so decode, H2D
+    and pyramid of the next reference view overlap the current depth map's kernels and its D2H.  The consumer's compute
+    stream waits on the item's event when the item is yielded.  ``close()`` (or leaving the iteration early) stops the
+    worker thread."""
 
     def __init__(self, dataset, indices: Sequence[int], dev, depth: int = 2):
-        self.dataset, self.indices, self.dev = dataset, list(indices), dev
+        self.dataset, self.indices, self.dev = dataset, list(indices), torch.device(dev)
         self.q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
-        self.stream = torch.cuda.Stream(device=dev)
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self._stop = threading.Event()
+        self.staged_ahead = 0          # items whose upload was enqueued before the previous item was yielded (tests read it)
         self.thread = threading.Thread(target=self._work, daemon=True)
         self.thread.start()
 
+    def _put(self, item) -> bool:
+        while not self._stop.is_set():
+            try:
+                self.q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
     def _work(self) -> None:
+        torch.cuda.set_device(self.dev)       # pin through THIS rank's device context, not device 0's
         try:
             for i in self.indices:
                 s = self.dataset[i]
                 s["raw"] = s["raw"].pin_memory()
-                self.q.put(s)
+                if not self._put(s):
+                    return
         except Exception as e:  # noqa: BLE001  (surfaced to the consumer)
-            self.q.put(e)
-        self.q.put(None)
+            self._put(e)
+            return
+        self._put(None)
+
+    def close(self) -> None:
+        """stop the decoder thread (a consumer that leaves early must not strand it on a full queue)"""
+        self._stop.set()
+        while True:
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                break
+        self.thread.join(timeout=5)
+
+    def _stage(self):
+        """next decoded sample -> (sample, device tensors, ready event) with the upload + pyramid enqueued on the side
+        stream; None at the end of the shard"""
+        s = self.q.get()
+        if s is None:
+            return None
+        if isinstance(s, Exception):
+            raise s
+        with torch.cuda.stream(self.stream):
+            tensors = to_device(s, self.dev)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        return s, tensors, ready
 
     def __iter__(self):
-        while True:
-            s = self.q.get()
-            if s is None:
-                return
-            if isinstance(s, Exception):
-                raise s
-            with torch.cuda.stream(self.stream):
-                tensors = to_device(s, self.dev)
-                ready = torch.cuda.Event()
-                ready.record(self.stream)
-            torch.cuda.current_stream(self.dev).wait_event(ready)
-            for t in list(tensors[0].values()) + list(tensors[1].values()) + [tensors[2], tensors[3]]:
-                t.record_stream(torch.cuda.current_stream(self.dev))      # allocated on the side stream, used on this one
-            yield s, tensors
+        try:
+            nxt = self._stage()
+            while nxt is not None:
+                s, tensors, ready = nxt
+                nxt = self._stage()                # item n+1 is on its way to the device before item n is consumed
+                if nxt is not None:
+                    self.staged_ahead += 1
+                cur = torch.cuda.current_stream(self.dev)
+                cur.wait_event(ready)
+                for t in list(tensors[0].values()) + list(tensors[1].values()) + [tensors[2], tensors[3]]:
+                    t.record_stream(cur)           # allocated on the side stream, used on this one
+                yield s, tensors
+        finally:
+            self.close()

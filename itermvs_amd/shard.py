@@ -66,6 +66,31 @@ def timed_steps(step: Callable[[int], None], steps: int, warmup: int) -> float:
     return max_over_ranks(elapsed)
 
 
+def timed_regions(step: Callable[[int], None], steps: int, warmup: int, repeats: int) -> List[float]:
+    """``warmup`` untimed calls, then ``repeats`` timed regions of exactly ``steps`` calls each, back to back, every region
+    bracketed by a barrier + device synchronise on both sides; returns the MAX-over-ranks elapsed seconds of each region
+    (``step`` sees a running index).  A single short region is one scheduling hiccup away from a bad number: callers
+    report the median region."""
+    for i in range(warmup):
+        step(i)
+    out, base = [], warmup
+    for _ in range(max(1, repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(base + i)
+        barrier()
+        out.append(max_over_ranks(time.perf_counter() - t0))
+        base += steps
+    return out
+
+
+def median(values: Sequence[float]) -> float:
+    v = sorted(values)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+
 def max_over_ranks(value: float) -> float:
     if dist.is_available() and dist.is_initialized():
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"

@@ -145,14 +145,24 @@ def _convex_upsample(nd: Tensor, weight: Tensor) -> Tensor:
 
 
 def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor], depth_min: Tensor,
-                  depth_max: Tensor, iteration: int, bn_training: bool = True):
-    """``Pipeline(test=False).forward``: returns the reference's training dict (net.py:115-120)."""
+                  depth_max: Tensor, iteration: int, bn_training: bool = True, feature_dtype: str = "fp32"):
+    """``Pipeline(test=False).forward``: returns the reference's training dict (net.py:115-120).
+    ``feature_dtype`` "bf16" / "fp16" (BASELINE cfg 4: bf16): the three pyramids are STORED in 16 bits for the fused
+    correlation kernels (forward and backward gather half the bytes, fp32 arithmetic), exactly like test mode's
+    ``Pipeline.feature_dtype``; the rounding is straight-through for autograd (fp32 gradients, fp32 weights)."""
+    if feature_dtype not in ops.FEATURE_DTYPES:
+        raise ValueError(f"feature_dtype must be one of {sorted(ops.FEATURE_DTYPES)}, got {feature_dtype!r}")
+    store_dt = ops.FEATURE_DTYPES[feature_dtype]
     net = _Net(w, bn_training)
     b, v, _, hh, ww = imgs.shape
     s = v - 1
     feats = net.features(imgs.reshape(b * v, 3, hh, ww))
     # channels-last copies of the pyramid: what the fused correlation kernels gather from (autograd sees a layout change)
     cl = {l: f.contiguous(memory_format=torch.channels_last) for l, f in feats.items()}
+    stored = None
+    if store_dt != torch.float32:
+        stored = {l: cl[l].detach().to(store_dt) for l in cl}                          # what the kernels read
+        cl = {l: cl[l] + (stored[l].float() - cl[l]).detach() for l in cl}             # same values for the torch side
     ref = {l: cl[l].view(b, v, *cl[l].shape[1:])[:, 0] for l in (1, 2, 3)}
     nan_flag = torch.zeros((1,), device=imgs.device, dtype=torch.int32)
     with torch.no_grad():
@@ -162,12 +172,15 @@ def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor
     inv_min, inv_max = inv_min_b.view(b, 1, 1, 1), inv_max_b.view(b, 1, 1, 1)
 
     u = "iter_mvs.upsample."
-    up_w = F.conv2d(F.relu(F.conv2d(ref[2], w[u + "0.weight"], padding=1)), w[u + "2.weight"])
+    # (the up-sampling head reads the UNROUNDED level-2 reference features, like test mode's planar fp32 copy)
+    ref2_fp32 = feats[2].view(b, v, *feats[2].shape[1:])[:, 0]
+    up_w = F.conv2d(F.relu(F.conv2d(ref2_fp32, w[u + "0.weight"], padding=1)), w[u + "2.weight"])
     up_w = torch.softmax(up_w.view(b, 1, 9, 4, 4, h, wd), dim=2)
 
     # ---- initialisation: itermvs.py:36-82 ------------------------------------------------------
     k = torch.arange(INIT_SAMPLES, device=imgs.device, dtype=torch.float32).view(1, -1, 1, 1)
-    corr_views = ops.corr_init_train(cl[3], b, v, proj[2], inv_min_b, inv_max_b, INIT_SAMPLES)      # [B,S,N,8,h3,w3]
+    corr_views = ops.corr_init_train(cl[3], b, v, proj[2], inv_min_b, inv_max_b, INIT_SAMPLES,
+                                     stored=None if stored is None else stored[3])                 # [B,S,N,8,h3,w3]
     acc, wsum, vws = 0, 1e-5, []
     for i in range(s):
         corr = corr_views[:, i]                                                                 # [B,N,8,h3,w3]
@@ -198,7 +211,7 @@ def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor
     # ---- iterations: itermvs.py:288-314 ----------------------------------------------------------
     for it in range(iteration):
         # hypotheses clamp(nd + offsets) -> depth (itermvs.py:290-293) are built inside the kernel, as at inference
-        aggs = ops.corr_iter_train(cl, b, v, ref_q, proj, view_w_const, inv_min_b, inv_max_b, nd, offsets)
+        aggs = ops.corr_iter_train(cl, b, v, ref_q, proj, view_w_const, inv_min_b, inv_max_b, nd, offsets, stored=stored)
         scores = [net.corr_net(aggs[i], l) for i, l in enumerate((1, 2, 3))]
         hidden = net.gru(hidden, torch.cat([nd] + scores, 1))
         conf0 = net.conf_logit(hidden)

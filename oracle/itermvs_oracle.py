@@ -466,16 +466,25 @@ def feature_net(wts: Weights, images: Tensor, training: bool = False) -> Dict[in
 # --------------------------------------------------------------------------
 def pipeline_forward(wts: Weights, imgs: Dict[str, Tensor], proj_matrices: Dict[str, Tensor],
                      depth_min: Tensor, depth_max: Tensor, iteration: int = 4,
-                     test: bool = True, training: bool = False, trace: Optional[dict] = None):
+                     test: bool = True, training: bool = False, trace: Optional[dict] = None,
+                     feature_storage: Optional[torch.dtype] = None):
     """net.py:78-128.  ``imgs['level_0']`` [B,V,3,H,W]; ``proj_matrices['level_l']``
     [B,V,4,4] for l=1..3.  Returns the same dict as the reference (test: keys
     depths_upsampled / confidence_upsampled; train: depths{combine,probability,
     initial}, depths_upsampled[list], confidences[list], confidence_upsampled).
-    ``trace`` (optional dict) receives intermediate tensors for kernel tests."""
+    ``trace`` (optional dict) receives intermediate tensors for kernel tests.
+    ``feature_storage`` (torch.bfloat16 / torch.float16): model of the build's 16-bit feature STORAGE (BASELINE cfg 4 /
+    cfg 5; not a reference feature): the three pyramids are rounded to that type (round to nearest even) before the
+    matching stages read them, arithmetic stays fp32, the rounding is straight-through for autograd, and the
+    up-sampling head keeps reading the unrounded level-2 features -- what itermvs_amd does with ``feature_dtype``."""
     x = imgs["level_0"]
     b, v, _, hh, ww = x.shape
     feats = feature_net(wts, x.reshape(b * v, 3, hh, ww), training)
-    per_view = {l: f.view(b, v, *f.shape[1:]) for l, f in feats.items()}
+    ref2_unrounded = feats[2].view(b, v, *feats[2].shape[1:])[:, 0]
+    gathered = feats
+    if feature_storage is not None:
+        gathered = {l: f + (f.to(feature_storage).float() - f).detach() for l, f in feats.items()}
+    per_view = {l: f.view(b, v, *f.shape[1:]) for l, f in gathered.items()}
     ref_f = {l: per_view[l][:, 0] for l in (1, 2, 3)}
     src_f = {l: [per_view[l][:, i] for i in range(1, v)] for l in (1, 2, 3)}
     projs = {l: proj_matrices[f"level_{l}"].float() for l in (1, 2, 3)}
@@ -485,7 +494,7 @@ def pipeline_forward(wts: Weights, imgs: Dict[str, Tensor], proj_matrices: Dict[
     depth_max = depth_max.float()
 
     h, w = ref_f[2].shape[2:]
-    up_w = upsample_weights(wts, ref_f[2])
+    up_w = upsample_weights(wts, ref2_unrounded)
     inv_min = (1.0 / depth_min).view(b, 1, 1, 1)
     inv_max = (1.0 / depth_max).view(b, 1, 1, 1)
 
@@ -495,7 +504,7 @@ def pipeline_forward(wts: Weights, imgs: Dict[str, Tensor], proj_matrices: Dict[
     hidden = hidden_init(wts, score)
     nd, prob, best = depth_init(wts, hidden)
     if trace is not None:
-        trace.update(feats=feats, up_w=up_w, view_weights=view_w, init_score=score, init_agg=agg0,
+        trace.update(feats=feats, feats_gathered=gathered, up_w=up_w, view_weights=view_w, init_score=score, init_agg=agg0,
                      hidden0=hidden, nd0=nd, best0=best, iters=[])
 
     depths = {"combine": [], "probability": [], "initial": []}

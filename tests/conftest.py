@@ -73,6 +73,46 @@ def weights_dtu():
     return load_weights("dtu")
 
 
+def grad_slice(g, n=256):
+    """``n`` evenly spaced elements of a gradient tensor (all of it when smaller); the indices tests/golden/make_golden.py
+    recorded the reference's gradients at"""
+    flat = g.detach().reshape(-1)
+    if flat.numel() <= n:
+        return flat.clone()
+    idx = torch.linspace(0, flat.numel() - 1, n).round().long().to(flat.device)
+    return flat[idx]
+
+
+def check_gradient_slices(g, tag, grads, rel_l2, min_cos, min_checked=10):
+    """Full-tensor gradient check against the reference's recorded gradient slices (``{tag}.grad_slices`` of a training
+    golden): for every parameter the reference differentiates, relative L2 error <= ``rel_l2`` and cosine >= ``min_cos`` of
+    the sliced gradient -- a norm cannot see a wrong direction, this can.  ``grads``: name -> gradient tensor (or None).
+    Returns (worst relative L2, worst cosine, parameters checked)."""
+    names = [str(x) for x in g.np(f"{tag}.grad_names")]
+    lens = [int(x) for x in g.np(f"{tag}.grad_slice_len")]
+    flat = g[f"{tag}.grad_slices"].double()
+    worst_l2, worst_cos, checked, off = 0.0, 1.0, 0, 0
+    for name, n in zip(names, lens):
+        want = flat[off:off + n]
+        off += n
+        if n == 0:
+            continue
+        got = grads[name]
+        assert got is not None, name
+        got = grad_slice(got).double().cpu()
+        assert got.numel() == n, name
+        wn = float(want.norm())
+        if wn < 1e-4:                       # rounding-noise gradients (e.g. the bias in front of a softmax: exactly 0 in theory)
+            assert float((got - want).norm()) <= 1e-4 * max(rel_l2 / 1e-3, 1.0), name
+            continue
+        l2 = float((got - want).norm()) / wn
+        cos = float((got * want).sum()) / (wn * max(float(got.norm()), 1e-30))
+        assert l2 <= rel_l2 and cos >= min_cos, (name, l2, cos)
+        worst_l2, worst_cos, checked = max(worst_l2, l2), min(worst_cos, cos), checked + 1
+    assert checked >= min_checked
+    return worst_l2, worst_cos, checked
+
+
 def run_ranks(worker, world, *args, attempts=3, timeout=180):
     """Spawn ``world`` CPU processes running ``worker(rank, world, port, *args, queue)`` and return their
     queue items sorted by rank; retried with a fresh rendezvous port if a rank fails to come up."""

@@ -43,6 +43,31 @@ def save(name, **arrays):
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(arrays)} arrays")
 
 
+def grad_slice(g, n=256):
+    """``n`` evenly spaced elements of a gradient tensor (all of it when smaller): what the full-tensor gradient checks of
+    tests/test_train_gpu.py compare (direction and magnitude, not just the norm).  Same indices as tests/conftest.py:grad_slice."""
+    flat = g.detach().reshape(-1)
+    if flat.numel() <= n:
+        return flat.clone()
+    idx = torch.linspace(0, flat.numel() - 1, n).round().long()
+    return flat[idx]
+
+
+def record_gradients(model, arrays, tag):
+    """per-parameter gradient norms (-1 = the reference leaves .grad None) and the concatenated gradient slices"""
+    names, norms, slices, lens = [], [], [], []
+    for k, p in model.named_parameters():
+        names.append(k)
+        norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+        sl = grad_slice(p.grad) if p.grad is not None else torch.zeros(0)
+        slices.append(sl.float())
+        lens.append(sl.numel())
+    arrays[f"{tag}.grad_names"] = np.array(names)
+    arrays[f"{tag}.grad_norms"] = np.array(norms, dtype=np.float64)
+    arrays[f"{tag}.grad_slices"] = npy(torch.cat(slices))
+    arrays[f"{tag}.grad_slice_len"] = np.array(lens, dtype=np.int64)
+
+
 def build_reference(weights, iteration, test):
     m = ref_net.Pipeline(iteration=iteration, test=test)
     m.load_state_dict(weights, strict=True)
@@ -236,12 +261,7 @@ def golden_train(weights):
         loss.backward()
         tag = "regress" if regress else "noregress"
         arrays[f"{tag}.loss"] = np.float64(loss.item())
-        names, norms = [], []
-        for k, p in model.named_parameters():
-            names.append(k)
-            norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
-        arrays[f"{tag}.grad_names"] = np.array(names)
-        arrays[f"{tag}.grad_norms"] = np.array(norms, dtype=np.float64)
+        record_gradients(model, arrays, tag)
         if regress:
             arrays["train.depths_upsampled"] = npy(out["depths_upsampled"][0])
             arrays["train.confidence_upsampled"] = npy(out["confidence_upsampled"])
@@ -272,12 +292,7 @@ def golden_train_cfg4(weights):
         loss.backward()
         tag = "regress" if regress else "noregress"
         arrays[f"{tag}.loss"] = np.float64(loss.item())
-        names, norms = [], []
-        for k, p in model.named_parameters():
-            names.append(k)
-            norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
-        arrays[f"{tag}.grad_names"] = np.array(names)
-        arrays[f"{tag}.grad_norms"] = np.array(norms, dtype=np.float64)
+        record_gradients(model, arrays, tag)
         if regress:
             d = out["depths_upsampled"][0]
             arrays["train.depth_sub"] = npy(d[:, :, ::8, ::8])

@@ -36,7 +36,8 @@ class MiopenEngine(InferenceEngine):
         mid = ops.bilinear_up(mid, 2).add_(F.conv2d(f1, w[p + "inner1.weight"], w[p + "inner1.bias"]))  # net.py:49
         o1 = F.conv2d(mid, w[p + "output1.weight"], w[p + "output1.bias"], padding=1)
         self.o2_planar = o2.contiguous()
-        return {l: ops.channels_last(f) for l, f in ((1, o1), (2, o2), (3, o3))}
+        # 16-bit feature storage: torch's cast rounds to nearest even like the HIP convolutions' channels-last epilogue
+        return {l: ops.channels_last(f).to(self.feature_dtype) for l, f in ((1, o1), (2, o2), (3, o3))}
 
     def _corr_net(self, x, level):
         w, p = self.w, f"iter_mvs.evaluation.corr_conv1.{level - 1}."

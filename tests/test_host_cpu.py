@@ -199,3 +199,29 @@ def test_weight_packings_follow_the_documented_layouts():
     assert float(a2[9, 2, 1, 15, 0]) == float(w2[9 * 16 + 15, 2 * 16 + 1 * 4 + 0, 0, 0])
     v = ops.pack_conv_weight(w)                                        # VALU format [Cin, k, k, Cout]
     assert v.shape == (48, 3, 3, 48) and float(v[7, 2, 1, 40]) == float(w[40, 7, 2, 1])
+
+
+def test_bench_self_launch_and_workload_names():
+    """`python bench.py --gpus 8` without a launcher re-executes itself under torch.distributed.run (one rank per GPU,
+    rendezvous on 127.0.0.1); the bench line names the BASELINE config that actually ran"""
+    import sys
+    import bench
+    cmd = bench.self_launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(bench.os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert bench.workload_name(5, 512, 640, 4).startswith("BASELINE cfg 2")
+    assert bench.workload_name(5, 1152, 1600, 4).startswith("BASELINE cfg 3")
+    assert bench.workload_name(11, 1280, 1920, 8).startswith("BASELINE cfg 5")
+    assert bench.workload_name(3, 64, 96, 2).startswith("custom")
+
+
+def test_timed_regions_and_median():
+    from itermvs_amd import shard
+    calls = []
+    regions = shard.timed_regions(lambda i: calls.append(i), steps=4, warmup=3, repeats=5)
+    assert len(regions) == 5 and all(r >= 0 for r in regions)
+    assert calls == list(range(3 + 4 * 5))                       # a running step index: warm-up, then 5 regions of 4
+    assert shard.median([3.0, 1.0, 2.0]) == 2.0 and shard.median([4.0, 1.0, 2.0, 3.0]) == 2.5

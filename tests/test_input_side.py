@@ -138,3 +138,32 @@ def test_eval_folder_mode_end_to_end(tmp_path):
     # the reference view of item 0 is view 0: its level-0 image is the scene image up to the 8-bit quantisation
     imgs, _, _, _ = to_device(ds[0], torch.device(DEV))
     assert float((imgs["level_0"][0, 0].cpu() - s["imgs"]["level_0"][0, 0]).abs().max()) <= 1.0 / 255 + 1e-6
+
+
+@pytest.mark.gpu
+def test_prefetcher_stages_one_sample_ahead(tmp_path):
+    """the prefetcher's contract: item n+1's upload + pyramid kernel are enqueued on the side stream BEFORE item n is
+    handed out (ordering: its ``ready`` event is already recorded while the consumer works on n), the tensors equal a
+    direct ``to_device``, and a consumer that leaves early does not strand the decoder thread"""
+    from itermvs_amd.scan_dataset import Prefetcher, ScanFolderDataset, to_device
+    _, scan = write_scan(str(tmp_path / "data"), 4, (96, 160))
+    ds = ScanFolderDataset(str(tmp_path / "data"), [scan], 4, (160, 96))
+    dev = torch.device(DEV)
+    pf = Prefetcher(ds, [0, 1, 2, 3], dev, depth=1)
+    seen, ahead = [], []
+    for sample, (imgs, projs, dmin, dmax) in pf:
+        ahead.append(pf.staged_ahead)
+        torch.cuda.current_stream().synchronize()
+        want = to_device(ds[len(seen)], dev)
+        assert torch.equal(imgs["level_0"], want[0]["level_0"]) and torch.equal(projs["level_2"], want[1]["level_2"])
+        assert torch.equal(dmin, want[2]) and torch.equal(dmax, want[3])
+        seen.append(sample["filename"])
+    assert len(seen) == 4 and len(set(seen)) == 4
+    assert ahead == [1, 2, 3, 3]                 # while item n was consumed, item n+1 was already staged (none after the last)
+    assert not pf.thread.is_alive()
+    # leaving early: close() drains the queue and the worker exits instead of blocking on a full queue
+    pf2 = Prefetcher(ds, [0, 1, 2, 3], dev, depth=1)
+    for _ in pf2:
+        break
+    pf2.thread.join(timeout=10)
+    assert not pf2.thread.is_alive()

@@ -280,12 +280,15 @@ def test_smoke_entry():
     ge.smoke()
 
 
-@pytest.mark.parametrize("cfg", ["cfg3", "cfg5"])
-def test_full_size_configs_cross_backend(cfg):
+@pytest.mark.parametrize("cfg,fdt", [("cfg3", "fp32"), ("cfg5", "fp32"), ("cfg5", "fp16")])
+def test_full_size_configs_cross_backend(cfg, fdt):
     """BASELINE cfg 3 (1600x1152, 5 views, 4 iterations) and cfg 5 (1920x1280, 11 views, 8 iterations):
     too large for the CPU oracle in a test, so parity is checked through size-independent properties --
     determinism, the two independent convolution back-ends (hand-written MFMA kernels vs MIOpen) agreeing
-    to the platform's chaos floor, first arg-max identical, outputs inside the depth range."""
+    to the platform's chaos floor, first arg-max identical, outputs inside the depth range.
+    cfg 5 also runs AS STATED in BASELINE.json: fp16 feature storage at the full 1920x1280 / 11 views / 8 iterations.
+    With 16-bit storage the two back-ends' features (1e-6 apart in fp32) round to different fp16 values on ~0.2 % of
+    the elements, so the chaos floor between them is higher than in fp32 -- the bounds below are the measured ones."""
     from itermvs_amd import synthetic
     from itermvs_amd.engine import InferenceEngine
     views, h, w, iters = {"cfg3": (5, 1152, 1600, 4), "cfg5": (11, 1280, 1920, 8)}[cfg]
@@ -294,8 +297,8 @@ def test_full_size_configs_cross_backend(cfg):
     imgs, pm, dmin, dmax = to_dev(s)
     projs = {l: pm[f"level_{l}"] for l in (1, 2, 3)}
     from miopen_engine import MiopenEngine
-    hip = InferenceEngine(model.weights(), iters)
-    mio = MiopenEngine(model.weights(), iters)
+    hip = InferenceEngine(model.weights(), iters, fdt)
+    mio = MiopenEngine(model.weights(), iters, fdt)
     t_hip, t_mio = {}, {}
     with torch.no_grad():
         d1, c1 = hip.run(imgs["level_0"], projs, dmin, dmax, trace=t_hip)
@@ -310,5 +313,48 @@ def test_full_size_configs_cross_backend(cfg):
     flips0 = float((t_hip["best0"] != t_mio["best0"]).float().mean())
     rel = (d1 - d2).abs() / d2
     bad = float((rel > 1e-4).float().mean())
-    print(f"{cfg}: first-argmax flips {flips0:.6f}; depth mismatch HIP-convs vs MIOpen {bad:.5f}, median {float(rel.median()):.1e}")
-    assert flips0 <= 1e-3 and float(rel.median()) <= 1e-6 and bad <= 0.03
+    print(f"{cfg} {fdt}: first-argmax flips {flips0:.6f}; depth mismatch HIP-convs vs MIOpen {bad:.5f}, median {float(rel.median()):.1e}")
+    if fdt == "fp32":
+        assert flips0 <= 1e-3 and float(rel.median()) <= 1e-6 and bad <= 0.03
+    else:
+        assert hip.feature_net(imgs["level_0"][0, :1].contiguous())[1].dtype == torch.float16
+        assert flips0 <= 5e-3 and float(rel.median()) <= 1e-5 and bad <= 0.15
+
+
+def test_in_place_weight_updates_refresh_the_packed_engine():
+    """test-mode Pipeline folds / packs its weights and captures hipGraphs once; an autograd-visible in-place update of a
+    parameter (what an optimizer step does) must be noticed at the next forward (net.py: version counters), in eager and
+    in graph mode; two graph runners of one engine own separate workspaces"""
+    from itermvs_amd import synthetic
+    from itermvs_amd.engine import GraphedRunner
+    s = synthetic.make_sample(batch=1, num_views=3, height=64, width=96, seed=5)
+    for graphs in (False, True):
+        m = make_model("seed0", 2)
+        m.use_graphs = graphs
+        a = m(*to_dev(s))["depths_upsampled"].clone()
+        eng = m._engine
+        with torch.no_grad():
+            m.get_parameter("iter_mvs.update.depth_head.4.bias").add_(torch.linspace(-1, 1, 256, device=DEV))
+        b = m(*to_dev(s))["depths_upsampled"].clone()
+        assert m._engine is not eng and not torch.equal(a, b)
+        fresh = make_model("seed0", 2)
+        fresh.load_state_dict(m.state_dict())
+        fresh = fresh.to(DEV).eval()
+        assert torch.equal(fresh(*to_dev(s))["depths_upsampled"], b)
+        assert m(*to_dev(s))["depths_upsampled"].data_ptr() and m._engine is not eng
+    imgs, pm, dmin, dmax = to_dev(s)
+    pj = {l: pm[f"level_{l}"] for l in (1, 2, 3)}
+    eng = make_model("seed0", 2)
+    eng(imgs, pm, dmin, dmax)
+    r1 = GraphedRunner(eng._engine, imgs["level_0"], pj, dmin, dmax)
+    r2 = GraphedRunner(eng._engine, imgs["level_0"], pj, dmin, dmax)
+    keys = [k for k in eng._engine._ws if k[3] is not None]
+    assert len(keys) == 2 and eng._engine._ws[keys[0]]["hx"].data_ptr() != eng._engine._ws[keys[1]]["hx"].data_ptr()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        o1 = r1(imgs["level_0"], pj, dmin, dmax)
+    with torch.cuda.stream(s2):
+        o2 = r2(imgs["level_0"], pj, dmin, dmax)
+    torch.cuda.synchronize()
+    assert torch.equal(o1[0], o2[0]) and torch.equal(o1[1], o2[1])

@@ -72,11 +72,17 @@ def check_head(eng, ws, w_cpu, hidden_o, best_o, nd_o, tag):
     return out, float(decided.float().mean())
 
 
-CASES = [("dtu", "scene", 5, 512, 640, 4), ("dtu", "noise", 5, 512, 640, 4), ("seed0", "noise", 5, 1152, 1600, 4)]
+# the last two: BASELINE cfg 5's geometry (10 source views, 8 GRU iterations) on a 512x384 crop, fp32 and with the fp16
+# feature storage that configuration names (the oracle models the storage: features rounded to fp16 before the matching
+# stages, ``feature_storage``); the full 1920x1280 size is covered by test_full_size_configs_cross_backend
+CASES = [("dtu", "scene", 5, 512, 640, 4, "fp32"), ("dtu", "noise", 5, 512, 640, 4, "fp32"), ("seed0", "noise", 5, 1152, 1600, 4, "fp32"),
+         ("dtu", "scene", 11, 384, 512, 8, "fp32"), ("dtu", "scene", 11, 384, 512, 8, "fp16")]
+STORAGE = {"fp32": None, "fp16": torch.float16, "bf16": torch.bfloat16}
 
 
-@pytest.mark.parametrize("wtag,kind,views,height,width,iters", CASES, ids=["cfg1-dtu-scene", "cfg1-dtu-noise", "cfg3-seed0-noise"])
-def test_every_stage_on_the_oracles_inputs(wtag, kind, views, height, width, iters):
+@pytest.mark.parametrize("wtag,kind,views,height,width,iters,storage", CASES,
+                         ids=["cfg1-dtu-scene", "cfg1-dtu-noise", "cfg3-seed0-noise", "cfg5geom-dtu-scene", "cfg5geom-dtu-scene-fp16"])
+def test_every_stage_on_the_oracles_inputs(wtag, kind, views, height, width, iters, storage):
     from itermvs_amd import ops, synthetic
     from itermvs_amd.engine import InferenceEngine
     torch.set_num_threads(min(32, max(8, torch.get_num_threads())))
@@ -85,8 +91,9 @@ def test_every_stage_on_the_oracles_inputs(wtag, kind, views, height, width, ite
          else synthetic.make_sample(batch=1, num_views=views, height=height, width=width, seed=0))
     t = {}
     with torch.no_grad():
-        out_o = O.pipeline_forward(w_cpu, s["imgs"], s["proj_matrices"], s["depth_min"], s["depth_max"], iters, trace=t)
-    eng = InferenceEngine({k: cu(v) for k, v in w_cpu.items()}, iters)
+        out_o = O.pipeline_forward(w_cpu, s["imgs"], s["proj_matrices"], s["depth_min"], s["depth_max"], iters, trace=t,
+                                   feature_storage=STORAGE[storage])
+    eng = InferenceEngine({k: cu(v) for k, v in w_cpu.items()}, iters, storage)
     b, v = 1, views
     sv = v - 1
     h, wd = height // 4, width // 4
@@ -102,11 +109,14 @@ def test_every_stage_on_the_oracles_inputs(wtag, kind, views, height, width, ite
     # FeatureNet on the same images (the only stage whose input is not an oracle intermediate)
     with torch.no_grad():
         feats = eng.feature_net(cu(s["imgs"]["level_0"]).reshape(b * v, 3, height, width).contiguous())
-    for l in (1, 2, 3):
-        lim(f"feat{l}", rel_err(feats[l], t["feats"][l]), 2e-5)
+    for l in (1, 2, 3):        # 16-bit storage: the engine's features are its fp32 results rounded once (half an fp16 ulp = 2^-12 relative)
+        assert feats[l].dtype == (STORAGE[storage] or torch.float32)
+        lim(f"feat{l}", rel_err(feats[l], t["feats"][l]), 2e-5 if storage == "fp32" else 5e-4)
 
-    # stage inputs from the oracle: features, reference-faithful fp32 projections (module.py:77-90), depth range
-    cl = {l: cu(t["feats"][l]).contiguous(memory_format=torch.channels_last) for l in (1, 2, 3)}
+    # stage inputs from the oracle: (stored) features, reference-faithful fp32 projections (module.py:77-90), depth range
+    cl = {l: cu(t["feats_gathered"][l]).to(feats[l].dtype).contiguous(memory_format=torch.channels_last) for l in (1, 2, 3)}
+    for l in (1, 2, 3):        # the oracle's rounded features are exactly representable in the storage type
+        assert torch.equal(cl[l].float().cpu(), t["feats_gathered"][l])
     pv = {l: cl[l].view(b, v, *cl[l].shape[1:]) for l in (1, 2, 3)}
     src = {l: [pv[l][:, i] for i in range(1, v)] for l in (1, 2, 3)}
     ref = {l: pv[l][:, 0] for l in (1, 2, 3)}

@@ -3,10 +3,15 @@ the reference's forward + full_loss + backward captured in tests/golden/train_sm
 import pytest
 import torch
 
-from conftest import golden, load_weights
+from conftest import check_gradient_slices, golden, grad_slice, load_weights, run_ranks
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# full-tensor gradient agreement with the reference (sliced gradients of every differentiated parameter): the training
+# graph is chaotic like inference (an arg-max flip moves a pixel's regression window), so the bound is the platform floor
+# between two back-ends, not fp32 rounding
+GRAD_REL_L2 = 8e-2
+GRAD_MIN_COS = 0.995
 
 
 @pytest.mark.parametrize("regress", [True, False])
@@ -44,7 +49,11 @@ def test_train_step_matches_reference(regress):
             err = abs(float(got.norm()) - want) / max(want, 1e-3)
             worst = max(worst, err)
             assert err <= 6e-2, (name, float(got.norm()), want)
-    print(f"train {tag}: loss {loss.item():.6f} (reference {ref:.6f}); worst grad-norm deviation {worst:.2e}")
+    # the gradient TENSORS (256 evenly spaced elements of each of the ~100 differentiated parameters) against the
+    # reference's: direction and magnitude.  Measured on the MI355X: see the printed line (profiles/r03).
+    l2, cos, nchk = check_gradient_slices(g, tag, {n: p.grad for n, p in params.items()}, rel_l2=GRAD_REL_L2, min_cos=GRAD_MIN_COS)
+    print(f"train {tag}: loss {loss.item():.6f} (reference {ref:.6f}); worst grad-norm deviation {worst:.2e}; "
+          f"gradient slices: worst rel L2 {l2:.2e}, worst cosine {cos:.6f} over {nchk} parameters")
     if regress:
         d = out["depths_upsampled"][0].detach().cpu()
         rel = (d - g["train.depths_upsampled"]).abs() / g["train.depths_upsampled"]
@@ -90,9 +99,117 @@ def test_train_step_cfg4_full_size(regress):
             err = abs(float(got.norm()) - want) / max(want, 1e-3)
             worst = max(worst, err)
             assert err <= 6e-2, (name, float(got.norm()), want)
+    l2, cos, nchk = check_gradient_slices(g, tag, {n: p.grad for n, p in params.items()}, rel_l2=GRAD_REL_L2, min_cos=GRAD_MIN_COS)
     print(f"train cfg4 {tag}: loss {loss.item():.6f} (reference {ref:.6f}); worst grad-norm deviation {worst:.2e}; "
-          f"peak device memory {peak:.0f} MiB")
+          f"gradient slices: worst rel L2 {l2:.2e}, worst cosine {cos:.6f} over {nchk} parameters; peak device memory {peak:.0f} MiB")
     if regress:
         d = out["depths_upsampled"][0].detach().cpu()
         rel = (d[:, :, ::8, ::8] - g["train.depth_sub"]).abs() / g["train.depth_sub"]
         assert float(rel.median()) <= 1e-5 and float((rel > 1e-4).float().mean()) <= 0.05
+
+
+def _gpu_step(model, sample, gt, mk, regress=True):
+    dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    dmin, dmax = sample["depth_min"].to(DEV), sample["depth_max"].to(DEV)
+    from itermvs_amd.net import full_loss
+    out = model(dev(sample["imgs"]), dev(sample["proj_matrices"]), dmin, dmax)
+    loss = full_loss(out["depths"], out["depths_upsampled"], out["confidences"], dev(gt), dev(mk), dmin, dmax, regress)
+    loss.backward()
+    return out, loss
+
+
+def test_train_step_cfg4_bf16_feature_storage():
+    """BASELINE cfg 4 AS STATED: 5-view 640x512 training step with bf16 feature storage (train.py --feature_dtype bf16).
+    The fused correlation forward AND backward gather bf16 features (fp32 arithmetic, fp32 gradients).  Two checks:
+    (1) against the pinned CPU oracle evaluated with the same storage model (oracle ``feature_storage=torch.bfloat16``:
+        features rounded to bf16 before the matching stages, straight-through) -- loss within 2e-3, every gradient slice
+        within the back-end floor used for the fp32 step;
+    (2) the stated tolerance against the REFERENCE's fp32 step (tests/golden/train_cfg4.npz): loss within 2 %, gradient
+        slices within 25 % relative L2 / cosine >= 0.97 -- bf16 storage perturbs the correlations by ~2^-9 and that flips
+        arg-max bins on a few per cent of the pixels."""
+    from itermvs_amd import synthetic
+    from itermvs_amd.net import Pipeline
+    from oracle import itermvs_oracle as O
+    g = golden("train_cfg4.npz")
+    sample, gt, mk = synthetic.make_training_sample(num_views=5, height=512, width=640, seed=2)
+    w0 = load_weights("seed0")
+    model = Pipeline(iteration=4, test=False)
+    model.load_state_dict(w0)
+    model = model.to(DEV).train()
+    model.feature_dtype = "bf16"
+    out, loss = _gpu_step(model, sample, gt, mk)
+    params = dict(model.named_parameters())
+    ref32 = float(g.np("regress.loss"))
+    assert abs(loss.item() - ref32) <= 2e-2 * abs(ref32), (loss.item(), ref32)
+    l2r, cosr, _ = check_gradient_slices(g, "regress", {n: p.grad for n, p in params.items()}, rel_l2=0.25, min_cos=0.97)
+
+    torch.set_num_threads(min(32, max(8, torch.get_num_threads())))
+    w = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in w0.items()}
+    oo = O.pipeline_forward(w, sample["imgs"], sample["proj_matrices"], sample["depth_min"], sample["depth_max"], iteration=4,
+                            test=False, training=True, feature_storage=torch.bfloat16)
+    lo = O.full_loss(oo["depths"], oo["depths_upsampled"], oo["confidences"], gt, mk, sample["depth_min"], sample["depth_max"], True)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) <= 2e-3 * abs(lo.item()), (loss.item(), lo.item())
+    worst_l2, worst_cos, n = 0.0, 1.0, 0
+    for name, p in params.items():
+        if w[name].grad is None:
+            assert p.grad is None or float(p.grad.norm()) == 0.0, name
+            continue
+        want, got = grad_slice(w[name].grad).double(), grad_slice(p.grad).double().cpu()
+        if float(want.norm()) < 1e-4:
+            continue
+        l2 = float((got - want).norm() / want.norm())
+        cos = float((got * want).sum() / (want.norm() * got.norm()))
+        assert l2 <= GRAD_REL_L2 and cos >= GRAD_MIN_COS, (name, l2, cos)
+        worst_l2, worst_cos, n = max(worst_l2, l2), min(worst_cos, cos), n + 1
+    assert n >= 90
+    print(f"train cfg4 bf16 storage: loss {loss.item():.6f}; oracle with bf16 storage {lo.item():.6f}; reference fp32 {ref32:.6f}; "
+          f"gradient slices vs bf16 oracle: rel L2 {worst_l2:.2e}, cosine {worst_cos:.6f} ({n} parameters); "
+          f"vs the fp32 reference: rel L2 {l2r:.2e}, cosine {cosr:.6f}")
+
+
+def _ddp_worker(rank, world, port, height, width, feature_dtype, q):
+    """one rank of the two-rank training step: both ranks share cuda:0 (the GPU box has one GPU), gloo rendezvous"""
+    import os
+    import torch.distributed as dist
+    from itermvs_amd import ddp, synthetic
+    from itermvs_amd.net import Pipeline
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    model = Pipeline(iteration=2, test=False)
+    model.load_state_dict(load_weights("seed0"))
+    model = model.to(DEV).train()
+    model.feature_dtype = feature_dtype
+    ddp.broadcast_parameters(model)
+    sample, gt, mk = synthetic.make_training_sample(num_views=3, height=height, width=width, seed=10 + rank)   # rank-local B=1
+    _gpu_step(model, sample, gt, mk)
+    local = {n: (None if p.grad is None else p.grad.detach().cpu().clone()) for n, p in model.named_parameters()}
+    n_red = ddp.flat_allreduce_gradients(model.parameters())
+    torch.cuda.synchronize()
+    reduced = {n: (None if p.grad is None else p.grad.detach().cpu().clone()) for n, p in model.named_parameters()}
+    q.put((rank, local, reduced, n_red))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("feature_dtype", ["fp32", "bf16"])
+def test_two_rank_training_step_on_one_gpu(feature_dtype):
+    """BASELINE cfg 4's data parallelism (train.py:194-243 with one process per GPU instead of DataParallel): two processes
+    share cuda:0, each runs a rank-local B=1 HIP-backed training step on its own sample, then ONE flat all-reduce
+    (ddp.flat_allreduce_gradients).  Parameter by parameter the result must be the mean of the two single-rank gradients,
+    identical on both ranks, and parameters without gradient stay without."""
+    res = run_ranks(_ddp_worker, 2, 128, 160, feature_dtype, timeout=600)
+    (_, l0, r0, n0), (_, l1, r1, n1) = res
+    assert n0 == n1 and n0 > 300_000
+    checked = 0
+    for name in l0:
+        if l0[name] is None:
+            assert l1[name] is None and r0[name] is None and r1[name] is None, name
+            continue
+        mean = (l0[name] + l1[name]) / 2
+        assert torch.equal(r0[name], r1[name]), name                              # every rank holds the same averaged gradient
+        assert torch.allclose(r0[name], mean, rtol=1e-6, atol=1e-12), name        # == mean of the two rank-local gradients
+        assert not torch.equal(l0[name], l1[name]) or float(l0[name].abs().max()) == 0.0, name   # the ranks really saw different data
+        checked += 1
+    assert checked >= 95

@@ -5,7 +5,8 @@ Every layer is captured into a hipGraph of REPS launches and the replay is timed
 kernel time plus the ~4.5 us launch floor of a graph kernel node (no Python launch overhead).
   conv_bench.py [filter]            default dispatch
   conv_bench.py --sweep [filter]    every (tile shape, channel blocking) of the tiled kernel via ITERMVS_TILE_FORCE
-Other variants through the environment: ITERMVS_CONV_TILE=0 (gather kernel), ITERMVS_TILE_PERSIST, ITERMVS_TILE_MINWORK."""
+The sweep and the other overrides (ITERMVS_TILE_PERSIST, ITERMVS_TILE_MINWORK, ITERMVS_STEM_TH ...) exist only in a library
+built with `make -C itermvs_amd/csrc clean all TUNING=1`; the product build has no environment switches."""
 import os
 import sys
 

@@ -4,9 +4,9 @@
 # gpurun_out/<round>_pmc_kernels.json by tools/pmc_summary.py -- copy that file to profiles/ and commit it; bench.py reads
 # roofline.traffic from it.  Run on the GPU box from the repo root:   bash tools/pmc_kernels.sh [round-tag]
 # PMC_CMD overrides the profiled command (default: the eager bench run), e.g. PMC_CMD="python tools/stem_bench.py 20".
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-CMD=${PMC_CMD:-python $R/bench.py --steps 3 --warmup 2 --eager --minimal}
+CMD=${PMC_CMD:-python $R/bench.py --steps 3 --warmup 2 --repeats 1 --eager --minimal}
 OUT=$R/gpurun_out/pmc_$TAG
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Where does the host-buffers-in / host-buffers-out form of the metric lose its time?  (GPU box only)
+
+Runs the cfg-1 depth map with uint8 images from pinned host memory in several choreographies and prints ms per depth map
+for each, so the cost of each ingredient (H2D, D2H, cross-stream events, Python) is visible in one table:
+
+    resident        two alternating graph runners on one stream, no copies            (= bench `value`)
+    events_only     the three-stream event choreography of bench.transfers_leg with the copies removed
+    h2d_only        + H2D (uint8 images, cameras, depth range) and the GPU pyramid kernel
+    d2h_only        + D2H of depth and confidence
+    full            both                                                               (= bench `with_transfers.uint8_images`)
+    serial          everything on ONE stream, no events: H2D -> pyramid -> replay -> D2H
+    full_packed     like full, but cameras + depth range travel as ONE pinned block and ONE copy
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from itermvs_amd import ops, synthetic  # noqa: E402
+from itermvs_amd.engine import GraphedRunner, InferenceEngine  # noqa: E402
+from itermvs_amd.net import Pipeline  # noqa: E402
+
+H, W, V, IT = 512, 640, 5, 4
+dev = torch.device("cuda")
+m = Pipeline(iteration=IT, test=True)
+m.load_state_dict(synthetic.random_state_dict(0))
+m = m.to(dev).eval()
+eng = InferenceEngine(m.weights(), IT)
+samples = [synthetic.make_sample(1, V, H, W, seed=i) for i in range(4)]
+s0 = samples[0]
+pj0 = {l: s0["proj_matrices"][f"level_{l}"].float().to(dev) for l in (1, 2, 3)}
+runners = [GraphedRunner(eng, s0["imgs"]["level_0"].float().to(dev), pj0, s0["depth_min"].float().to(dev),
+                         s0["depth_max"].float().to(dev)) for _ in range(2)]
+host_in = []
+for s in samples:
+    img = s["imgs"]["level_0"].float()
+    u8 = ((img[0].permute(0, 2, 3, 1) + 1) * 127.5).round().clamp(0, 255).to(torch.uint8).contiguous()
+    host_in.append((u8.pin_memory(), torch.stack([s["proj_matrices"][f"level_{l}"].float() for l in (1, 2, 3)]).pin_memory(),
+                    s["depth_min"].float().pin_memory(), s["depth_max"].float().pin_memory()))
+host_out = [tuple(torch.empty(o.shape, dtype=o.dtype).pin_memory() for o in r.out) for r in runners]
+raw_dev = [torch.empty(host_in[0][0].shape, dtype=torch.uint8, device=dev) for _ in runners]
+s_in, s_cmp, s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
+
+
+def timed(step, n=200, warm=20):
+    for i in range(warm):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        step(warm + i)
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3, t_host / n * 1e3
+
+
+def make_three_stream(h2d: bool, d2h: bool):
+    ev_in = [torch.cuda.Event() for _ in range(2)]
+    ev_done = [torch.cuda.Event() for _ in range(2)]
+    ev_out = [torch.cuda.Event() for _ in range(2)]
+    started = [False, False]
+
+    def step(i):
+        k = i % 2
+        r = runners[k]
+        h_img, h_proj, h_min, h_max = host_in[i % len(host_in)]
+        with torch.cuda.stream(s_in):
+            if started[k]:
+                s_in.wait_event(ev_done[k])
+            if h2d:
+                raw_dev[k].copy_(h_img, non_blocking=True)
+                ops.image_pyramid(raw_dev[k], H, W, all_levels=False, out0=r.imgs[0])
+                r.proj_stack.copy_(h_proj, non_blocking=True)
+                r.depth_min.copy_(h_min, non_blocking=True)
+                r.depth_max.copy_(h_max, non_blocking=True)
+            ev_in[k].record(s_in)
+        with torch.cuda.stream(s_cmp):
+            s_cmp.wait_event(ev_in[k])
+            if started[k]:
+                s_cmp.wait_event(ev_out[k])
+            r(r.imgs, r.projs, r.depth_min, r.depth_max)
+            ev_done[k].record(s_cmp)
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(ev_done[k])
+            if d2h:
+                for h, d in zip(host_out[k], r.out):
+                    h.copy_(d, non_blocking=True)
+            ev_out[k].record(s_out)
+        started[k] = True
+    return step
+
+
+def resident(i):
+    r = runners[i % 2]
+    with torch.cuda.stream(s_cmp):
+        r(r.imgs, r.projs, r.depth_min, r.depth_max)
+
+
+def serial(i):
+    k = i % 2
+    r = runners[k]
+    h_img, h_proj, h_min, h_max = host_in[i % len(host_in)]
+    with torch.cuda.stream(s_cmp):
+        raw_dev[k].copy_(h_img, non_blocking=True)
+        ops.image_pyramid(raw_dev[k], H, W, all_levels=False, out0=r.imgs[0])
+        r.proj_stack.copy_(h_proj, non_blocking=True)
+        r.depth_min.copy_(h_min, non_blocking=True)
+        r.depth_max.copy_(h_max, non_blocking=True)
+        r(r.imgs, r.projs, r.depth_min, r.depth_max)
+        for h, d in zip(host_out[k], r.out):
+            h.copy_(d, non_blocking=True)
+
+
+rows = [("resident", resident), ("events_only", make_three_stream(False, False)), ("h2d_only", make_three_stream(True, False)),
+        ("d2h_only", make_three_stream(False, True)), ("full", make_three_stream(True, True)), ("serial", serial)]
+print(f"{'choreography':<14} {'ms/map':>8} {'host ms/step':>13} {'maps/s':>8}")
+for name, fn in rows:
+    ms, host = timed(fn)
+    print(f"{name:<14} {ms:8.3f} {host:13.3f} {1e3 / ms:8.1f}", flush=True)
+eng.check_projection_finite()

@@ -50,6 +50,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--n_views", type=int, default=5)
     p.add_argument("--img_wh", nargs="+", type=int, default=[640, 512])
     p.add_argument("--steps_per_epoch", type=int, default=8, help="synthetic dataset only")
+    p.add_argument("--feature_dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
+                   help="storage type of the feature pyramids the fused correlation kernels gather from (BASELINE cfg 4: bf16); "
+                        "arithmetic, gradients and weights stay fp32")
     return p
 
 
@@ -147,6 +150,7 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     model = Pipeline(iteration=args.iteration, test=False).to(dev)
+    model.feature_dtype = args.feature_dtype
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, betas=(0.9, 0.999), weight_decay=args.wd)  # train.py:98
     start_epoch = 0
     ckpt = latest_checkpoint(args.logdir) if args.resume else args.loadckpt
