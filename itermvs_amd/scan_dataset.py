@@ -123,7 +123,10 @@ class Prefetcher:
     worker thread."""
 
     def __init__(self, dataset, indices: Sequence[int], dev, depth: int = 2):
-        self.dataset, self.indices, self.dev = dataset, list(indices), torch.device(dev)
+        dev = torch.device(dev)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.dataset, self.indices, self.dev = dataset, list(indices), dev
         self.q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
         self.stream = torch.cuda.Stream(device=self.dev)
         self._stop = threading.Event()
@@ -141,8 +144,8 @@ class Prefetcher:
         return False
 
     def _work(self) -> None:
-        torch.cuda.set_device(self.dev)       # pin through THIS rank's device context, not device 0's
         try:
+            torch.cuda.set_device(self.dev)   # pin through THIS rank's device context, not device 0's
             for i in self.indices:
                 s = self.dataset[i]
                 s["raw"] = s["raw"].pin_memory()
@@ -166,7 +169,13 @@ class Prefetcher:
     def _stage(self):
         """next decoded sample -> (sample, device tensors, ready event) with the upload + pyramid enqueued on the side
         stream; None at the end of the shard"""
-        s = self.q.get()
+        while True:
+            try:
+                s = self.q.get(timeout=1.0)
+                break
+            except queue.Empty:
+                if not self.thread.is_alive() and self.q.empty():
+                    raise RuntimeError("Prefetcher: the decoder thread ended without delivering the end-of-shard marker")
         if s is None:
             return None
         if isinstance(s, Exception):

@@ -12,6 +12,7 @@
 # Every step runs under its own `timeout`; outputs land in gpurun_out/ (copy what should be judged into profiles/).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
+export MIOPEN_LOG_LEVEL=3
 mkdir -p gpurun_out
 TAG=$1; shift
 O=gpurun_out/$TAG
@@ -20,8 +21,8 @@ for step in "$@"; do
   n=$((n+1))
   arg=$(echo "${step#*:}" | tr '+' ' ')
   case "$step" in
-    tests)     timeout 1500 python -m pytest tests -m gpu -q -s > ${O}_tests.log 2>&1; tail -3 ${O}_tests.log; grep -E "^FAILED|^ERROR" ${O}_tests.log | head -20 ;;
-    tests:*)   timeout 1500 python -m pytest tests -m gpu -q -s -k "$arg" > ${O}_tests_$n.log 2>&1; tail -3 ${O}_tests_$n.log; grep -E "^FAILED|^ERROR" ${O}_tests_$n.log | head -20 ;;
+    tests)     timeout 1500 python -m pytest tests -m gpu -q -s --timeout 600 > ${O}_tests.log 2>&1; tail -3 ${O}_tests.log; grep -E "^FAILED|^ERROR" ${O}_tests.log | head -20 ;;
+    tests:*)   timeout 1500 python -m pytest tests -m gpu -q -s --timeout 600 -k "$arg" > ${O}_tests_$n.log 2>&1; tail -3 ${O}_tests_$n.log; grep -E "^FAILED|^ERROR" ${O}_tests_$n.log | head -20 ;;
     bench)     timeout 900 python bench.py > ${O}_bench.json 2> ${O}_bench.err; python tools/bench_digest.py ${O}_bench.json ;;
     bench:*)   timeout 900 python bench.py $arg > ${O}_bench_$n.json 2> ${O}_bench_$n.err; python tools/bench_digest.py ${O}_bench_$n.json ;;
     trace)     (cd /tmp && export TMPDIR=/tmp && rm -rf $R/${O}_prof && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/${O}_prof -- python $R/bench.py --steps 30 --warmup 6 --repeats 1 --minimal > $R/${O}_prof.log 2>&1)
