@@ -37,8 +37,7 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
     const WarpRcp rc = make_rcp(g);
     const float inv_min = a.inv_min[b], inv_max = a.inv_max[b];
     const float* proj = a.proj + ((size_t)(lvl * a.B + b) * a.S) * 12;
-    const uint32_t sy = (uint32_t)L.sy, sx = (uint32_t)L.sx;
-    const int lane = threadIdx.x & 63;
+    const uint32_t sy = (uint32_t)L.sy * feat_bytes<FT>(), sx = (uint32_t)L.sx * feat_bytes<FT>();   // byte strides (chunk_corr)
 
     // index arithmetic without integer division on the common path (an unsigned division costs ~25 vector instructions,
     // and these gather kernels are bound by instruction issue): items per pixel is a power of two for the reference's
@@ -76,33 +75,37 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
 #pragma unroll
         for (int q = 0; q < K::NG; ++q) acc[q] = 0.0f;
         float wsum = 1e-5f;  // itermvs.py:88
-        const uint32_t joff = (uint32_t)(j * 4);
-        const int gbase = lane - j;
-        // The projection and bilinear footprint of (pixel, hypothesis) in view s are the same for
-        // all LPT chunk lanes: lane j computes them for view s0 + j, then the group walks the batch of
-        // views and every lane fetches the footprint of view s0 + k from lane k (wavefront shuffles).
-        for (int s0 = 0; s0 < a.S; s0 += K::LPT) {
+        const uint32_t joff = (uint32_t)(j * 4) * feat_bytes<FT>();
+        // The projection, the bilinear footprint and the view weight of (pixel, hypothesis) in view s are the same for the
+        // four chunk lanes: lane j evaluates them for view s0 + j, then the quad walks the batch of views and every lane
+        // takes view s0 + k's from lane k with DPP quad_perm moves.
+        for (int s0 = 0; s0 < a.S; s0 += 4) {
             Footprint mine = {0u, 0u, 0u, 0u, 0.0f, 0.0f, 0.0f, 0.0f};
+            float w_mine = 0.0f;
             if (s0 + j < a.S) {
                 const float* m = proj + (s0 + j) * 12;
                 float rx, ry, rz, ix, iy;
                 ray_dir(m, xs, ys, rx, ry, rz);
                 project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
                 mine = make_footprint(ix, iy, L.W1, L.H1, sy, sx);
+                w_mine = a.view_w[((size_t)b * a.S + s0 + j) * P + p];
             }
-            const int nb = min(K::LPT, a.S - s0);
-            for (int k = 0; k < nb; ++k) {
-                const Footprint tp = shfl_footprint(mine, gbase + k);
-                float corr[K::NG];
-                chunk_corr<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), joff, tp, refv, corr);
-                const float wv = a.view_w[((size_t)b * a.S + s0 + k) * P + p];
+            const int nb = min(4, a.S - s0);          // wave-uniform
 #pragma unroll
-                for (int q = 0; q < K::NG; ++q) acc[q] = acc[q] + corr[q] * wv;  // itermvs.py:115
-                wsum = wsum + wv;                                                // itermvs.py:116
+            for (int k = 0; k < 4; ++k) {
+                if (k < nb) {
+                    const Footprint tp = quad_footprint(mine, k);
+                    const float wv = quad_bcast(w_mine, k);
+                    float corr[K::NG];
+                    chunk_corr<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), joff, tp, refv, corr);
+#pragma unroll
+                    for (int q = 0; q < K::NG; ++q) acc[q] = acc[q] + corr[q] * wv;  // itermvs.py:115
+                    wsum = wsum + wv;                                                // itermvs.py:116
+                }
             }
         }
 #pragma unroll
-        for (int q = 0; q < K::NG; ++q) lds[(n * ITERMVS_GROUPS + j * K::NG + q) * LS + px] = acc[q] / wsum;
+        for (int q = 0; q < K::NG; ++q) lds[(n * ITERMVS_GROUPS + K::group(j, q)) * LS + px] = acc[q] / wsum;
     }
     __syncthreads();
     const int rows = N * ITERMVS_GROUPS;
@@ -175,8 +178,7 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
     const float inv_min = a.inv_min[b], inv_max = a.inv_max[b];
     const float* m = a.proj + ((size_t)b * a.S + s) * 12;
     const float* fsrc = feat_base<FT>(a.src[s], (int64_t)b * a.sb);
-    const uint32_t sy = (uint32_t)a.sy, sx = (uint32_t)a.sx;
-    const int lane = threadIdx.x & 63;
+    const uint32_t sy = (uint32_t)a.sy * feat_bytes<FT>(), sx = (uint32_t)a.sx * feat_bytes<FT>();   // byte strides (chunk_corr)
 
     // index arithmetic without integer division on the common path (an unsigned division costs ~25 vector instructions,
     // and these gather kernels are bound by instruction issue): items per pixel is a power of two for the reference's
@@ -206,8 +208,8 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
             for (int c = 0; c < K::VEC; ++c)
                 refv[c] = ld_feat<FT>((const float*)a.ref.data, b * a.ref.sb + chunk_channel<K::VEC>(j, c) * a.ref.sc + y * a.ref.sy + x * a.ref.sx);
         }
-        // lane j projects hypothesis grp*LPT + j once; the group then walks its LPT hypotheses and
-        // every lane reads the footprint of hypothesis k from lane k (wavefront shuffles)
+        // lane j projects hypothesis grp*LPT + j once; the quad then walks its LPT hypotheses and
+        // every lane takes the footprint of hypothesis k from lane k (DPP quad_perm moves)
         const int nl_mine = grp * K::LPT + j;
         Footprint mine = {0u, 0u, 0u, 0u, 0.0f, 0.0f, 0.0f, 0.0f};
         if (nl_mine < nb) {
@@ -224,16 +226,18 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
             project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
             mine = make_footprint(ix, iy, a.W1, a.H1, sy, sx);
         }
-        const uint32_t joff = (uint32_t)(j * 4);
-        const int gbase = lane - j;
-        const int cnt = min(K::LPT, nb - grp * K::LPT);
-        for (int k = 0; k < cnt; ++k) {
-            const Footprint tp = shfl_footprint(mine, gbase + k);
-            float corr[K::NG];
-            chunk_corr<CPG, FT>(fsrc, joff, tp, refv, corr);
-            const int nl = grp * K::LPT + k;
+        const uint32_t joff = (uint32_t)(j * 4) * feat_bytes<FT>();
+        const int cnt = min(K::LPT, nb - grp * K::LPT);      // uniform per quad; whole quads take the branch together
 #pragma unroll
-            for (int q = 0; q < K::NG; ++q) lds[(nl * ITERMVS_GROUPS + j * K::NG + q) * LS + px] = corr[q];
+        for (int k = 0; k < K::LPT; ++k) {
+            if (k < cnt) {
+                const Footprint tp = quad_footprint(mine, k);
+                float corr[K::NG];
+                chunk_corr<CPG, FT>(fsrc, joff, tp, refv, corr);
+                const int nl = grp * K::LPT + k;
+#pragma unroll
+                for (int q = 0; q < K::NG; ++q) lds[(nl * ITERMVS_GROUPS + K::group(j, q)) * LS + px] = corr[q];
+            }
         }
     }
     __syncthreads();

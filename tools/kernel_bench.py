@@ -12,6 +12,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from itermvs_amd import _lib  # noqa: E402
+if "--lib" in sys.argv:     # A/B between library builds (tools only): must be set before the first load
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from itermvs_amd import ops, synthetic  # noqa: E402
 from itermvs_amd.engine import sample_offsets  # noqa: E402
 
@@ -40,17 +43,27 @@ def build(h, w, views, depth_kind, dev):
     return dict(src=src, ref=ref, ref_q=ref_q, proj=proj, nd=nd.to(dev), vw=vw.to(dev), inv_min=inv_min, inv_max=inv_max)
 
 
-def time_it(fn, n=50):
-    for _ in range(5):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3      # us
+def time_it(fn, n=20, reps=5):
+    """us per launch: n launches captured into one hipGraph (no host launch cost between them), best of `reps` replays"""
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin()
+        for _ in range(n):
+            fn()
+        g.capture_end()
+        best = 1e9
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / n * 1e3)
+    return best
 
 
 def main():
@@ -58,7 +71,9 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--views", type=int, default=5)
+    ap.add_argument("--lib", default=None, help="another build of libitermvs_hip.so (A/B runs)")
     args = ap.parse_args()
+    print("library:", _lib.LIB_PATH)
     dev = torch.device("cuda")
     offs = sample_offsets()
     for kind in ("noise", "smooth"):
@@ -66,10 +81,12 @@ def main():
         buf = [torch.empty((1, len(offs[l]), 8, args.height // 4, args.width // 4), device=dev) for l in (1, 2, 3)]
         run = lambda: ops.corr_iter(d["src"], d["ref_q"], d["proj"], d["vw"], d["inv_min"], d["inv_max"],
                                     norm_depth=d["nd"], offsets=offs, out=buf)
-        print(f"corr_iter depth={kind:6s}: {time_it(run):8.2f} us/launch", flush=True)
+        us = time_it(run)
+        print(f"corr_iter depth={kind:6s}: {us:8.2f} us/launch   checksums {[round(float(t.double().abs().sum()), 3) for t in buf]}", flush=True)
     d = build(args.height, args.width, args.views, "noise", dev)
-    us = time_it(lambda: ops.corr_init(d["src"][3], d["ref"][3], d["proj"][2], d["inv_min"], d["inv_max"], 32))
-    print(f"corr_init: {us:8.2f} us/launch")
+    out = torch.empty((1, args.views - 1, 32, 8, args.height // 8, args.width // 8), device=dev)
+    us = time_it(lambda: ops.corr_init(d["src"][3], d["ref"][3], d["proj"][2], d["inv_min"], d["inv_max"], 32, out=out))
+    print(f"corr_init: {us:8.2f} us/launch   checksum {float(out.double().abs().sum()):.3f}")
 
 
 if __name__ == "__main__":
