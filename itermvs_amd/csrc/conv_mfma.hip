@@ -151,6 +151,134 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const MfmaArgs a) {
     conv_epilogue<MB, NB>(make_epilogue(a, n, P), acc, m0, kslot, pix_off, oy, ox);
 }
 
+// ---------------------------------------------------------------------------------------------
+// FeatureNet's lateral layers (models/net.py:46,49): out = conv1x1(x) + bias + F.interpolate(coarse, x2, bilinear).
+// In the generic epilogue above every output element gathers its four coarse taps from global memory (192 gather loads
+// per lane against 28 operand loads and 48 MFMAs: 49 us for a layer whose traffic is worth 23 us, and 2.3x its bytes
+// moved through the L1).  Here a workgroup owns a 4 x 64 output tile (one row per wave, four 16-pixel slots); the
+// (4/2 + 2) x (64/2 + 2) coarse patch of all 48 channels is staged ONCE in LDS, border-replicated, so the taps of every
+// element are LDS reads at (i0, j0), (i0, j0 + 1), (i0 + 1, j0), (i0 + 1, j0 + 1) -- the arithmetic and its order are
+// those of the generic epilogue (== bilinear_up_kernel), results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLatTH = 4, kLatTW = 64;                       // output tile (rows = waves)
+constexpr int kLatPH = kLatTH / 2 + 2, kLatPW = kLatTW / 2 + 2;   // coarse patch 4 x 34
+constexpr int kLatRS = 37;                                   // LDS row stride; channel stride 4 * 37 = 148 floats: the two
+constexpr int kLatCS = kLatPH * kLatRS;                      // channel quads of a half-wave land 16 banks apart
+
+template <int MB>
+__global__ void __launch_bounds__(256, 4) lateral_up2_kernel(const MfmaArgs a, const int tiles_x) {
+    __shared__ float patch[MB * 16 * kLatCS];
+    constexpr int NB = kLatTW / 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kslot = lane >> 4, l16 = lane & 15;
+    const int n = blockIdx.z;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int P = a.Hout * a.Wout;
+    const int Hc = a.Hout >> 1, Wc = a.Wout >> 1;
+
+    // ---- stage the coarse patch: wave w takes channels w, w + 4, ...; lanes 0..33 one patch row per load ----
+    {
+        const uint32_t cplane_b = (uint32_t)(Hc * Wc) * 4u;
+        const __amdgpu_buffer_rsrc_t rc = epi_rsrc(a.add + (int64_t)n * a.add_sn, (uint32_t)a.Cout * cplane_b);
+        const int cy0 = ty * (kLatTH / 2) - 1, cx0 = tx * (kLatTW / 2) - 1;
+        int cx = cx0 + lane;
+        cx = cx < 0 ? 0 : (cx > Wc - 1 ? Wc - 1 : cx);
+        const uint32_t voff = lane < kLatPW ? (uint32_t)cx * 4u : kOob;
+        uint32_t rowoff[kLatPH];
+#pragma unroll
+        for (int i = 0; i < kLatPH; ++i) {
+            int cy = cy0 + i;
+            cy = cy < 0 ? 0 : (cy > Hc - 1 ? Hc - 1 : cy);
+            rowoff[i] = (uint32_t)(cy * Wc) * 4u;
+        }
+#pragma unroll 1
+        for (int c = wave; c < MB * 16; c += 16) {       // 4 channels x 4 rows = 16 loads in flight per trip
+            float v[4][kLatPH];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < kLatPH; ++i)
+                    v[u][i] = (c + 4 * u < a.Cout) ? bload(rc, voff, (uint32_t)(c + 4 * u) * cplane_b + rowoff[i]) : 0.0f;
+            if (lane < kLatPW) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < kLatPH; ++i) patch[(c + 4 * u) * kLatCS + i * kLatRS + lane] = v[u][i];
+            }
+        }
+    }
+
+    // ---- 1x1 convolution of this wave's row: 16 * MB channels x 64 pixels ----
+    const int oy = ty * kLatTH + wave;
+    const bool row_ok = oy < a.Hout;
+    int ox[NB];
+    bool pv[NB];
+    uint32_t iv[NB];
+    const uint32_t plane = (uint32_t)(a.Hin * a.Win);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        ox[nb] = tx * kLatTW + nb * 16 + l16;
+        pv[nb] = row_ok && ox[nb] < a.Wout;
+        iv[nb] = pv[nb] ? (uint32_t)kslot * plane * 4u + (uint32_t)(oy * a.Win + ox[nb]) * 4u : kOob;
+    }
+    f32x4 acc[MB][NB];
+    conv_bias_init<MB, NB>(acc, a.bias[0], a.Cout, 0, kslot);
+    {
+        const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (int64_t)n * a.in_sn), 0, (int)(a.Cin * plane * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight[0], 0, (int)((uint32_t)a.CinPad * a.CoutPad * 4u), 0x00020000);
+        const uint32_t wv = (uint32_t)(kslot * a.CoutPad + l16) * 4u;
+        const uint32_t wstep_b = 16u * a.CoutPad, istep_b = 16u * plane;
+        const int steps = a.CinPad >> 2;
+        uint32_t ws = 0, is = 0;
+        int st = 0;
+        for (; st + 4 <= steps; st += 4) {
+            k_group<MB, NB, 4>(acc, wr, wv, ws, wstep_b, ir, iv, is, istep_b);
+            ws += 4 * wstep_b;
+            is += 4 * istep_b;
+        }
+        for (; st < steps; ++st) {
+            k_group<MB, NB, 1>(acc, wr, wv, ws, wstep_b, ir, iv, is, istep_b);
+            ws += wstep_b;
+            is += istep_b;
+        }
+    }
+    __syncthreads();                                      // the patch is complete
+
+    // ---- epilogue: + x2 bilinear up-sampling of the patch (same arithmetic as conv_epilogue_act<0, 2>), planar stores ----
+    const uint32_t plane_b = (uint32_t)P * 4u;
+    const __amdgpu_buffer_rsrc_t ro = epi_rsrc(a.out + (int64_t)n * a.out_sn, (uint32_t)a.Cout * plane_b);
+    float sy = ((float)oy + 0.5f) * 0.5f - 0.5f;
+    sy = sy < 0.0f ? 0.0f : sy;
+    int y0 = (int)sy;
+    y0 = y0 > Hc - 1 ? Hc - 1 : y0;
+    const float ly1 = sy - (float)y0, ly0 = 1.0f - ly1;
+    const int i0 = y0 - (ty * (kLatTH / 2) - 1);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        float sx = ((float)ox[nb] + 0.5f) * 0.5f - 0.5f;
+        sx = sx < 0.0f ? 0.0f : sx;
+        int x0 = (int)sx;
+        x0 = x0 > Wc - 1 ? Wc - 1 : x0;
+        const float lx1 = sx - (float)x0, lx0 = 1.0f - lx1;
+        int j0 = x0 - (tx * (kLatTW / 2) - 1);
+        j0 = pv[nb] ? j0 : 0;                             // lanes beyond the image read a valid LDS address, store nothing
+        const int ii = row_ok ? i0 : 0;
+        const float* __restrict__ pb = patch + (kslot * 4) * kLatCS + ii * kLatRS + j0;
+        const uint32_t voff = pv[nb] ? (uint32_t)(oy * a.Wout + ox[nb]) * 4u + (uint32_t)(kslot * 4) * plane_b : kEpiOob;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* __restrict__ pc = pb + (mb * 16 + r) * kLatCS;
+                const float v00 = pc[0], v01 = pc[1], v10 = pc[kLatRS], v11 = pc[kLatRS + 1];
+                const float top = v00 * lx0 + v01 * lx1;
+                const float bot = v10 * lx0 + v11 * lx1;
+                const float ad = top * ly0 + bot * ly1;
+                epi_store(acc[mb][nb][r] + ad, ro, voff, (uint32_t)(mb * 16 + r) * plane_b);
+            }
+    }
+}
+
 // Split-K variant for layers with too few output tiles to fill the chip (ConvGRU gates, heads, the
 // coarse CorrNet layers: a few hundred 16x16 tiles, each a serial chain of up to 100 dependent k-steps).
 // The four waves of a block share ONE 16-pixel x 16*MB-channel tile and each takes every fourth k-step;
@@ -249,6 +377,13 @@ int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStr
     a.add_mode = p->add_mode; a.out_nhwc = p->out_layout;
     const int P = hout * wout;
     const int mt = a.CoutPad / 16;
+    // FeatureNet's lateral layers: 1x1 + bias + x2 bilinear up-sampled residual with the coarse patch staged in LDS
+    if (p->ksize == 1 && p->add_mode == 1 && p->add && p->out_layout == 0 && !p->out2 && p->act == 0 && p->stride == 1 && p->pad == 0 &&
+        p->n_seg == 1 && mt == 3 && !p->split_cout) {
+        const int tiles_x = (wout + kLatTW - 1) / kLatTW, tiles_y = (hout + kLatTH - 1) / kLatTH;
+        hipLaunchKernelGGL((lateral_up2_kernel<3>), dim3(tiles_x * tiles_y, 1, p->N), dim3(256), 0, stream, a, tiles_x);
+        return itermvs_launch_status();
+    }
     // largest register blocking (MB x NB tiles of 16 channels x 16 pixels per wave) that still yields
     // >= 2048 waves (2 per SIMD): bigger tiles need fewer loads per MFMA, more waves hide latency
     struct Cfg { int mb, nb; };

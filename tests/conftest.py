@@ -83,34 +83,81 @@ def grad_slice(g, n=256):
     return flat[idx]
 
 
-def check_gradient_slices(g, tag, grads, rel_l2, min_cos, min_checked=10):
-    """Full-tensor gradient check against the reference's recorded gradient slices (``{tag}.grad_slices`` of a training
-    golden): for every parameter the reference differentiates, relative L2 error <= ``rel_l2`` and cosine >= ``min_cos`` of
-    the sliced gradient -- a norm cannot see a wrong direction, this can.  ``grads``: name -> gradient tensor (or None).
-    Returns (worst relative L2, worst cosine, parameters checked)."""
-    names = [str(x) for x in g.np(f"{tag}.grad_names")]
-    lens = [int(x) for x in g.np(f"{tag}.grad_slice_len")]
-    flat = g[f"{tag}.grad_slices"].double()
-    worst_l2, worst_cos, checked, off = 0.0, 1.0, 0, 0
-    for name, n in zip(names, lens):
-        want = flat[off:off + n]
-        off += n
-        if n == 0:
+def oracle_training_step(weights, sample, gt, mk, iteration, regress, feature_storage=None, perturb=0.0):
+    """one training step of the pinned CPU oracle -> (loss, {parameter name: gradient or None}); ``perturb`` adds
+    N(0, perturb) noise to the images (the size of a convolution back-end's rounding) for chaos-floor measurements"""
+    from oracle import itermvs_oracle as O
+    w = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in weights.items()}
+    imgs = {k: v for k, v in sample["imgs"].items()}
+    if perturb:
+        gen = torch.Generator().manual_seed(99)
+        imgs["level_0"] = imgs["level_0"] + perturb * torch.randn(imgs["level_0"].shape, generator=gen)
+    out = O.pipeline_forward(w, imgs, sample["proj_matrices"], sample["depth_min"], sample["depth_max"], iteration=iteration,
+                             test=False, training=True, feature_storage=feature_storage)
+    loss = O.full_loss(out["depths"], out["depths_upsampled"], out["confidences"], gt, mk, sample["depth_min"], sample["depth_max"], regress)
+    loss.backward()
+    return float(loss.item()), {k: v.grad for k, v in w.items() if v.requires_grad}
+
+
+def gradient_chaos_floor(weights, sample, gt, mk, iteration, regress, feature_storage=None, perturb=2e-6):
+    """Per-parameter relative L2 change of the (sliced) oracle gradient when the images move by ``perturb`` -- rounding-size
+    noise.  The training graph is chaotic like inference (an arg-max flip moves a regression window; some gradients are small
+    sums of large cancelling terms, e.g. the bias in front of a soft-max): a back-end can only be asked to agree with the
+    reference to a few times this floor.  Returns ({name: floor}, base gradients, base loss)."""
+    l0, g0 = oracle_training_step(weights, sample, gt, mk, iteration, regress, feature_storage)
+    _, g1 = oracle_training_step(weights, sample, gt, mk, iteration, regress, feature_storage, perturb)
+    floor = {}
+    for n, a in g0.items():
+        if a is None:
+            continue
+        a, b = grad_slice(a).double(), grad_slice(g1[n]).double()
+        floor[n] = float((a - b).norm()) / max(float(a.norm()), 1e-30)
+    return floor, g0, l0
+
+
+def check_gradient_slices(g, tag, grads, rel_l2, min_cos, min_checked=10, floor=None, floor_factor=4.0, want=None):
+    """Full-tensor gradient check: for every parameter the reference differentiates, the sliced gradient (256 evenly spaced
+    elements, conftest.grad_slice) must agree with the reference's recorded one (``{tag}.grad_slices`` of a training golden;
+    or ``want``: name -> gradient tensor) in relative L2 (<= ``rel_l2``) and cosine (>= ``min_cos``) -- a norm cannot see a
+    wrong direction, this can.  ``floor`` (gradient_chaos_floor): parameters whose gradient is ill-conditioned get
+    max(rel_l2, floor_factor * floor) instead, and at least ``min_checked`` parameters must have been held to the base
+    tolerance.  ``grads``: name -> gradient tensor (or None).  Returns a report dict."""
+    if want is None:
+        names = [str(x) for x in g.np(f"{tag}.grad_names")]
+        lens = [int(x) for x in g.np(f"{tag}.grad_slice_len")]
+        flat = g[f"{tag}.grad_slices"].double()
+        want, off = {}, 0
+        for name, n in zip(names, lens):
+            want[name] = flat[off:off + n] if n else None
+            off += n
+    else:
+        want = {k: (None if v is None else grad_slice(v).double()) for k, v in want.items()}
+    rows, strict = [], 0
+    for name, ws in want.items():
+        if ws is None:
             continue
         got = grads[name]
         assert got is not None, name
         got = grad_slice(got).double().cpu()
-        assert got.numel() == n, name
-        wn = float(want.norm())
+        assert got.numel() == ws.numel(), name
+        wn = float(ws.norm())
         if wn < 1e-4:                       # rounding-noise gradients (e.g. the bias in front of a softmax: exactly 0 in theory)
-            assert float((got - want).norm()) <= 1e-4 * max(rel_l2 / 1e-3, 1.0), name
+            assert float((got - ws).norm()) <= 1e-4 * max(rel_l2 / 1e-3, 1.0), name
             continue
-        l2 = float((got - want).norm()) / wn
-        cos = float((got * want).sum()) / (wn * max(float(got.norm()), 1e-30))
-        assert l2 <= rel_l2 and cos >= min_cos, (name, l2, cos)
-        worst_l2, worst_cos, checked = max(worst_l2, l2), min(worst_cos, cos), checked + 1
-    assert checked >= min_checked
-    return worst_l2, worst_cos, checked
+        l2 = float((got - ws).norm()) / wn
+        cos = float((got * ws).sum()) / (wn * max(float(got.norm()), 1e-30))
+        fl = floor.get(name, 0.0) if floor else 0.0
+        bound = max(rel_l2, floor_factor * fl)
+        rows.append((l2, cos, fl, bound, name))
+        strict += bound == rel_l2
+    rows.sort(reverse=True)
+    bad = [r for r in rows if r[0] > r[3] or (r[3] == rel_l2 and r[1] < min_cos)]
+    report = {"worst_l2": rows[0][0], "worst_cos": min(r[1] for r in rows), "checked": len(rows), "strict": strict,
+              "median_l2": sorted(r[0] for r in rows)[len(rows) // 2],
+              "worst": [(n, round(l2, 4), round(c, 5), round(f, 4)) for l2, c, f, _, n in rows[:5]]}
+    assert not bad, [(n, l2, c, f) for l2, c, f, _, n in bad[:6]]
+    assert strict >= min_checked, report
+    return report
 
 
 def run_ranks(worker, world, *args, attempts=3, timeout=180):

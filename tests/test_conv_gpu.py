@@ -45,7 +45,8 @@ def packed(wt, fmt):
     return ops().MfmaWeight(wt) if fmt == "mfma" else ops().pack_conv_weight(wt)
 
 
-@pytest.mark.parametrize("shape", [(16, 48, 1, 32, 40, 3), (32, 48, 1, 18, 22, 2), (16, 32, 3, 64, 96, 2)])
+@pytest.mark.parametrize("shape", [(16, 48, 1, 32, 40, 3), (32, 48, 1, 18, 22, 2), (16, 32, 3, 64, 96, 2),
+                                   (16, 48, 1, 66, 130, 1), (16, 48, 1, 256, 320, 2), (32, 48, 1, 128, 160, 5), (20, 48, 1, 2, 2, 1)])
 def test_conv_fused_bilinear_residual(shape):
     """FeatureNet's `F.interpolate(coarse, scale_factor=2, 'bilinear') + inner(x)` (models/net.py:46,49) with the
     up-sampling evaluated in the conv epilogue: identical to bilinear_up + residual add"""
