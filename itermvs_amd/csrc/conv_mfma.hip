@@ -209,20 +209,29 @@ __global__ void __launch_bounds__(256, 4) lateral_up2_kernel(const MfmaArgs a, c
     }
 
     // ---- 1x1 convolution of this wave's row: 16 * MB channels x 64 pixels ----
+    // Operand roles are SWAPPED against conv_mfma_kernel: the pixels are the A operand (rows), the weights the B operand
+    // (columns), so D[pixel, channel] puts FOUR CONSECUTIVE PIXELS of one channel into a lane (pixel 4*kslot + r, channel
+    // l16): one dwordx4 store per accumulator into the NCHW plane instead of four dword stores into four planes, and the
+    // twelve taps of those four pixels are six LDS reads.  The k-ordered sums are the same, element for element.
     const int oy = ty * kLatTH + wave;
     const bool row_ok = oy < a.Hout;
-    int ox[NB];
-    bool pv[NB];
     uint32_t iv[NB];
     const uint32_t plane = (uint32_t)(a.Hin * a.Win);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        ox[nb] = tx * kLatTW + nb * 16 + l16;
-        pv[nb] = row_ok && ox[nb] < a.Wout;
-        iv[nb] = pv[nb] ? (uint32_t)kslot * plane * 4u + (uint32_t)(oy * a.Win + ox[nb]) * 4u : kOob;
+        const int ox = tx * kLatTW + nb * 16 + l16;
+        iv[nb] = (row_ok && ox < a.Wout) ? (uint32_t)kslot * plane * 4u + (uint32_t)(oy * a.Win + ox) * 4u : kOob;
     }
     f32x4 acc[MB][NB];
-    conv_bias_init<MB, NB>(acc, a.bias[0], a.Cout, 0, kslot);
+    {
+        const __amdgpu_buffer_rsrc_t rb = epi_rsrc(a.bias[0], a.bias[0] ? (uint32_t)a.Cout * 4u : 0u);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const float bs = a.bias[0] ? epi_load(rb, (uint32_t)(mb * 16 + l16) * 4u) : 0.0f;    // 0 beyond Cout
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{bs, bs, bs, bs};
+        }
+    }
     {
         const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (int64_t)n * a.in_sn), 0, (int)(a.Cin * plane * 4u), 0x00020000);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight[0], 0, (int)((uint32_t)a.CinPad * a.CoutPad * 4u), 0x00020000);
@@ -230,52 +239,84 @@ __global__ void __launch_bounds__(256, 4) lateral_up2_kernel(const MfmaArgs a, c
         const uint32_t wstep_b = 16u * a.CoutPad, istep_b = 16u * plane;
         const int steps = a.CinPad >> 2;
         uint32_t ws = 0, is = 0;
-        int st = 0;
-        for (; st + 4 <= steps; st += 4) {
-            k_group<MB, NB, 4>(acc, wr, wv, ws, wstep_b, ir, iv, is, istep_b);
-            ws += 4 * wstep_b;
-            is += 4 * istep_b;
-        }
-        for (; st < steps; ++st) {
-            k_group<MB, NB, 1>(acc, wr, wv, ws, wstep_b, ir, iv, is, istep_b);
-            ws += wstep_b;
-            is += istep_b;
+#pragma unroll 1
+        for (int st = 0; st < steps; st += 2) {          // two k-steps per trip (CinPad is a multiple of 4: 16 / 32 on the path)
+            const int u_n = st + 1 < steps ? 2 : 1;
+            float wv_[2][MB], xv[2][NB];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) wv_[u][mb] = u < u_n ? bload(wr, wv + mb * 64, ws + u * wstep_b) : 0.0f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) xv[u][nb] = u < u_n ? bload(ir, iv[nb], is + u * istep_b) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (u < u_n) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][nb], wv_[u][mb], acc[mb][nb], 0, 0, 0);
+                }
+            ws += 2 * wstep_b;
+            is += 2 * istep_b;
         }
     }
     __syncthreads();                                      // the patch is complete
 
-    // ---- epilogue: + x2 bilinear up-sampling of the patch (same arithmetic as conv_epilogue_act<0, 2>), planar stores ----
-    const uint32_t plane_b = (uint32_t)P * 4u;
-    const __amdgpu_buffer_rsrc_t ro = epi_rsrc(a.out + (int64_t)n * a.out_sn, (uint32_t)a.Cout * plane_b);
+    // ---- epilogue: + x2 bilinear up-sampling of the patch (same arithmetic as conv_epilogue_act<0, 2>) ----
     float sy = ((float)oy + 0.5f) * 0.5f - 0.5f;
     sy = sy < 0.0f ? 0.0f : sy;
     int y0 = (int)sy;
     y0 = y0 > Hc - 1 ? Hc - 1 : y0;
     const float ly1 = sy - (float)y0, ly0 = 1.0f - ly1;
-    const int i0 = y0 - (ty * (kLatTH / 2) - 1);
+    const int i0 = row_ok ? y0 - (ty * (kLatTH / 2) - 1) : 0;
+    const bool vec_ok = (a.Wout & 3) == 0 && (((uintptr_t)a.out | (uintptr_t)(a.out_sn * 4)) & 15) == 0;   // uniform
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        float sx = ((float)ox[nb] + 0.5f) * 0.5f - 0.5f;
-        sx = sx < 0.0f ? 0.0f : sx;
-        int x0 = (int)sx;
-        x0 = x0 > Wc - 1 ? Wc - 1 : x0;
-        const float lx1 = sx - (float)x0, lx0 = 1.0f - lx1;
-        int j0 = x0 - (tx * (kLatTW / 2) - 1);
-        j0 = pv[nb] ? j0 : 0;                             // lanes beyond the image read a valid LDS address, store nothing
-        const int ii = row_ok ? i0 : 0;
-        const float* __restrict__ pb = patch + (kslot * 4) * kLatCS + ii * kLatRS + j0;
-        const uint32_t voff = pv[nb] ? (uint32_t)(oy * a.Wout + ox[nb]) * 4u + (uint32_t)(kslot * 4) * plane_b : kEpiOob;
+        const int oxb = tx * kLatTW + nb * 16 + kslot * 4;                  // this lane's four pixels: oxb .. oxb + 3
+        // Their coarse columns x0 are (2m - 1, 2m, 2m, 2m + 1) for oxb = 4m, i.e. patch columns jb + (0, 1, 1, 2) with
+        // jb = nb * 8 + kslot * 2: a STATIC tap pattern over four patch values per row.  At the left image border sx clamps
+        // to 0 (x0 = 0, weights (1, 0)); the static pattern then reads the replicated border column with weight 1 and the
+        // true column 0 with weight 0 -- the same value as F.interpolate's v[0] * 1 + v[1] * 0.
+        float lx0[4], lx1[4];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+        for (int r = 0; r < 4; ++r) {
+            float sx = ((float)(oxb + r) + 0.5f) * 0.5f - 0.5f;
+            sx = sx < 0.0f ? 0.0f : sx;
+            int x0 = (int)sx;
+            x0 = x0 > Wc - 1 ? Wc - 1 : x0;
+            lx1[r] = sx - (float)x0;
+            lx0[r] = 1.0f - lx1[r];
+        }
+        const bool px_ok = row_ok && oxb < a.Wout;
+        const int jb = nb * 8 + kslot * 2;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int co = mb * 16 + l16;
+            const float* __restrict__ pc = patch + co * kLatCS + i0 * kLatRS + jb;
+            const float t0[4] = {pc[0], pc[1], pc[2], pc[3]};
+            const float t1[4] = {pc[kLatRS], pc[kLatRS + 1], pc[kLatRS + 2], pc[kLatRS + 3]};
+            f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float* __restrict__ pc = pb + (mb * 16 + r) * kLatCS;
-                const float v00 = pc[0], v01 = pc[1], v10 = pc[kLatRS], v11 = pc[kLatRS + 1];
-                const float top = v00 * lx0 + v01 * lx1;
-                const float bot = v10 * lx0 + v11 * lx1;
-                const float ad = top * ly0 + bot * ly1;
-                epi_store(acc[mb][nb][r] + ad, ro, voff, (uint32_t)(mb * 16 + r) * plane_b);
+                constexpr int kTap[4] = {0, 1, 1, 2};
+                const float top = t0[kTap[r]] * lx0[r] + t0[kTap[r] + 1] * lx1[r];
+                const float bot = t1[kTap[r]] * lx0[r] + t1[kTap[r] + 1] * lx1[r];
+                o[r] = acc[mb][nb][r] + (top * ly0 + bot * ly1);
             }
+            if (px_ok && co < a.Cout) {
+                float* __restrict__ dst = a.out + (int64_t)n * a.out_sn + (int64_t)co * P + (int64_t)oy * a.Wout + oxb;
+                if (vec_ok) {
+                    *reinterpret_cast<f32x4*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (oxb + r < a.Wout) dst[r] = o[r];
+                }
+            }
+        }
     }
 }
 
