@@ -176,43 +176,11 @@ __global__ void __launch_bounds__(256, 4) lateral_up2_kernel(const MfmaArgs a, c
     const int P = a.Hout * a.Wout;
     const int Hc = a.Hout >> 1, Wc = a.Wout >> 1;
 
-    // ---- stage the coarse patch: wave w takes channels w, w + 4, ...; lanes 0..33 one patch row per load ----
-    {
-        const uint32_t cplane_b = (uint32_t)(Hc * Wc) * 4u;
-        const __amdgpu_buffer_rsrc_t rc = epi_rsrc(a.add + (int64_t)n * a.add_sn, (uint32_t)a.Cout * cplane_b);
-        const int cy0 = ty * (kLatTH / 2) - 1, cx0 = tx * (kLatTW / 2) - 1;
-        int cx = cx0 + lane;
-        cx = cx < 0 ? 0 : (cx > Wc - 1 ? Wc - 1 : cx);
-        const uint32_t voff = lane < kLatPW ? (uint32_t)cx * 4u : kOob;
-        uint32_t rowoff[kLatPH];
-#pragma unroll
-        for (int i = 0; i < kLatPH; ++i) {
-            int cy = cy0 + i;
-            cy = cy < 0 ? 0 : (cy > Hc - 1 ? Hc - 1 : cy);
-            rowoff[i] = (uint32_t)(cy * Wc) * 4u;
-        }
-#pragma unroll 1
-        for (int c = wave; c < MB * 16; c += 16) {       // 4 channels x 4 rows = 16 loads in flight per trip
-            float v[4][kLatPH];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int i = 0; i < kLatPH; ++i)
-                    v[u][i] = (c + 4 * u < a.Cout) ? bload(rc, voff, (uint32_t)(c + 4 * u) * cplane_b + rowoff[i]) : 0.0f;
-            if (lane < kLatPW) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int i = 0; i < kLatPH; ++i) patch[(c + 4 * u) * kLatCS + i * kLatRS + lane] = v[u][i];
-            }
-        }
-    }
-
-    // ---- 1x1 convolution of this wave's row: 16 * MB channels x 64 pixels ----
+    // ---- operand set-up of this wave's row: 16 * MB channels x 64 pixels ----
     // Operand roles are SWAPPED against conv_mfma_kernel: the pixels are the A operand (rows), the weights the B operand
     // (columns), so D[pixel, channel] puts FOUR CONSECUTIVE PIXELS of one channel into a lane (pixel 4*kslot + r, channel
     // l16): one dwordx4 store per accumulator into the NCHW plane instead of four dword stores into four planes, and the
-    // twelve taps of those four pixels are six LDS reads.  The k-ordered sums are the same, element for element.
+    // twelve taps of those four pixels are eight LDS reads.  The k-ordered sums are the same, element for element.
     const int oy = ty * kLatTH + wave;
     const bool row_ok = oy < a.Hout;
     uint32_t iv[NB];
@@ -232,37 +200,78 @@ __global__ void __launch_bounds__(256, 4) lateral_up2_kernel(const MfmaArgs a, c
             for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{bs, bs, bs, bs};
         }
     }
-    {
-        const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (int64_t)n * a.in_sn), 0, (int)(a.Cin * plane * 4u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight[0], 0, (int)((uint32_t)a.CinPad * a.CoutPad * 4u), 0x00020000);
-        const uint32_t wv = (uint32_t)(kslot * a.CoutPad + l16) * 4u;
-        const uint32_t wstep_b = 16u * a.CoutPad, istep_b = 16u * plane;
-        const int steps = a.CinPad >> 2;
-        uint32_t ws = 0, is = 0;
-#pragma unroll 1
-        for (int st = 0; st < steps; st += 2) {          // two k-steps per trip (CinPad is a multiple of 4: 16 / 32 on the path)
-            const int u_n = st + 1 < steps ? 2 : 1;
-            float wv_[2][MB], xv[2][NB];
+    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (int64_t)n * a.in_sn), 0, (int)(a.Cin * plane * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight[0], 0, (int)((uint32_t)a.CinPad * a.CoutPad * 4u), 0x00020000);
+    const uint32_t wv = (uint32_t)(kslot * a.CoutPad + l16) * 4u;
+    const uint32_t wstep_b = 16u * a.CoutPad, istep_b = 16u * plane;
+    const int steps = a.CinPad >> 2;
+    // four k-steps: loads, then (later) their MFMAs -- the loads of the first group and of the first patch half are issued
+    // back to back, so a workgroup pays two memory round trips before its epilogue instead of five
+    float gw[4][MB], gx[4][NB];
+    auto gemm_load = [&](int st0) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) wv_[u][mb] = u < u_n ? bload(wr, wv + mb * 64, ws + u * wstep_b) : 0.0f;
+            for (int mb = 0; mb < MB; ++mb) gw[u][mb] = bload(wr, wv + mb * 64, (uint32_t)(st0 + u) * wstep_b);   // beyond CinPad: 0
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) xv[u][nb] = u < u_n ? bload(ir, iv[nb], is + u * istep_b) : 0.0f;
+            for (int nb = 0; nb < NB; ++nb) gx[u][nb] = bload(ir, iv[nb], (uint32_t)(st0 + u) * istep_b);        // beyond Cin: 0
+        }
+    };
+    auto gemm_mfma = [&](int st0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (st0 + u < steps) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gx[u][nb], gw[u][mb], acc[mb][nb], 0, 0, 0);
             }
+    };
+
+    // ---- the coarse patch: wave w takes channels w + 4u (u = 0..11) in two halves; lanes 0..33 hold one patch row per load ----
+    const uint32_t cplane_b = (uint32_t)(Hc * Wc) * 4u;
+    const __amdgpu_buffer_rsrc_t rc = epi_rsrc(a.add + (int64_t)n * a.add_sn, (uint32_t)a.Cout * cplane_b);
+    uint32_t pvoff, rowoff[kLatPH];
+    {
+        const int cy0 = ty * (kLatTH / 2) - 1, cx0 = tx * (kLatTW / 2) - 1;
+        int cx = cx0 + lane;
+        cx = cx < 0 ? 0 : (cx > Wc - 1 ? Wc - 1 : cx);
+        pvoff = lane < kLatPW ? (uint32_t)cx * 4u : kOob;
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (u < u_n) {
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][nb], wv_[u][mb], acc[mb][nb], 0, 0, 0);
-                }
-            ws += 2 * wstep_b;
-            is += 2 * istep_b;
+        for (int i = 0; i < kLatPH; ++i) {
+            int cy = cy0 + i;
+            cy = cy < 0 ? 0 : (cy > Hc - 1 ? Hc - 1 : cy);
+            rowoff[i] = (uint32_t)(cy * Wc) * 4u;
         }
     }
+    constexpr int kHalf = MB * 2;                      // channels per wave and half (MB * 16 / 4 waves / 2)
+    float pv_[kHalf][kLatPH];
+    auto patch_load = [&](int half) {
+#pragma unroll
+        for (int u = 0; u < kHalf; ++u)
+#pragma unroll
+            for (int i = 0; i < kLatPH; ++i)           // channels >= Cout lie beyond the descriptor: 0
+                pv_[u][i] = bload(rc, pvoff, (uint32_t)(wave + 4 * (half * kHalf + u)) * cplane_b + rowoff[i]);
+    };
+    auto patch_store = [&](int half) {
+        if (lane < kLatPW) {
+#pragma unroll
+            for (int u = 0; u < kHalf; ++u)
+#pragma unroll
+                for (int i = 0; i < kLatPH; ++i) patch[(wave + 4 * (half * kHalf + u)) * kLatCS + i * kLatRS + lane] = pv_[u][i];
+        }
+    };
+    gemm_load(0);
+    patch_load(0);
+    gemm_mfma(0);
+    for (int st0 = 4; st0 < steps; st0 += 4) {
+        gemm_load(st0);
+        gemm_mfma(st0);
+    }
+    patch_store(0);
+    patch_load(1);
+    patch_store(1);
     __syncthreads();                                      // the patch is complete
 
     // ---- epilogue: + x2 bilinear up-sampling of the patch (same arithmetic as conv_epilogue_act<0, 2>) ----

@@ -17,9 +17,13 @@ mkdir -p $T/old
 for f in corr.hip corr_common.hpp common.hpp; do git -C $R show $OLD:itermvs_amd/csrc/$f > $T/old/$f; done
 /opt/rocm/bin/hipcc $FLAGS -c $T/old/corr.hip -o $T/corr_old.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_old.o -o $V/libitermvs_old.so
-for w in 5 6 8; do
+for w in ${LB_VARIANTS:-}; do
   sed "s/__launch_bounds__(kThreads) corr_iter_kernel/__launch_bounds__(kThreads, $w) corr_iter_kernel/; s/__launch_bounds__(kThreads) corr_init_kernel/__launch_bounds__(kThreads, $w) corr_init_kernel/" $C/corr.hip > $T/corr_w$w.hip
   /opt/rocm/bin/hipcc $FLAGS -I$C -c $T/corr_w$w.hip -o $T/corr_w$w.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_w$w.o -o $V/libitermvs_w$w.so
 done
+# nopx4: today's conv_tile.hip with the four-pixels-per-lane epilogue switched off
+sed "s/a.px4 = p->out_layout == 0/a.px4 = false \&\& p->out_layout == 0/" $C/conv_tile.hip > $T/conv_tile_nopx4.hip
+/opt/rocm/bin/hipcc $FLAGS -I$C -c $T/conv_tile_nopx4.hip -o $T/conv_tile_nopx4.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/*.o | grep -v "/conv_tile.o") $T/conv_tile_nopx4.o -o $V/libitermvs_nopx4.so
 ls -la $V

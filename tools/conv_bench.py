@@ -13,6 +13,11 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from itermvs_amd import _lib  # noqa: E402
+if "--lib" in sys.argv:     # A/B between library builds (tools only): must be set before the first load
+    _i = sys.argv.index("--lib")
+    _lib.LIB_PATH = os.path.abspath(sys.argv[_i + 1])
+    del sys.argv[_i:_i + 2]
 from itermvs_amd import ops  # noqa: E402
 
 # name, N, Cin, Cout, H, W (input), k, stride, dil, launches per depth map
@@ -76,6 +81,7 @@ def main():
     dev = torch.device("cuda")
     gen = torch.Generator().manual_seed(0)
     total = 0.0
+    print("library:", _lib.LIB_PATH)
     for name, n, cin, cout, h, w, k, stride, dil, count in LAYERS:
         if only not in name:
             continue
