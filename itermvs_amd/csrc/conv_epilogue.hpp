@@ -284,77 +284,4 @@ __device__ __forceinline__ void conv_epilogue(const EpilogueArgs& e, const f32x4
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// "Four pixels per lane" form (conv_tile.hip, PX4): the MFMA operand roles are swapped (pixels = A / rows, weights = B /
-// columns), so a lane's accumulator holds FOUR CONSECUTIVE PIXELS (4*q + r) of ONE output channel (l16) instead of four
-// channels of one pixel.  In the NCHW planes those are 16 contiguous bytes: every residual / gate operand is one
-// dwordx4 load and every result one dwordx4 store -- a quarter of the vector-memory instructions of the form above (a
-// wave-level load or store costs the CU about the same whatever its width).  The k-ordered sums are identical.
-// Requirements (checked on the host): planar fp32 output, Wout % 4 == 0, 16-byte aligned tensors, no dot / NHWC epilogue.
-// ---------------------------------------------------------------------------------------------
-template <int MB, int NB>
-__device__ __forceinline__ void conv_bias_init_px4(f32x4 (&acc)[MB][NB], const float* bias, int Cout, int m0, int l16) {
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int co = m0 + mb * 16 + l16;
-        const float bs = (bias && co < Cout) ? bias[co] : 0.0f;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{bs, bs, bs, bs};
-    }
-}
-
-// pix[nb]: element index inside a channel plane of this lane's first pixel of slot nb, or -1 (slot outside the image)
-template <int ACT, int ADD, int MB, int NB>
-__device__ __forceinline__ void conv_epilogue_px4_act(const EpilogueArgs& e, const f32x4 (&acc)[MB][NB], int m0, int l16,
-                                                      const int (&pix)[NB]) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        if (pix[nb] < 0) continue;
-        f32x4 ad[MB], a1[MB], a2[MB];
-        int64_t off[MB];
-        bool ok[MB];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {                 // the optional operands of the whole slot first (see the header note on vmcnt)
-            const int co = m0 + mb * 16 + l16;
-            ok[mb] = co < e.Cout;
-            off[mb] = (int64_t)co * e.P + pix[nb];
-            ad[mb] = a1[mb] = a2[mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (ok[mb]) {
-                if constexpr (ADD == 1) ad[mb] = *reinterpret_cast<const f32x4*>(e.add + off[mb]);
-                if constexpr (ACT == 4 || ACT == 5) a1[mb] = *reinterpret_cast<const f32x4*>(e.aux1 + off[mb]);
-                if constexpr (ACT == 5) a2[mb] = *reinterpret_cast<const f32x4*>(e.aux2 + off[mb]);
-            }
-        }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            if (!ok[mb]) continue;
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float x = ADD != 0 ? acc[mb][nb][r] + ad[mb][r] : acc[mb][nb][r];
-                v[r] = conv_activation<ACT>(x, a1[mb][r], a2[mb][r]);
-            }
-            *reinterpret_cast<f32x4*>(e.out + off[mb]) = v;
-            if (e.out2) *reinterpret_cast<f32x4*>(e.out2 + off[mb]) = v;
-        }
-    }
-}
-
-template <int MB, int NB>
-__device__ __forceinline__ void conv_epilogue_px4(const EpilogueArgs& e, const f32x4 (&acc)[MB][NB], int m0, int l16,
-                                                  const int (&pix)[NB]) {
-    const int key = e.act * 3 + (e.add ? 1 : 0);
-    switch (key) {
-        case 0: conv_epilogue_px4_act<0, 0, MB, NB>(e, acc, m0, l16, pix); break;
-        case 1: conv_epilogue_px4_act<0, 1, MB, NB>(e, acc, m0, l16, pix); break;
-        case 3: conv_epilogue_px4_act<1, 0, MB, NB>(e, acc, m0, l16, pix); break;
-        case 4: conv_epilogue_px4_act<1, 1, MB, NB>(e, acc, m0, l16, pix); break;
-        case 6: conv_epilogue_px4_act<2, 0, MB, NB>(e, acc, m0, l16, pix); break;
-        case 9: conv_epilogue_px4_act<3, 0, MB, NB>(e, acc, m0, l16, pix); break;
-        case 12: conv_epilogue_px4_act<4, 0, MB, NB>(e, acc, m0, l16, pix); break;
-        case 15: conv_epilogue_px4_act<5, 0, MB, NB>(e, acc, m0, l16, pix); break;
-        default: break;   // other combinations never select the PX4 form (itermvs_conv2d_tile)
-    }
-}
-
 }  // namespace itermvs

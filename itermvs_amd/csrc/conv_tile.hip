@@ -47,7 +47,6 @@ struct TileArgs {
     int64_t out_b_sn;
     int split, act_b;
     int pad, act, add_mode, out_nhwc, nchunk, nstage, tiles_x, tiles_y, ncb, total;
-    int px4;                  // accumulators hold four pixels of one channel per lane (conv_epilogue_px4)
     uint32_t rcp_tiles_x, rcp_tiles_y;   // floor(2^32 / d) + 1
 };
 
@@ -111,7 +110,7 @@ struct TileGeom {
     static_assert(NB % TWT == 0 || TWT % NB == 0, "a wave's segments must form whole rows or a row part");
 };
 
-template <int MB, int S, int STRIDE, int DIL, int TH, int TWT, int CPS, int PX4>
+template <int MB, int S, int STRIDE, int DIL, int TH, int TWT, int CPS>
 __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
     using G = TileGeom<S, STRIDE, DIL, TH, TWT>;
     constexpr int NB = G::NB;
@@ -249,8 +248,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
     while (true) {
         const int seg = (cur.n >= a.seg_end[0]) + (cur.n >= a.seg_end[1]);
         f32x4 acc[MB][NB];
-        if constexpr (PX4) conv_bias_init_px4<MB, NB>(acc, a.bias[seg], a.Cout, m0, l16);
-        else conv_bias_init<MB, NB>(acc, a.bias[seg], a.Cout, m0, q);
+        conv_bias_init<MB, NB>(acc, a.bias[seg], a.Cout, m0, q);
         const int wn = w + gridDim.x;
         Work nxt = cur;
         for (int st = 0; st < a.nstage; ++st) {
@@ -306,11 +304,8 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            // PX4: pixels are the A operand (rows), weights the B operand -> D[pixel 4q + r][channel l16]
-                            if constexpr (PX4) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[u & 1][nb].v[s2], av[u & 1][mb].v[s2], acc[mb][nb], 0, 0, 0);
-                            else acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u & 1][mb].v[s2], bv[u & 1][nb].v[s2], acc[mb][nb], 0, 0, 0);
-                        }
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u & 1][mb].v[s2], bv[u & 1][nb].v[s2], acc[mb][nb], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -345,17 +340,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
                 e.Cout = a.split;
             }
         }
-        if constexpr (PX4) {
-            int pix4[NB];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int oy = cur.oy0 + row0 + nb / TWT, oxb = cur.ox0 + (col0 + nb % TWT) * 16 + q * 4;
-                pix4[nb] = oy < a.Hout && oxb < a.Wout ? oy * a.Wout + oxb : -1;      // Wout % 4 == 0: all four or none
-            }
-            conv_epilogue_px4<MB, NB>(e, acc, me, l16, pix4);
-        } else {
-            conv_epilogue<MB, NB>(e, acc, me, q, pix_off, py, px);
-        }
+        conv_epilogue<MB, NB>(e, acc, me, q, pix_off, py, px);
         TILE_STAMP(4);
 #ifdef ITERMVS_TILE_TRACE
         ++trace_tile;
@@ -391,15 +376,13 @@ static int launch_tile(TileArgs& a, int mt, hipStream_t stream) {
     // are resident at once -- a persistent workgroup queued behind another would serialise its tile list
     static const int want = [] { const char* e = itermvs_tuning_env("ITERMVS_TILE_PERSIST"); const int v = e ? atoi(e) : 4; return v < 1 ? 4 : v; }();
     int fit = 1;
-    if ((a.px4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS, 1>, 256, lds)
-               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS, 0>, 256, lds)) != hipSuccess || fit < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS>, 256, lds) != hipSuccess || fit < 1)
         fit = 1;
     int gx = 256 * (want < fit ? want : fit) / a.ncb;
     if (gx > a.total) gx = a.total;
     if (gx < 1) gx = 1;
     const dim3 grid(gx, a.ncb);
-    if (a.px4) hipLaunchKernelGGL((conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS, 1>), grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS, 0>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS>), grid, dim3(256), lds, stream, a);
     return 0;
 }
 
@@ -587,13 +570,6 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
     a.Cout = p->Cout; a.CoutPad = (p->Cout + 15) / 16 * 16; a.Hout = hout; a.Wout = wout;
     a.pad = p->pad; a.act = p->act; a.add_mode = p->add_mode; a.out_nhwc = p->out_layout;
     a.split = p->split_cout; a.act_b = p->act_b; a.out_b = p->out_b; a.out_b_sn = p->out_b_sn;
-    // four-pixels-per-lane accumulators (dwordx4 epilogue): planar fp32 results whose rows and tensors allow 16-byte accesses
-    {
-        auto al16 = [](const void* ptr, int64_t sn) { return (((uintptr_t)ptr) & 15) == 0 && (sn & 3) == 0; };
-        a.px4 = p->out_layout == 0 && p->act != 6 && p->act != 7 && p->add_mode == 0 && (wout & 3) == 0 &&
-                al16(p->out, p->out_sn) && al16(p->out2, 0) && al16(p->add, p->add_sn) && al16(p->aux1, p->aux1_sn) &&
-                al16(p->aux2, p->aux2_sn) && al16(p->out_b, p->out_b_sn);
-    }
     const int S = p->Cin <= 4 ? 1 : p->Cin <= 8 ? 2 : 4;
     a.nchunk = (p->Cin + 4 * S - 1) / (4 * S);
     const int mt = a.CoutPad / 16;

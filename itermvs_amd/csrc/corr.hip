@@ -18,6 +18,11 @@
 
 namespace itermvs {
 
+#ifndef ITERMVS_CORR_TW
+#define ITERMVS_CORR_TW 8
+#endif
+constexpr int kIterTW = ITERMVS_CORR_TW;      // width of the iteration kernel's 32-pixel tile (a power of two, >= 4)
+
 // ---------------------------------------------------------------------------------------------
 // iteration branch
 // ---------------------------------------------------------------------------------------------
@@ -28,9 +33,15 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
     const int N = L.N;
     const int b = blockIdx.z;
     const int P = a.H * a.W;
-    const int tile = xcd_tile((P + TILE - 1) / TILE);
-    const int p0 = tile * TILE;
-    if (p0 >= P) return;          // padding blocks of the XCD-aligned grid (uniform per block)
+    // pixel tile = kIterTW x (TILE / kIterTW) pixels: a 2-D patch of the sample grid maps to a compact patch of every
+    // source map, so the rows its bilinear taps touch are shared by the vertically adjacent pixels of the SAME workgroup
+    // (vector-L1 hits) instead of being fetched again by whichever workgroup owns the next row strip
+    constexpr int TW = kIterTW, TH = TILE / kIterTW;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int tile = xcd_tile(tiles_x * tiles_y);
+    if (tile >= tiles_x * tiles_y) return;          // padding blocks of the XCD-aligned grid (uniform per block)
+    const int tile_ty = tile / tiles_x, tile_tx = tile - tile_ty * tiles_x;
+    const int x0 = tile_tx * TW, y0 = tile_ty * TH;
     const int per_px = N * K::LPT;
     const int items = TILE * per_px;
     const WarpGeom g = make_geom(a.W, a.H, L.W1, L.H1);
@@ -41,23 +52,17 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
 
     // index arithmetic without integer division on the common path (an unsigned division costs ~25 vector instructions,
     // and these gather kernels are bound by instruction issue): items per pixel is a power of two for the reference's
-    // hypothesis counts, and a tile of 32 consecutive pixels wraps at most one image row when W >= 32
+    // hypothesis counts, the tile width is a compile-time power of two
     const int px_shift = (per_px & (per_px - 1)) == 0 ? 31 - __clz(per_px) : -1;
-    const int tile_y0 = p0 / a.W, tile_x0 = p0 - tile_y0 * a.W;
 #pragma unroll 1
     for (int item = threadIdx.x; item < items; item += kThreads) {
         const int px = px_shift >= 0 ? item >> px_shift : item / per_px;
         const int rem = item - px * per_px;
         const int n = rem / K::LPT;
         const int j = rem - n * K::LPT;      // the LPT lanes of one (pixel, hypothesis) are adjacent lanes
-        const int p = p0 + px;
-        if (p >= P) continue;                // whole lane groups drop out together
-        int y = tile_y0, x = tile_x0 + px;
-        if (a.W >= TILE) {
-            if (x >= a.W) { x -= a.W; ++y; }
-        } else {
-            y = p / a.W; x = p - y * a.W;
-        }
+        const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
+        if (x >= a.W || y >= a.H) continue;  // whole lane groups drop out together
+        const int p = y * a.W + x;
 
         float d;
         if (L.depth) {
@@ -109,23 +114,23 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
     }
     __syncthreads();
     const int rows = N * ITERMVS_GROUPS;
-    if constexpr (TILE % 4 == 0) {
-        // 16-byte stores where the rows allow it (a wave-level store costs the CU about the same whatever its width:
-        // tools/ubench/tile_read.hip): P a multiple of 4 keeps every quad of a tile row inside one plane row and aligned
-        if ((P & 3) == 0 && ((uintptr_t)L.out & 15) == 0) {
-            for (int idx = threadIdx.x; idx < rows * (TILE / 4); idx += kThreads) {
-                const int row = idx / (TILE / 4), px = (idx - row * (TILE / 4)) * 4;
-                if (p0 + px < P) {
-                    const float* __restrict__ l = lds + row * LS + px;
-                    *reinterpret_cast<float4*>(L.out + ((size_t)b * rows + row) * P + p0 + px) = make_float4(l[0], l[1], l[2], l[3]);
-                }
+    // 16-byte stores where the rows allow it (a wave-level store costs the CU about the same whatever its width): W a
+    // multiple of 4 keeps every quad of a tile row inside one plane row and aligned
+    if ((a.W & 3) == 0 && ((uintptr_t)L.out & 15) == 0) {
+        for (int idx = threadIdx.x; idx < rows * (TILE / 4); idx += kThreads) {
+            const int row = idx / (TILE / 4), px = (idx - row * (TILE / 4)) * 4;
+            const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
+            if (x < a.W && y < a.H) {
+                const float* __restrict__ l = lds + row * LS + px;
+                *reinterpret_cast<float4*>(L.out + ((size_t)b * rows + row) * P + (size_t)y * a.W + x) = make_float4(l[0], l[1], l[2], l[3]);
             }
-            return;
         }
+        return;
     }
     for (int idx = threadIdx.x; idx < rows * TILE; idx += kThreads) {
         const int row = idx / TILE, px = idx - row * TILE;
-        if (p0 + px < P) L.out[((size_t)b * rows + row) * P + p0 + px] = lds[row * LS + px];
+        const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
+        if (x < a.W && y < a.H) L.out[((size_t)b * rows + row) * P + (size_t)y * a.W + x] = lds[row * LS + px];
     }
 }
 
@@ -167,9 +172,12 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
     const int nb = min(a.NB, a.N - n0);
     const int b = blockIdx.z;
     const int P = a.H * a.W;
-    const int tile = xcd_tile((P + TILE - 1) / TILE);
-    const int p0 = tile * TILE;
-    if (p0 >= P) return;
+    constexpr int TW = kIterTW, TH = TILE / kIterTW;       // 2-D pixel tile (see corr_iter_level)
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int tile = xcd_tile(tiles_x * tiles_y);
+    if (tile >= tiles_x * tiles_y) return;
+    const int tile_ty = tile / tiles_x, tile_tx = tile - tile_ty * tiles_x;
+    const int x0 = tile_tx * TW, y0 = tile_ty * TH;
     const int ngrp = (nb + K::LPT - 1) / K::LPT;   // groups of LPT hypotheses
     const int per_px = ngrp * K::LPT;
     const int items = TILE * per_px;
@@ -180,25 +188,16 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
     const float* fsrc = feat_base<FT>(a.src[s], (int64_t)b * a.sb);
     const uint32_t sy = (uint32_t)a.sy * feat_bytes<FT>(), sx = (uint32_t)a.sx * feat_bytes<FT>();   // byte strides (chunk_corr)
 
-    // index arithmetic without integer division on the common path (an unsigned division costs ~25 vector instructions,
-    // and these gather kernels are bound by instruction issue): items per pixel is a power of two for the reference's
-    // hypothesis counts, and a tile of 32 consecutive pixels wraps at most one image row when W >= 32
-    const int px_shift = (per_px & (per_px - 1)) == 0 ? 31 - __clz(per_px) : -1;
-    const int tile_y0 = p0 / a.W, tile_x0 = p0 - tile_y0 * a.W;
+    const int px_shift = (per_px & (per_px - 1)) == 0 ? 31 - __clz(per_px) : -1;      // (no integer division on the common path)
 #pragma unroll 1
     for (int item = threadIdx.x; item < items; item += kThreads) {
         const int px = px_shift >= 0 ? item >> px_shift : item / per_px;
         const int rem = item - px * per_px;
         const int grp = rem / K::LPT;
         const int j = rem - grp * K::LPT;
-        const int p = p0 + px;
-        if (p >= P) continue;
-        int y = tile_y0, x = tile_x0 + px;
-        if (a.W >= TILE) {
-            if (x >= a.W) { x -= a.W; ++y; }
-        } else {
-            y = p / a.W; x = p - y * a.W;
-        }
+        const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
+        if (x >= a.W || y >= a.H) continue;
+        const int p = y * a.W + x;
         float refv[K::VEC];
         if (a.ref.sc == 1) {       // channels-last reference (the engine's layout): the chunk is VEC/4 vector loads off one address
             load_feat<K::VEC, FT>(feat_base<FT>((const float*)a.ref.data, (int64_t)b * a.ref.sb),
@@ -243,21 +242,21 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
     __syncthreads();
     const int rows = nb * ITERMVS_GROUPS;
     float* o = a.out + (((size_t)b * a.S + s) * a.N + n0) * ITERMVS_GROUPS * P;
-    if constexpr (TILE % 4 == 0) {
-        if ((P & 3) == 0 && ((uintptr_t)a.out & 15) == 0) {      // 16-byte stores (see corr_iter_level)
-            for (int idx = threadIdx.x; idx < rows * (TILE / 4); idx += kThreads) {
-                const int row = idx / (TILE / 4), px = (idx - row * (TILE / 4)) * 4;
-                if (p0 + px < P) {
-                    const float* __restrict__ l = lds + row * LS + px;
-                    *reinterpret_cast<float4*>(o + (size_t)row * P + p0 + px) = make_float4(l[0], l[1], l[2], l[3]);
-                }
+    if ((a.W & 3) == 0 && ((uintptr_t)a.out & 15) == 0) {      // 16-byte stores (see corr_iter_level)
+        for (int idx = threadIdx.x; idx < rows * (TILE / 4); idx += kThreads) {
+            const int row = idx / (TILE / 4), px = (idx - row * (TILE / 4)) * 4;
+            const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
+            if (x < a.W && y < a.H) {
+                const float* __restrict__ l = lds + row * LS + px;
+                *reinterpret_cast<float4*>(o + (size_t)row * P + (size_t)y * a.W + x) = make_float4(l[0], l[1], l[2], l[3]);
             }
-            return;
         }
+        return;
     }
     for (int idx = threadIdx.x; idx < rows * TILE; idx += kThreads) {
         const int row = idx / TILE, px = idx - row * TILE;
-        if (p0 + px < P) o[(size_t)row * P + p0 + px] = lds[row * LS + px];
+        const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
+        if (x < a.W && y < a.H) o[(size_t)row * P + (size_t)y * a.W + x] = lds[row * LS + px];
     }
 }
 
@@ -452,8 +451,8 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
     itermvs_profile_begin(1, (hipStream_t)stream);
     {
         constexpr int TILE = 32;
-        const int P = p->H * p->W;
-        const dim3 grid((((P + TILE - 1) / TILE + 7) / 8) * 8, 3, p->B);
+        const int tiles = ((p->W + kIterTW - 1) / kIterTW) * ((p->H + TILE / kIterTW - 1) / (TILE / kIterTW));
+        const dim3 grid(((tiles + 7) / 8) * 8, 3, p->B);
         switch (dtype) {
             case ITERMVS_F16: hipLaunchKernelGGL((corr_iter_kernel<TILE, ITERMVS_F16>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
             case ITERMVS_BF16: hipLaunchKernelGGL((corr_iter_kernel<TILE, ITERMVS_BF16>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
@@ -480,10 +479,10 @@ extern "C" int itermvs_corr_init(const itermvs_corr_init_params* p, void* stream
     a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.N = p->N;
     a.C = p->src.C; a.H1 = p->src.H; a.W1 = p->src.W; a.NB = kInitNB;
     constexpr int TILE = 32;
-    const int P = p->H * p->W;
     const int nblocks = (p->N + kInitNB - 1) / kInitNB;
     itermvs_profile_begin(2, (hipStream_t)stream);
-    const dim3 grid((((P + TILE - 1) / TILE + 7) / 8) * 8, p->S * nblocks, p->B);
+    const int tiles = ((p->W + kIterTW - 1) / kIterTW) * ((p->H + TILE / kIterTW - 1) / (TILE / kIterTW));
+    const dim3 grid(((tiles + 7) / 8) * 8, p->S * nblocks, p->B);
     ITERMVS_RETURN_IF(p->ref.dtype != p->src.dtype, ITERMVS_ERR_DTYPE);
     switch (p->src.dtype) {
         case ITERMVS_F16: hipLaunchKernelGGL((corr_init_kernel<TILE, ITERMVS_F16>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;

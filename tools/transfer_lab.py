@@ -9,6 +9,7 @@ for each, so the cost of each ingredient (H2D, D2H, cross-stream events, Python)
     h2d_only        + H2D (uint8 images, cameras, depth range) and the GPU pyramid kernel
     d2h_only        + D2H of depth and confidence
     full            both                                                               (= bench `with_transfers.uint8_images`)
+    full_pyr_cmp    like full, but the uint8 -> float pyramid kernel runs on the compute stream in front of the replay
     serial          everything on ONE stream, no events: H2D -> pyramid -> replay -> D2H
     full_packed     like full, but cameras + depth range travel as ONE pinned block and ONE copy
 """
@@ -57,7 +58,7 @@ def timed(step, n=200, warm=20):
     return (time.perf_counter() - t0) / n * 1e3, t_host / n * 1e3
 
 
-def make_three_stream(h2d: bool, d2h: bool):
+def make_three_stream(h2d: bool, d2h: bool, pyramid_on_compute: bool = False):
     ev_in = [torch.cuda.Event() for _ in range(2)]
     ev_done = [torch.cuda.Event() for _ in range(2)]
     ev_out = [torch.cuda.Event() for _ in range(2)]
@@ -72,7 +73,8 @@ def make_three_stream(h2d: bool, d2h: bool):
                 s_in.wait_event(ev_done[k])
             if h2d:
                 raw_dev[k].copy_(h_img, non_blocking=True)
-                ops.image_pyramid(raw_dev[k], H, W, all_levels=False, out0=r.imgs[0])
+                if not pyramid_on_compute:
+                    ops.image_pyramid(raw_dev[k], H, W, all_levels=False, out0=r.imgs[0])
                 r.proj_stack.copy_(h_proj, non_blocking=True)
                 r.depth_min.copy_(h_min, non_blocking=True)
                 r.depth_max.copy_(h_max, non_blocking=True)
@@ -81,6 +83,8 @@ def make_three_stream(h2d: bool, d2h: bool):
             s_cmp.wait_event(ev_in[k])
             if started[k]:
                 s_cmp.wait_event(ev_out[k])
+            if h2d and pyramid_on_compute:      # only SDMA copies run beside the graph; the normalise / resize kernel is in line
+                ops.image_pyramid(raw_dev[k], H, W, all_levels=False, out0=r.imgs[0])
             r(r.imgs, r.projs, r.depth_min, r.depth_max)
             ev_done[k].record(s_cmp)
         with torch.cuda.stream(s_out):
@@ -115,7 +119,8 @@ def serial(i):
 
 
 rows = [("resident", resident), ("events_only", make_three_stream(False, False)), ("h2d_only", make_three_stream(True, False)),
-        ("d2h_only", make_three_stream(False, True)), ("full", make_three_stream(True, True)), ("serial", serial)]
+        ("d2h_only", make_three_stream(False, True)), ("full", make_three_stream(True, True)),
+        ("full_pyr_cmp", make_three_stream(True, True, True)), ("serial", serial), ("resident", resident), ("full", make_three_stream(True, True))]
 print(f"{'choreography':<14} {'ms/map':>8} {'host ms/step':>13} {'maps/s':>8}")
 for name, fn in rows:
     ms, host = timed(fn)
