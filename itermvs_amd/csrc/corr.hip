@@ -18,10 +18,14 @@
 
 namespace itermvs {
 
+// Pixel tile of the two fused correlation kernels: 16 x 2 pixels.  Measured on MI355X at cfg 1 (profiles/r03, tools/
+// kernel_bench.py; -DITERMVS_CORR_TW=<8|16|32> builds the other shapes): 8 x 4 / 16 x 2 / 32 x 1 tiles run the iteration
+// kernel in 24.3 / 24.1 / 23.9 us on a noise depth map and 21.9 / 21.5 / 21.7 us on a smooth one, the initialisation
+// kernel in 24.6 / 23.4 / 25.3 us -- the tile shape is NOT what bounds them (vector-L1 hits were already 85 %).
 #ifndef ITERMVS_CORR_TW
-#define ITERMVS_CORR_TW 8
+#define ITERMVS_CORR_TW 16
 #endif
-constexpr int kIterTW = ITERMVS_CORR_TW;      // width of the iteration kernel's 32-pixel tile (a power of two, >= 4)
+constexpr int kIterTW = ITERMVS_CORR_TW;      // a power of two, >= 4, dividing 32
 
 // ---------------------------------------------------------------------------------------------
 // iteration branch
