@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B builds of libitermvs_hip.so for tools/kernel_bench.py --lib (this container; the .so files travel to the GPU box with
 # the snapshot, tools/ubench/variants/ is git-ignored):
-#   tw16 / tw32   the fused correlation kernels with other pixel-tile shapes
+#   tw8 / tw32   the fused correlation kernels with other pixel-tile shapes
 #   LB_VARIANTS="5 6" adds corr.hip with __launch_bounds__(256, N) on the two fused correlation kernels
 set -e
 R=$(cd $(dirname $0)/.. && pwd)
@@ -17,8 +17,8 @@ for w in ${LB_VARIANTS:-}; do
   /opt/rocm/bin/hipcc $FLAGS -I$C -c $T/corr_w$w.hip -o $T/corr_w$w.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_w$w.o -o $V/libitermvs_w$w.so
 done
-# tw16 / tw32: the fused correlation kernels with 16 x 2 / 32 x 1 pixel tiles (default: 8 x 4)
-for tw in ${TW_VARIANTS:-16 32}; do
+# tw8 / tw32: the fused correlation kernels with 8 x 4 / 32 x 1 pixel tiles (default: 16 x 2)
+for tw in ${TW_VARIANTS:-8 32}; do
   /opt/rocm/bin/hipcc $FLAGS -DITERMVS_CORR_TW=$tw -I$C -c $C/corr.hip -o $T/corr_tw$tw.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_tw$tw.o -o $V/libitermvs_tw$tw.so
 done
