@@ -26,12 +26,6 @@ namespace itermvs {
 #define ITERMVS_CORR_TW 16
 #endif
 constexpr int kIterTW = ITERMVS_CORR_TW;      // a power of two, >= 4, dividing 32
-#ifndef ITERMVS_INIT_PAIR
-#define ITERMVS_INIT_PAIR 1                   // initialisation kernel: two hypotheses of a quad in flight
-#endif
-#ifndef ITERMVS_IPT_MASK
-#define ITERMVS_IPT_MASK 3                    // two items per lane in flight on the C=16 (bit 0) and C=32 (bit 1) levels
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // iteration branch
@@ -64,91 +58,63 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
     // and these gather kernels are bound by instruction issue): items per pixel is a power of two for the reference's
     // hypothesis counts, the tile width is a compile-time power of two
     const int px_shift = (per_px & (per_px - 1)) == 0 ? 31 - __clz(per_px) : -1;
-    // IPT independent items per lane and trip (C=16 / C=32: the two trips of a 32-pixel x 4-hypothesis tile become one):
-    // their tap loads are issued together, so the dependent round trips (loads -> wait -> blend, per view) halve.
-    // C=48 has one item per lane anyway (2 hypotheses) and 12 loads per view in flight.
-    constexpr int IPT = (CPG == 2 && (ITERMVS_IPT_MASK & 1)) || (CPG == 4 && (ITERMVS_IPT_MASK & 2)) ? 2 : 1;
-    const int j = threadIdx.x & 3;           // the 4 lanes of one (pixel, hypothesis) are one quad
-    const uint32_t joff = (uint32_t)(j * 4) * feat_bytes<FT>();
 #pragma unroll 1
-    for (int item0 = threadIdx.x; item0 < items; item0 += kThreads * IPT) {
-        int px[IPT], n[IPT], p[IPT];
-        bool live[IPT];
-        float d[IPT], xs[IPT], ys[IPT], refv[IPT][K::VEC], acc[IPT][K::NG], wsum[IPT];
-#pragma unroll
-        for (int t = 0; t < IPT; ++t) {
-            const int item = item0 + t * kThreads;
-            const bool in_range = item < items;
-            const int it = in_range ? item : item0;      // a lane without a second item repeats its first and writes nothing
-            px[t] = px_shift >= 0 ? it >> px_shift : it / per_px;
-            n[t] = (it - px[t] * per_px) / K::LPT;
-            const int x = x0 + (px[t] & (TW - 1)), y = y0 + px[t] / TW;
-            live[t] = in_range && x < a.W && y < a.H;    // whole quads together
-            const int xc = min(x, a.W - 1), yc = min(y, a.H - 1);   // pixels beyond the image: computed on the border, not written
-            p[t] = yc * a.W + xc;
-            if (L.depth) {
-                d[t] = L.depth[((size_t)b * N + n[t]) * P + p[t]];
-            } else {  // itermvs.py:291-293
-                float ns = a.nd[b * a.nd_sb + p[t]] + L.offs[n[t]];
-                ns = fminf(fmaxf(ns, 0.0f), 1.0f);
-                d[t] = unnormalize_depth(ns, inv_min, inv_max);
-            }
-            load_vec<K::VEC>(a.ref_q + ((size_t)b * P + p[t]) * a.CQ + L.coff + j * 4, refv[t]);
-            xs[t] = (float)xc * g.xr;
-            ys[t] = (float)yc * g.yr;
-#pragma unroll
-            for (int q = 0; q < K::NG; ++q) acc[t][q] = 0.0f;
-            wsum[t] = 1e-5f;  // itermvs.py:88
+    for (int item = threadIdx.x; item < items; item += kThreads) {
+        const int px = px_shift >= 0 ? item >> px_shift : item / per_px;
+        const int rem = item - px * per_px;
+        const int n = rem / K::LPT;
+        const int j = rem - n * K::LPT;      // the LPT lanes of one (pixel, hypothesis) are adjacent lanes
+        const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
+        if (x >= a.W || y >= a.H) continue;  // whole lane groups drop out together
+        const int p = y * a.W + x;
+
+        float d;
+        if (L.depth) {
+            d = L.depth[((size_t)b * N + n) * P + p];
+        } else {  // itermvs.py:291-293
+            float ns = a.nd[b * a.nd_sb + p] + L.offs[n];
+            ns = fminf(fmaxf(ns, 0.0f), 1.0f);
+            d = unnormalize_depth(ns, inv_min, inv_max);
         }
+        float refv[K::VEC];
+        load_vec<K::VEC>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff + j * 4, refv);
+
+        const float xs = (float)x * g.xr, ys = (float)y * g.yr;
+        float acc[K::NG];
+#pragma unroll
+        for (int q = 0; q < K::NG; ++q) acc[q] = 0.0f;
+        float wsum = 1e-5f;  // itermvs.py:88
+        const uint32_t joff = (uint32_t)(j * 4) * feat_bytes<FT>();
         // The projection, the bilinear footprint and the view weight of (pixel, hypothesis) in view s are the same for the
         // four chunk lanes: lane j evaluates them for view s0 + j, then the quad walks the batch of views and every lane
         // takes view s0 + k's from lane k with DPP quad_perm moves.
         for (int s0 = 0; s0 < a.S; s0 += 4) {
-            Footprint mine[IPT];
-            float w_mine[IPT];
-#pragma unroll
-            for (int t = 0; t < IPT; ++t) {
-                mine[t] = Footprint{0u, 0u, 0u, 0u, 0.0f, 0.0f, 0.0f, 0.0f};
-                w_mine[t] = 0.0f;
-            }
+            Footprint mine = {0u, 0u, 0u, 0u, 0.0f, 0.0f, 0.0f, 0.0f};
+            float w_mine = 0.0f;
             if (s0 + j < a.S) {
                 const float* m = proj + (s0 + j) * 12;
-#pragma unroll
-                for (int t = 0; t < IPT; ++t) {
-                    float rx, ry, rz, ix, iy;
-                    ray_dir(m, xs[t], ys[t], rx, ry, rz);
-                    project_fast(g, rc, m, rx, ry, rz, d[t], ix, iy);
-                    mine[t] = make_footprint(ix, iy, L.W1, L.H1, sy, sx);
-                    w_mine[t] = a.view_w[((size_t)b * a.S + s0 + j) * P + p[t]];
-                }
+                float rx, ry, rz, ix, iy;
+                ray_dir(m, xs, ys, rx, ry, rz);
+                project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
+                mine = make_footprint(ix, iy, L.W1, L.H1, sy, sx);
+                w_mine = a.view_w[((size_t)b * a.S + s0 + j) * P + p];
             }
             const int nb = min(4, a.S - s0);          // wave-uniform
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (k < nb) {
-                    Footprint tp[IPT];
-                    float wv[IPT], corr[IPT][K::NG];
+                    const Footprint tp = quad_footprint(mine, k);
+                    const float wv = quad_bcast(w_mine, k);
+                    float corr[K::NG];
+                    chunk_corr<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), joff, tp, refv, corr);
 #pragma unroll
-                    for (int t = 0; t < IPT; ++t) {
-                        tp[t] = quad_footprint(mine[t], k);
-                        wv[t] = quad_bcast(w_mine[t], k);
-                    }
-                    chunk_corr_n<CPG, FT, IPT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), joff, tp, refv, corr);
-#pragma unroll
-                    for (int t = 0; t < IPT; ++t) {
-#pragma unroll
-                        for (int q = 0; q < K::NG; ++q) acc[t][q] = acc[t][q] + corr[t][q] * wv[t];  // itermvs.py:115
-                        wsum[t] = wsum[t] + wv[t];                                                    // itermvs.py:116
-                    }
+                    for (int q = 0; q < K::NG; ++q) acc[q] = acc[q] + corr[q] * wv;  // itermvs.py:115
+                    wsum = wsum + wv;                                                // itermvs.py:116
                 }
             }
         }
 #pragma unroll
-        for (int t = 0; t < IPT; ++t)
-            if (live[t]) {
-#pragma unroll
-                for (int q = 0; q < K::NG; ++q) lds[(n[t] * ITERMVS_GROUPS + K::group(j, q)) * LS + px[t]] = acc[t][q] / wsum[t];
-            }
+        for (int q = 0; q < K::NG; ++q) lds[(n * ITERMVS_GROUPS + K::group(j, q)) * LS + px] = acc[q] / wsum;
     }
     __syncthreads();
     const int rows = N * ITERMVS_GROUPS;
@@ -265,28 +231,15 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
         }
         const uint32_t joff = (uint32_t)(j * 4) * feat_bytes<FT>();
         const int cnt = min(K::LPT, nb - grp * K::LPT);      // uniform per quad; whole quads take the branch together
-        // the quad's hypotheses two at a time (ITERMVS_INIT_PAIR): their tap loads are issued together, half the dependent
-        // memory round trips per item (a surplus second hypothesis repeats the first and is not written)
-        constexpr int HP = ITERMVS_INIT_PAIR ? 2 : 1;
 #pragma unroll
-        for (int k = 0; k < K::LPT; k += HP) {
+        for (int k = 0; k < K::LPT; ++k) {
             if (k < cnt) {
-                Footprint tp[HP];
-                float rv[HP][K::VEC], corr[HP][K::NG];
+                const Footprint tp = quad_footprint(mine, k);
+                float corr[K::NG];
+                chunk_corr<CPG, FT>(fsrc, joff, tp, refv, corr);
+                const int nl = grp * K::LPT + k;
 #pragma unroll
-                for (int t = 0; t < HP; ++t) {
-                    tp[t] = quad_footprint(mine, (t == 1 && k + 1 >= K::LPT) ? k : k + t);
-#pragma unroll
-                    for (int c = 0; c < K::VEC; ++c) rv[t][c] = refv[c];
-                }
-                chunk_corr_n<CPG, FT, HP>(fsrc, joff, tp, rv, corr);
-#pragma unroll
-                for (int t = 0; t < HP; ++t)
-                    if (k + t < cnt) {
-                        const int nl = grp * K::LPT + k + t;
-#pragma unroll
-                        for (int q = 0; q < K::NG; ++q) lds[(nl * ITERMVS_GROUPS + K::group(j, q)) * LS + px] = corr[t][q];
-                    }
+                for (int q = 0; q < K::NG; ++q) lds[(nl * ITERMVS_GROUPS + K::group(j, q)) * LS + px] = corr[q];
             }
         }
     }

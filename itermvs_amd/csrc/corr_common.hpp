@@ -213,94 +213,66 @@ __device__ __forceinline__ void blend_corr(const TapData<Chunk<CPG>::VEC>& t, co
     }
 }
 
-// One view's contribution for one lane, for IPT independent items (pixel, hypothesis) at once: the chunk is walked one
-// 16-channel block at a time -- the 4 tap loads (one float4 each) of ALL items first, then their blends and products with
-// the reference block -- so 16 tap registers per item are live at once and the loads of the items overlap: the kernels are
-// bound by dependent memory round trips (loads -> wait -> blend, per view), and two items in flight per lane halve them.
-// Arithmetic and summation order per item are fixed (bit-identical for every IPT).
-// `fb`: wave-uniform base of the view's map; the footprints' row / column offsets and `joff` are in BYTES (make_footprint
+// One view's contribution for one lane: the chunk is walked one 16-channel block at a time (4 tap loads of one float4 each,
+// blend, products with the reference block) so that only 16 tap registers are live at once -- with all 12 loads of a C=48
+// chunk in flight the kernel needed 114 VGPRs (4 waves per SIMD); block by block it fits 64 (8 waves), and the memory-level
+// parallelism comes from the doubled occupancy instead.  Arithmetic and summation order are those of blend_corr.
+// `fb`: wave-uniform base of the view's map; the footprint's row / column offsets and `joff` are in BYTES (make_footprint
 // was given byte strides), so a tap address is a 32-bit add and the 16-channel blocks ride in the instruction's immediate.
-template <int CPG, int FT, int IPT>
-__device__ __forceinline__ void chunk_corr_n(const float* __restrict__ fbase, uint32_t joff, const Footprint (&tp)[IPT],
-                                             const float (&refv)[IPT][Chunk<CPG>::VEC], float (&corr)[IPT][Chunk<CPG>::NG]) {
-    constexpr int NBLK = Chunk<CPG>::VEC / 4;
-    constexpr uint32_t BLK = 16u * feat_bytes<FT>();      // bytes between the lane's 16-channel blocks
-    const char* __restrict__ fb = reinterpret_cast<const char*>(fbase);
-    uint32_t o00[IPT], o01[IPT], o10[IPT], o11[IPT];
-#pragma unroll
-    for (int t = 0; t < IPT; ++t) {
-        o00[t] = tp[t].r0 + tp[t].c0 + joff; o01[t] = tp[t].r0 + tp[t].c1 + joff;
-        o10[t] = tp[t].r1 + tp[t].c0 + joff; o11[t] = tp[t].r1 + tp[t].c1 + joff;
-    }
-    float lo[IPT][NBLK], hi[IPT][NBLK];
-#pragma unroll
-    for (int i = 0; i < NBLK; ++i) {
-        float v00[IPT][4], v01[IPT][4], v10[IPT][4], v11[IPT][4];
-#pragma unroll
-        for (int t = 0; t < IPT; ++t) {
-            load4_at<FT>(fb, o00[t] + BLK * i, v00[t]);
-            load4_at<FT>(fb, o01[t] + BLK * i, v01[t]);
-            load4_at<FT>(fb, o10[t] + BLK * i, v10[t]);
-            load4_at<FT>(fb, o11[t] + BLK * i, v11[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < IPT; ++t) {
-            float w[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                w[c] = fmaf(tp[t].se, v11[t][c], fmaf(tp[t].sw, v10[t][c], fmaf(tp[t].ne, v01[t][c], tp[t].nw * v00[t][c])));
-            const float* r = refv[t] + 4 * i;
-            if constexpr (CPG == 4) {   // one 4-channel group per block: a single fma chain (itermvs.py:103-104 order)
-                lo[t][i] = fmaf(w[3], r[3], fmaf(w[2], r[2], fmaf(w[1], r[1], w[0] * r[0])));
-                hi[t][i] = 0.0f;
-            } else {
-                lo[t][i] = fmaf(w[1], r[1], w[0] * r[0]);
-                hi[t][i] = fmaf(w[3], r[3], w[2] * r[2]);
-            }
-        }
-        if (i + 1 < NBLK) __builtin_amdgcn_sched_barrier(0);     // the next block's loads stay behind this block's blend
-    }
-#pragma unroll
-    for (int t = 0; t < IPT; ++t) {
-        if constexpr (CPG == 2) {
-            corr[t][0] = lo[t][0] * 0.5f;
-            corr[t][1] = hi[t][0] * 0.5f;
-        } else if constexpr (CPG == 4) {   // channels 4j..4j+3 = group j, 16+4j.. = group 4+j
-            corr[t][0] = lo[t][0] * 0.25f;
-            corr[t][1] = lo[t][1] * 0.25f;
-        } else {
-            // lane j (= lane & 3) holds channels 16i + 4j + k (i = 0..2, k = 0..3); group g = channels 6g .. 6g+5.
-            // lo_i / hi_i = products of the lower / upper channel pair of block i:
-            //   g0 = s0[j0] + lo0[j1]   g1 = hi0[j1] + s0[j2]      (s_i = lo_i + hi_i)
-            //   g2 = s0[j3] + lo1[j0]   g3 = hi1[j0] + s1[j1]
-            //   g4 = s1[j2] + lo1[j3]   g5 = hi1[j3] + s2[j0]
-            //   g6 = s2[j1] + lo2[j2]   g7 = hi2[j2] + s2[j3]
-            // lane d finalises groups 2d and 2d+1; each source lane selects what it owes and one quad_perm per term delivers it.
-            const float s0 = lo[t][0] + hi[t][0], s1 = lo[t][1] + hi[t][1], s2 = lo[t][2] + hi[t][2];
-            const int j = threadIdx.x & 3;
-            const float ta = (j == 0 || j == 3) ? s0 : (j == 2 ? s1 : s2);
-            const float tb = (j == 1) ? lo[t][0] : (j == 2 ? lo[t][2] : lo[t][1]);
-            const float tc = (j == 1) ? hi[t][0] : (j == 2 ? hi[t][2] : hi[t][1]);
-            const float tdd = (j == 2) ? s0 : (j == 1 ? s1 : s2);
-            const float g_first = quad_perm<ITERMVS_QP(0, 3, 2, 1)>(ta) + quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tb);
-            const float g_second = quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tc) + quad_perm<ITERMVS_QP(2, 1, 0, 3)>(tdd);
-            // mean over the 6 channels of the group (itermvs.py:103-104): three instructions instead of the ~10 of an IEEE division
-            corr[t][0] = div_rcp(g_first, 6.0f, 1.0f / 6.0f);
-            corr[t][1] = div_rcp(g_second, 6.0f, 1.0f / 6.0f);
-        }
-    }
-}
-
 template <int CPG, int FT>
 __device__ __forceinline__ void chunk_corr(const float* __restrict__ fbase, uint32_t joff, const Footprint& tp,
                                            const float (&refv)[Chunk<CPG>::VEC], float (&corr)[Chunk<CPG>::NG]) {
-    const Footprint tps[1] = {tp};
-    float rv[1][Chunk<CPG>::VEC], cr[1][Chunk<CPG>::NG];
+    constexpr int NBLK = Chunk<CPG>::VEC / 4;
+    constexpr uint32_t BLK = 16u * feat_bytes<FT>();      // bytes between the lane's 16-channel blocks
+    const char* __restrict__ fb = reinterpret_cast<const char*>(fbase);
+    const uint32_t o00 = tp.r0 + tp.c0 + joff, o01 = tp.r0 + tp.c1 + joff, o10 = tp.r1 + tp.c0 + joff, o11 = tp.r1 + tp.c1 + joff;
+    float lo[NBLK], hi[NBLK];
 #pragma unroll
-    for (int c = 0; c < Chunk<CPG>::VEC; ++c) rv[0][c] = refv[c];
-    chunk_corr_n<CPG, FT, 1>(fbase, joff, tps, rv, cr);
+    for (int i = 0; i < NBLK; ++i) {
+        float v00[4], v01[4], v10[4], v11[4], w[4];
+        load4_at<FT>(fb, o00 + BLK * i, v00);
+        load4_at<FT>(fb, o01 + BLK * i, v01);
+        load4_at<FT>(fb, o10 + BLK * i, v10);
+        load4_at<FT>(fb, o11 + BLK * i, v11);
 #pragma unroll
-    for (int q = 0; q < Chunk<CPG>::NG; ++q) corr[q] = cr[0][q];
+        for (int c = 0; c < 4; ++c)
+            w[c] = fmaf(tp.se, v11[c], fmaf(tp.sw, v10[c], fmaf(tp.ne, v01[c], tp.nw * v00[c])));
+        const float* r = refv + 4 * i;
+        if constexpr (CPG == 4) {   // one 4-channel group per block: a single fma chain (itermvs.py:103-104 order)
+            lo[i] = fmaf(w[3], r[3], fmaf(w[2], r[2], fmaf(w[1], r[1], w[0] * r[0])));
+            hi[i] = 0.0f;
+        } else {
+            lo[i] = fmaf(w[1], r[1], w[0] * r[0]);
+            hi[i] = fmaf(w[3], r[3], w[2] * r[2]);
+        }
+        if (i + 1 < NBLK) __builtin_amdgcn_sched_barrier(0);     // the next block's loads stay behind this block's blend
+    }
+    if constexpr (CPG == 2) {
+        corr[0] = lo[0] * 0.5f;
+        corr[1] = hi[0] * 0.5f;
+    } else if constexpr (CPG == 4) {   // channels 4j..4j+3 = group j, 16+4j.. = group 4+j
+        corr[0] = lo[0] * 0.25f;
+        corr[1] = lo[1] * 0.25f;
+    } else {
+        // lane j (= lane & 3) holds channels 16i + 4j + k (i = 0..2, k = 0..3); group g = channels 6g .. 6g+5.
+        // lo_i / hi_i = products of the lower / upper channel pair of block i:
+        //   g0 = s0[j0] + lo0[j1]   g1 = hi0[j1] + s0[j2]      (s_i = lo_i + hi_i)
+        //   g2 = s0[j3] + lo1[j0]   g3 = hi1[j0] + s1[j1]
+        //   g4 = s1[j2] + lo1[j3]   g5 = hi1[j3] + s2[j0]
+        //   g6 = s2[j1] + lo2[j2]   g7 = hi2[j2] + s2[j3]
+        // lane d finalises groups 2d and 2d+1; each source lane selects what it owes and one quad_perm per term delivers it.
+        const float s0 = lo[0] + hi[0], s1 = lo[1] + hi[1], s2 = lo[2] + hi[2];
+        const int j = threadIdx.x & 3;
+        const float ta = (j == 0 || j == 3) ? s0 : (j == 2 ? s1 : s2);
+        const float tb = (j == 1) ? lo[0] : (j == 2 ? lo[2] : lo[1]);
+        const float tc = (j == 1) ? hi[0] : (j == 2 ? hi[2] : hi[1]);
+        const float tdd = (j == 2) ? s0 : (j == 1 ? s1 : s2);
+        const float g_first = quad_perm<ITERMVS_QP(0, 3, 2, 1)>(ta) + quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tb);
+        const float g_second = quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tc) + quad_perm<ITERMVS_QP(2, 1, 0, 3)>(tdd);
+        // mean over the 6 channels of the group (itermvs.py:103-104): three instructions instead of the ~10 of an IEEE division
+        corr[0] = div_rcp(g_first, 6.0f, 1.0f / 6.0f);
+        corr[1] = div_rcp(g_second, 6.0f, 1.0f / 6.0f);
+    }
 }
 
 // XCD-aware tile order: block k is observed to run on XCD k % 8 (a speed assumption only), so give

@@ -17,13 +17,8 @@ for w in ${LB_VARIANTS:-}; do
   /opt/rocm/bin/hipcc $FLAGS -I$C -c $T/corr_w$w.hip -o $T/corr_w$w.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_w$w.o -o $V/libitermvs_w$w.so
 done
-# ipt0 / ipt1: one item per lane on every level / two only on the C=16 level (default mask 3: C=16 and C=32)
-for m in ${IPT_VARIANTS:-0 1}; do
-  /opt/rocm/bin/hipcc $FLAGS -DITERMVS_IPT_MASK=$m -I$C -c $C/corr.hip -o $T/corr_ipt$m.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_ipt$m.o -o $V/libitermvs_ipt$m.so
-done
 # tw8 / tw32: the fused correlation kernels with 8 x 4 / 32 x 1 pixel tiles (default: 16 x 2)
-for tw in ${TW_VARIANTS:-}; do
+for tw in ${TW_VARIANTS:-8 32}; do
   /opt/rocm/bin/hipcc $FLAGS -DITERMVS_CORR_TW=$tw -I$C -c $C/corr.hip -o $T/corr_tw$tw.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_tw$tw.o -o $V/libitermvs_tw$tw.so
 done
