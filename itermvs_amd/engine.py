@@ -58,13 +58,23 @@ def fold_batchnorm(w: Mapping[str, Tensor], prefix: str, eps: float = 1e-5) -> T
 class InferenceEngine:
     """Test-mode ``IterMVS.forward`` (itermvs.py:253-329) on hand-written HIP kernels."""
 
-    def __init__(self, weights: Mapping[str, Tensor], iteration: int, feature_dtype: str = "fp32"):
-        """``feature_dtype``: storage type of the three feature pyramids the correlation kernels gather from -- "fp32"
+    def __init__(self, weights: Mapping[str, Tensor], iteration: int, feature_dtype: str = "fp32", projection: str = "device_fp64"):
+        """``projection``: how ``src_proj @ inverse(ref_proj)`` (module.py:77-90) is composed.  "device_fp64" (default): on the
+        GPU in fp64, rounded once, inside the launch that packs the reference features -- no host round trip, within 5e-5
+        px of any fp32 evaluation.  "host_fp32": on the host with torch in fp32, operation for operation like the reference
+        (``torch.inverse`` per batch item, then ``torch.matmul``) -- for users who need tap indices identical to a
+        reference run on the same host; costs a device-to-host copy of the cameras and a synchronisation per forward, and
+        cannot be captured into a hipGraph.  (The reference itself has no single bit pattern here: its fp32 LAPACK inverse
+        differs between CPU BLAS builds and from its own CUDA path.)
+        ``feature_dtype``: storage type of the three feature pyramids the correlation kernels gather from -- "fp32"
         (default, the reference's numerics), "bf16" or "fp16" (BASELINE cfg 4 / cfg 5: half the gathered bytes, fp32
         arithmetic; the output convolutions of FeatureNet round their fp32 results to nearest even)."""
         if feature_dtype not in ops.FEATURE_DTYPES:
             raise ValueError(f"feature_dtype must be one of {sorted(ops.FEATURE_DTYPES)}, got {feature_dtype!r}")
         self.feature_dtype = ops.FEATURE_DTYPES[feature_dtype]
+        if projection not in ("device_fp64", "host_fp32"):
+            raise ValueError(f"projection must be 'device_fp64' or 'host_fp32', got {projection!r}")
+        self.projection = projection
         w = {k: v.detach() for k, v in weights.items()}
         dev = w["feature_net.conv1.conv.weight"].device
         if dev.type != "cuda":
@@ -313,8 +323,12 @@ class InferenceEngine:
         up_logits = self.upsample_logits(ref2_nchw, ws)                 # only needed by the final convex up-sampling
         # camera composition (+ inverse depth range) rides in the launch that packs the reference features
         pstack = projs if torch.is_tensor(projs) else torch.stack([projs[1], projs[2], projs[3]])
-        ref_q, proj, inv_min, inv_max = ops.ref_quarter_compose(ref[1], ref[2], ref[3], pstack.reshape(3 * b, v, 4, 4), self.nan_flag,
-                                                                (depth_min, depth_max))
+        if self.projection == "host_fp32":
+            proj, inv_min, inv_max = self.compose_on_host(pstack.reshape(3, b, v, 4, 4), depth_min, depth_max)
+            ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
+        else:
+            ref_q, proj, inv_min, inv_max = ops.ref_quarter_compose(ref[1], ref[2], ref[3], pstack.reshape(3 * b, v, 4, 4), self.nan_flag,
+                                                                    (depth_min, depth_max))
         proj = proj.view(3, b, s, 12)
 
         view_w = self.stage_init(ws, src[3], ref[3], proj[2], inv_min, inv_max, trace)          # itermvs.py:270-276
@@ -342,6 +356,23 @@ class InferenceEngine:
 
         # convex up-sampling of the depth and bilinear up-sampling of the confidence: one launch     itermvs.py:321-324
         return ops.final_upsample(up_logits, hx, inv_min, inv_max, conf, nd_channel=HIDDEN)
+
+    def compose_on_host(self, pstack: Tensor, depth_min: Tensor, depth_max: Tensor):
+        """module.py:77-90 on the host in fp32, operation for operation (``projection="host_fp32"``): pstack [3,B,V,4,4] ->
+        (proj [3,B,S,12], 1/depth_min, 1/depth_max) on the device.  Synchronises (the cameras come back from the GPU)."""
+        pm = pstack.detach().float().cpu()
+        levels = []
+        for l in range(3):
+            ref_p = pm[l, :, 0]                                                     # [B,4,4]
+            inv = torch.stack([torch.inverse(ref_p[i]) for i in range(ref_p.shape[0])])
+            views = [torch.matmul(pm[l, :, k], inv)[:, :3, :4].reshape(-1, 12) for k in range(1, pm.shape[2])]
+            levels.append(torch.stack(views, 1))
+        proj = torch.stack(levels)                                                  # [3,B,S,12]
+        if bool(torch.isnan(proj).any()):
+            self.nan_flag.fill_(1)                                                  # surfaces through check_projection_finite
+        dev = pstack.device
+        inv_min, inv_max = 1.0 / depth_min.detach().float().cpu(), 1.0 / depth_max.detach().float().cpu()      # itermvs.py:267-268
+        return proj.to(dev), inv_min.to(dev), inv_max.to(dev)
 
     def check_projection_finite(self) -> None:
         """Deferred form of the reference's NaN asserts (module.py:83,87) for every ``run`` / graph replay enqueued since

@@ -89,6 +89,9 @@ class Pipeline(nn.Module):
         # numerics), "bf16" / "fp16" (BASELINE cfg 4 / 5: half the gathered bytes, fp32 arithmetic, fp32 gradients); set before
         # the first forward (or call invalidate())
         self.feature_dtype = "fp32"
+        # "device_fp64" (default) or "host_fp32": see InferenceEngine -- the second reproduces the reference's fp32
+        # `src @ inverse(ref)` on the host (tap indices identical to a reference run on this host; eager mode only)
+        self.projection = "device_fp64"
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     # -- weights ----------------------------------------------------------------------------
@@ -147,10 +150,12 @@ class Pipeline(nn.Module):
             if self._engine is not None and self._engine_version != self._weights_version():
                 self.invalidate()                 # parameters were updated in place since the weights were packed
             if self._engine is None:
-                self._engine = InferenceEngine(self.weights(), self.iteration, self.feature_dtype)
+                self._engine = InferenceEngine(self.weights(), self.iteration, self.feature_dtype, self.projection)
                 self._engine_version = self._weights_version()
             with torch.no_grad():
                 if self.use_graphs:
+                    if self.projection != "device_fp64":
+                        raise RuntimeError("projection='host_fp32' reads the cameras back on the host: not capturable, use eager mode")
                     from .engine import GraphedRunner
                     key = (tuple(x.shape), x.device.index)
                     runner = self._runners.get(key)

@@ -358,3 +358,39 @@ def test_in_place_weight_updates_refresh_the_packed_engine():
         o2 = r2(imgs["level_0"], pj, dmin, dmax)
     torch.cuda.synchronize()
     assert torch.equal(o1[0], o2[0]) and torch.equal(o1[1], o2[1])
+
+
+def test_host_fp32_projection_mode_reproduces_the_reference_composition():
+    """``projection="host_fp32"``: the engine composes ``src @ inverse(ref)`` on the host in fp32 like module.py:77-90 --
+    bit for bit the pinned oracle's restatement of those lines on this host, so the kernels see the reference's own
+    matrices (tap indices identical to a reference run here); the default device composition stays within the tap-index
+    bounds of test_compose_proj_tap_indices.  Outputs of the two modes agree to the chaos floor; graph capture refuses
+    the mode (it reads the cameras back)."""
+    from itermvs_amd import synthetic
+    from oracle import itermvs_oracle as O
+    s = synthetic.make_sample(batch=2, num_views=4, height=64, width=96, seed=7)
+    imgs, pm, dmin, dmax = to_dev(s)
+    m_host = make_model("seed0", 2)
+    m_host.projection = "host_fp32"
+    m_dev = make_model("seed0", 2)
+    t_host, t_dev = {}, {}
+    projs = {l: pm[f"level_{l}"] for l in (1, 2, 3)}
+    from itermvs_amd.engine import InferenceEngine
+    e_host = InferenceEngine(m_host.weights(), 2, projection="host_fp32")
+    e_dev = InferenceEngine(m_dev.weights(), 2)
+    with torch.no_grad():
+        d_h, _ = e_host.run(imgs["level_0"], projs, dmin, dmax, trace=t_host)
+        d_d, _ = e_dev.run(imgs["level_0"], projs, dmin, dmax, trace=t_dev)
+    for i, l in enumerate((1, 2, 3)):
+        mats = s["proj_matrices"][f"level_{l}"].float()
+        for k in range(1, mats.shape[1]):
+            want = O.compose_projection(mats[:, k], mats[:, 0])[:, :3, :4].reshape(-1, 12)
+            assert torch.equal(t_host["proj"][i][:, k - 1].cpu(), want)                     # the reference's own numbers
+            assert maxdiff(t_dev["proj"][i][:, k - 1], want) <= 2e-5 * float(want.abs().max())
+    rel = ((d_h - d_d).abs() / d_d).cpu()
+    assert float(rel.median()) <= 1e-5 and float((rel > 1e-4).float().mean()) <= 0.02
+    out = m_host(imgs, pm, dmin, dmax)["depths_upsampled"]
+    assert torch.equal(out, d_h)
+    m_host.use_graphs = True
+    with pytest.raises(RuntimeError, match="host_fp32"):
+        m_host(imgs, pm, dmin, dmax)
