@@ -358,7 +358,8 @@ def main() -> None:
         if pmc_file:
             pmc = json.load(open(pmc_file))
             entry = next((v for k, v in pmc.get("kernels", {}).items() if k.startswith(kernel_name + "<") or k == kernel_name), None)
-            if entry and pmc.get("workload") == [args.views, args.height, args.width, args.batch] and "traffic_bytes_per_launch" in entry:
+            if (entry and pmc.get("workload") == [args.views, args.height, args.width, args.batch] and args.feature_dtype == "fp32"
+                    and "traffic_bytes_per_launch" in entry):
                 roofline["traffic"] = entry["traffic_bytes_per_launch"]
                 roofline["traffic_source"] = f"profiles/{os.path.basename(pmc_file)}: " + pmc["source"]
         if t_init:
