@@ -110,7 +110,7 @@ struct TileGeom {
     static_assert(NB % TWT == 0 || TWT % NB == 0, "a wave's segments must form whole rows or a row part");
 };
 
-template <int MB, int S, int STRIDE, int DIL, int TH, int TWT, int CPS, int DB>
+template <int MB, int S, int STRIDE, int DIL, int TH, int TWT, int CPS>
 __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
     using G = TileGeom<S, STRIDE, DIL, TH, TWT>;
     constexpr int NB = G::NB;
@@ -118,9 +118,8 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
     constexpr int WROW = 16 * MB * S;                // floats of one weight row (tap, chunk, q): [16*MB co][S]
     constexpr int WBLK = 4 * WROW;                   // floats per (chunk, tap)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int BUF_FLOATS = CPS * CH_FLOATS;                      // one staged tile: [CPS][4][PL]
-    float* __restrict__ tile = smem;                                 // DB: two tiles (the one the matrix cores read, the next one)
-    float* __restrict__ wlds = smem + (DB ? 2 : 1) * BUF_FLOATS;     // [nchunk][9][4][16*MB][S]
+    float* __restrict__ tile = smem;                                 // [CPS][4][PL]
+    float* __restrict__ wlds = smem + CPS * CH_FLOATS;               // [nchunk][9][4][16*MB][S]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l16 = lane & 15;
@@ -214,12 +213,10 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
     // the wave sits in the issue of its 24 loads for 2-5k cycles -- as long as the whole MFMA phase.)
     constexpr int kLoads = CPS * G::ITEMS * S;
     constexpr int kParts = 9 * CPS;
-    // DB: the loads are issued in the first kFetchParts taps, the LDS stores of the arrived values in the last kWriteParts
-    constexpr int kWriteParts = DB ? 3 : 0, kFetchParts = kParts - kWriteParts;
     auto fetch_part = [&](uint32_t soff, int part) {
 #pragma unroll
         for (int e = 0; e < kLoads; ++e)
-            if (e * kFetchParts / kLoads == part) {
+            if (e * kParts / kLoads == part) {
                 const int c = e / (G::ITEMS * S), j = (e / S) % G::ITEMS, s2 = e % S;
                 stage[c][j].v[s2] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(ir, goff[j], soff + c * chunk_b + s2 * plane * 4u, 0));
@@ -227,18 +224,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
     };
     auto fetch = [&](uint32_t soff) {
 #pragma unroll
-        for (int part = 0; part < kFetchParts; ++part) fetch_part(soff, part);
-    };
-    // staged registers -> LDS tile `dst`; part < 0: everything, else the part's share of the CPS * ITEMS vector stores
-    auto stage_to_lds = [&](float* __restrict__ dst, int part) {
-#pragma unroll
-        for (int c = 0; c < CPS; ++c)
-#pragma unroll
-            for (int j = 0; j < G::ITEMS; ++j) {
-                const int e = c * G::ITEMS + j;
-                if (part >= 0 && e * (kWriteParts > 0 ? kWriteParts : 1) / (CPS * G::ITEMS) != part) continue;
-                if (j < G::ITEMS - 1 || tid + j * 256 < 4 * G::IN_PX) lds_write<S>(dst + c * CH_FLOATS + loff[j], stage[c][j]);
-            }
+        for (int part = 0; part < kParts; ++part) fetch_part(soff, part);
     };
 
     // this wave's segments: id = wave * NB + nb -> (row, column block) of the output tile
@@ -259,16 +245,6 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
     Work cur = decode(w);
     setup(cur);
     fetch(0);
-    int par = 0;                                    // DB: which LDS tile the matrix cores read
-    if constexpr (DB) {
-        // Double-buffered LDS (layers whose workgroups walk several stages): the next stage's values go from the staging
-        // registers into the OTHER tile during the last taps of the current stage's MFMA loop, so a stage costs one barrier
-        // and no exposed LDS-store phase (round 2's phase stamps: ~2.5k of a tile's 7k cycles were barrier + LDS store).
-        wseg = (cur.n >= a.seg_end[0]) + (cur.n >= a.seg_end[1]);
-        fill_weights(wseg);
-        stage_to_lds(tile, -1);
-        __syncthreads();
-    }
     while (true) {
         const int seg = (cur.n >= a.seg_end[0]) + (cur.n >= a.seg_end[1]);
         f32x4 acc[MB][NB];
@@ -277,23 +253,19 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
         Work nxt = cur;
         for (int st = 0; st < a.nstage; ++st) {
             TILE_STAMP(0);
-            if constexpr (!DB) {
-                __syncthreads();                        // the previous stage's LDS reads are done
-                if (seg != wseg) {                      // first tile, or a batch item of another weight set
-                    fill_weights(seg);
-                    wseg = seg;
-                }
-                stage_to_lds(tile, -1);
-                __syncthreads();
-            } else if (seg != wseg) {                   // a batch item of another weight set (every wave is past the last barrier)
+            __syncthreads();                        // the previous stage's LDS reads are done
+            if (seg != wseg) {                      // first tile, or a batch item of another weight set
                 fill_weights(seg);
                 wseg = seg;
-                __syncthreads();
             }
+#pragma unroll
+            for (int c = 0; c < CPS; ++c)
+#pragma unroll
+                for (int j = 0; j < G::ITEMS; ++j)
+                    if (j < G::ITEMS - 1 || tid + j * 256 < 4 * G::IN_PX) lds_write<S>(tile + c * CH_FLOATS + loff[j], stage[c][j]);
+            __syncthreads();
             TILE_STAMP(1);
             const float* __restrict__ ast = abase + st * (CPS * 9 * WBLK);
-            const float* __restrict__ bcur = bbase + (DB ? par * BUF_FLOATS : 0);
-            float* __restrict__ tnext = tile + (DB ? (par ^ 1) * BUF_FLOATS : 0);
             __builtin_amdgcn_sched_barrier(0);
             // the next stage: the following chunks of this tile, or the first ones of the workgroup's next tile
             bool prefetch = true;
@@ -318,7 +290,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const int r = (nb / TWT), cc = nb % TWT;     // relative to (row0, col0)
-                    bv[set][nb] = lds_read<S>(bcur + c * CH_FLOATS +
+                    bv[set][nb] = lds_read<S>(bbase + c * CH_FLOATS +
                                               ((r * STRIDE + ky * DIL) * G::IN_W + cc * 16 * STRIDE + kx * DIL) * S);
                 }
             };
@@ -326,7 +298,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
 #pragma unroll
             for (int u = 0; u < kParts; ++u) {
                 if (u + 1 < kParts) read_operands(u + 1, (u + 1) & 1);
-                if (prefetch && u < kFetchParts) fetch_part(pf_soff, u);
+                if (prefetch) fetch_part(pf_soff, u);
 #pragma unroll
                 for (int s2 = 0; s2 < S; ++s2)
 #pragma unroll
@@ -334,14 +306,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u & 1][mb].v[s2], bv[u & 1][nb].v[s2], acc[mb][nb], 0, 0, 0);
-                if constexpr (DB) {
-                    if (prefetch && u >= kFetchParts) stage_to_lds(tnext, u - kFetchParts);
-                }
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (DB) {
-                __syncthreads();                        // the other tile is complete, this one is free
-                par ^= 1;
             }
         }
 
@@ -389,18 +354,14 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
 constexpr int kLdsBudget = 64 * 1024;    // per workgroup (default dynamic-LDS limit; two workgroups fit a CU)
 
 template <int MB, int S, int STRIDE, int DIL, int TH, int TWT, int CPS>
-static constexpr int tile_lds_bytes(int nchunk, int db = 0) {
-    return ((db ? 2 : 1) * CPS * 4 * TileGeom<S, STRIDE, DIL, TH, TWT>::PL + nchunk * 36 * 16 * MB * S) * 4;
+static constexpr int tile_lds_bytes(int nchunk) {
+    return (CPS * 4 * TileGeom<S, STRIDE, DIL, TH, TWT>::PL + nchunk * 36 * 16 * MB * S) * 4;
 }
-
-#ifndef ITERMVS_TILE_DB
-#define ITERMVS_TILE_DB 1       // double-buffered LDS tiles where they fit and a workgroup walks more than one stage
-#endif
 
 template <int MB, int S, int STRIDE, int DIL, int TH, int TWT, int CPS>
 static int launch_tile(TileArgs& a, int mt, hipStream_t stream) {
     constexpr int TW = 16 * TWT;
-    int lds = tile_lds_bytes<MB, S, STRIDE, DIL, TH, TWT, CPS>(a.nchunk);
+    const int lds = tile_lds_bytes<MB, S, STRIDE, DIL, TH, TWT, CPS>(a.nchunk);
     if (lds > kLdsBudget) return 1;
     a.tiles_x = (a.Wout + TW - 1) / TW;
     a.tiles_y = (a.Hout + TH - 1) / TH;
@@ -414,32 +375,14 @@ static int launch_tile(TileArgs& a, int mt, hipStream_t stream) {
     // tile list of its channel block (one tile each when there are fewer tiles than that); never more than
     // are resident at once -- a persistent workgroup queued behind another would serialise its tile list
     static const int want = [] { const char* e = itermvs_tuning_env("ITERMVS_TILE_PERSIST"); const int v = e ? atoi(e) : 4; return v < 1 ? 4 : v; }();
-    auto grid_for = [&](int fit) {
-        int gx = 256 * (want < fit ? want : fit) / a.ncb;
-        if (gx > a.total) gx = a.total;
-        return gx < 1 ? 1 : gx;
-    };
     int fit = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS, 0>, 256, lds) != hipSuccess || fit < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS>, 256, lds) != hipSuccess || fit < 1)
         fit = 1;
-    int gx = grid_for(fit);
-    // double-buffered LDS tiles: only where a workgroup walks several stages (tiles or chunk stages), the two tiles fit the
-    // budget and the residency does not drop
-    bool db = false;
-    if (ITERMVS_TILE_DB) {
-        const int lds2 = tile_lds_bytes<MB, S, STRIDE, DIL, TH, TWT, CPS>(a.nchunk, 1);
-        const int64_t stages_per_wg = (int64_t)a.nstage * ((a.total + gx - 1) / gx);
-        int fit2 = 0;
-        if (lds2 <= kLdsBudget && stages_per_wg >= 2 &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit2, conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS, 1>, 256, lds2) == hipSuccess &&
-            grid_for(fit2) == gx) {
-            db = true;
-            lds = lds2;
-        }
-    }
+    int gx = 256 * (want < fit ? want : fit) / a.ncb;
+    if (gx > a.total) gx = a.total;
+    if (gx < 1) gx = 1;
     const dim3 grid(gx, a.ncb);
-    if (db) hipLaunchKernelGGL((conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS, 1>), grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS, 0>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS>), grid, dim3(256), lds, stream, a);
     return 0;
 }
 

@@ -18,13 +18,8 @@ for w in ${LB_VARIANTS:-}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_w$w.o -o $V/libitermvs_w$w.so
 done
 # tw8 / tw32: the fused correlation kernels with 8 x 4 / 32 x 1 pixel tiles (default: 16 x 2)
-for tw in ${TW_VARIANTS:-}; do
+for tw in ${TW_VARIANTS:-8 32}; do
   /opt/rocm/bin/hipcc $FLAGS -DITERMVS_CORR_TW=$tw -I$C -c $C/corr.hip -o $T/corr_tw$tw.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_tw$tw.o -o $V/libitermvs_tw$tw.so
 done
-# nodb: conv_tile.hip without the double-buffered LDS tiles
-if [ "${NODB:-1}" = "1" ]; then
-  /opt/rocm/bin/hipcc $FLAGS -DITERMVS_TILE_DB=0 -I$C -c $C/conv_tile.hip -o $T/conv_tile_nodb.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/*.o | grep -v "/conv_tile.o") $T/conv_tile_nodb.o -o $V/libitermvs_nodb.so
-fi
 ls -la $V
