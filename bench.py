@@ -311,9 +311,12 @@ def main() -> None:
                 # an event-record node costs ~5 us of graph time: runner A carries them on iterations 0, 2, ...,
                 # runner B on 1, 3, ... -- every iteration position is sampled in every second replay
                 from itermvs_amd.engine import InferenceEngine
+                # runner 0 brackets the corr_iter launch of GRU iteration 0, runner 1 that of iteration 2 and the corr_init launch,
+                # runners 2 and 3 carry no timing nodes at all (a bracket costs ~5 us of graph time)
                 models[k]._engine = InferenceEngine(models[k].weights(), models[k].iteration, args.feature_dtype)
-                models[k]._engine.profile_iterations = {0} if k % 2 == 0 else {min(2, args.iters - 1)}
-                models[k]._engine.profile_init = (k % 2 == 1)
+                models[k]._engine_version = models[k]._weights_version()      # (the engine belongs to the current weights)
+                models[k]._engine.profile_iterations = {0} if k == 0 else ({min(2, args.iters - 1)} if k == 1 else set())
+                models[k]._engine.profile_init = (k == 1)
             models[k](*samples[k % n_resident])
             if ab == 4:
                 r = next(iter(models[k]._runners.values()))
@@ -347,10 +350,11 @@ def main() -> None:
                     "algorithmic_bytes_per_launch": b_iter, "avg_launch_ms": avg_ms, "launches_timed": len(t_iter),
                     "iterations_sampled": sorted({0, min(2, args.iters - 1)}) if ab == 4 else list(range(args.iters)),
                     "timing": ("external hipEvent record nodes around the launch inside the replayed hipGraph, read for every replay "
-                               "of the timed regions; of the two alternating runners one brackets the corr_iter launch of GRU "
+                               "of the timed regions; of the four alternating runners one brackets the corr_iter launch of GRU "
                                "iteration 0 (hypotheses around the first, noisy depth map), the other the launch of iteration 2 "
-                               "(smooth depth map, like iterations 1 and 3) and the corr_init launch; avg_launch_ms is the mean over "
-                               "both positions (a bracket costs ~6 us of graph time, included in `value`)"
+                               "(smooth depth map, like iterations 1 and 3) and the corr_init launch, two more runners carry no timing "
+                               "nodes; avg_launch_ms is the mean over both positions (a bracket costs ~5 us of graph time: ~4 us per "
+                               "step on average, included in `value`)"
                                if ab == 4 else "hipEvent pairs on the launch stream inside the timed region, every iteration")}
         # HBM bytes per launch: rocprofv3 --pmc passes of THIS command (tools/pmc_kernels.sh -> tools/pmc_summary.py ->
         # profiles/<round>_pmc_kernels.json); taken only if the summary names the kernel that ran here and the same workload
