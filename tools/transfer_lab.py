@@ -11,7 +11,7 @@ for each, so the cost of each ingredient (H2D, D2H, cross-stream events, Python)
     full            both                                                               (= bench `with_transfers.uint8_images`)
     full_pyr_cmp    like full, but the uint8 -> float pyramid kernel runs on the compute stream in front of the replay
     serial          everything on ONE stream, no events: H2D -> pyramid -> replay -> D2H
-    one_graph       ONE captured graph per runner: replay || (H2D of the next sample + pyramid), then D2H -- one launch per step
+    host_sync       like full, but no cross-stream wait on the compute stream: the host waits for the (long finished) upload
 """
 import os
 import sys
@@ -97,6 +97,50 @@ def make_three_stream(h2d: bool, d2h: bool, pyramid_on_compute: bool = False):
     return step
 
 
+def make_host_sync():
+    """like full, but the COMPUTE stream never waits on another stream: the host waits for the upload of sample i (issued
+    one step earlier, long done) and for the download of replay i-2 before it enqueues replay i; only the copy streams wait
+    on the compute stream's events"""
+    ev_in = [torch.cuda.Event() for _ in range(2)]
+    ev_done = [torch.cuda.Event() for _ in range(2)]
+    ev_out = [torch.cuda.Event() for _ in range(2)]
+    state = {"n": 0}
+
+    def upload(i):
+        k = i % 2
+        r = runners[k]
+        h_img, h_proj, h_min, h_max = host_in[i % len(host_in)]
+        with torch.cuda.stream(s_in):
+            if i >= 2:
+                s_in.wait_event(ev_done[k])        # replay i-2 has consumed these static inputs
+            raw_dev[k].copy_(h_img, non_blocking=True)
+            ops.image_pyramid(raw_dev[k], H, W, all_levels=False, out0=r.imgs[0])
+            r.proj_stack.copy_(h_proj, non_blocking=True)
+            r.depth_min.copy_(h_min, non_blocking=True)
+            r.depth_max.copy_(h_max, non_blocking=True)
+            ev_in[k].record(s_in)
+
+    def step(i):
+        k = i % 2
+        r = runners[k]
+        if state["n"] == 0:
+            upload(i)
+        state["n"] += 1
+        upload(i + 1)                              # the next sample starts travelling now
+        ev_in[k].synchronize()                     # host: sample i is on the device
+        if i >= 2:
+            ev_out[k].synchronize()                # host: outputs of replay i-2 are on the host
+        with torch.cuda.stream(s_cmp):
+            r(r.imgs, r.projs, r.depth_min, r.depth_max)
+            ev_done[k].record(s_cmp)
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(ev_done[k])
+            for h, d in zip(host_out[k], r.out):
+                h.copy_(d, non_blocking=True)
+            ev_out[k].record(s_out)
+    return step
+
+
 def resident(i):
     r = runners[i % 2]
     with torch.cuda.stream(s_cmp):
@@ -172,8 +216,7 @@ except Exception as e:  # noqa: BLE001
 rows = [("resident", resident), ("events_only", make_three_stream(False, False)), ("h2d_only", make_three_stream(True, False)),
         ("d2h_only", make_three_stream(False, True)), ("full", make_three_stream(True, True)),
         ("full_pyr_cmp", make_three_stream(True, True, True)), ("serial", serial), ("resident", resident), ("full", make_three_stream(True, True))]
-if have_big:
-    rows += [("one_graph", one_graph), ("full", make_three_stream(True, True)), ("one_graph", one_graph)]
+rows += [("host_sync", make_host_sync()), ("full", make_three_stream(True, True)), ("host_sync", make_host_sync())]
 print(f"{'choreography':<14} {'ms/map':>8} {'host ms/step':>13} {'maps/s':>8}")
 for name, fn in rows:
     ms, host = timed(fn)
