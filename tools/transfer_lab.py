@@ -141,6 +141,38 @@ def make_host_sync():
     return step
 
 
+_abl_ev = [torch.cuda.Event() for _ in range(4)]
+
+
+def abl_record(i):              # resident + one event record on the compute stream after the replay
+    r = runners[i % 2]
+    with torch.cuda.stream(s_cmp):
+        r(r.imgs, r.projs, r.depth_min, r.depth_max)
+        _abl_ev[i % 2].record(s_cmp)
+
+
+def abl_record_wait(i):         # ... + another stream waits on it and records its own event (no copies anywhere)
+    abl_record(i)
+    with torch.cuda.stream(s_out):
+        s_out.wait_event(_abl_ev[i % 2])
+        _abl_ev[2 + i % 2].record(s_out)
+
+
+def abl_h2d_noevents(i):        # resident + the uploads on another stream with NO ordering at all (timing only)
+    k = i % 2
+    h_img, h_proj, h_min, h_max = host_in[i % len(host_in)]
+    with torch.cuda.stream(s_in):
+        raw_dev[k].copy_(h_img, non_blocking=True)
+    resident(i)
+
+
+def abl_timing_event(i):        # resident + a TIMING event record (what torch.cuda.Event(enable_timing=True) costs)
+    r = runners[i % 2]
+    with torch.cuda.stream(s_cmp):
+        r(r.imgs, r.projs, r.depth_min, r.depth_max)
+        torch.cuda.Event(enable_timing=True).record(s_cmp)
+
+
 def resident(i):
     r = runners[i % 2]
     with torch.cuda.stream(s_cmp):
@@ -216,7 +248,8 @@ except Exception as e:  # noqa: BLE001
 rows = [("resident", resident), ("events_only", make_three_stream(False, False)), ("h2d_only", make_three_stream(True, False)),
         ("d2h_only", make_three_stream(False, True)), ("full", make_three_stream(True, True)),
         ("full_pyr_cmp", make_three_stream(True, True, True)), ("serial", serial), ("resident", resident), ("full", make_three_stream(True, True))]
-rows += [("host_sync", make_host_sync()), ("full", make_three_stream(True, True)), ("host_sync", make_host_sync())]
+rows += [("abl_record", abl_record), ("abl_rec_wait", abl_record_wait), ("abl_h2d_noev", abl_h2d_noevents), ("abl_timing_ev", abl_timing_event),
+         ("resident", resident), ("host_sync", make_host_sync()), ("full", make_three_stream(True, True)), ("host_sync", make_host_sync())]
 print(f"{'choreography':<14} {'ms/map':>8} {'host ms/step':>13} {'maps/s':>8}")
 for name, fn in rows:
     ms, host = timed(fn)
