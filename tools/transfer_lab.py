@@ -12,6 +12,7 @@ for each, so the cost of each ingredient (H2D, D2H, cross-stream events, Python)
     full_pyr_cmp    like full, but the uint8 -> float pyramid kernel runs on the compute stream in front of the replay
     serial          everything on ONE stream, no events: H2D -> pyramid -> replay -> D2H
     host_sync       like full, but no cross-stream wait on the compute stream: the host waits for the (long finished) upload
+    host_driven     no cross-stream wait anywhere: the host waits for replay i-1, then issues its download and the next upload
 """
 import os
 import sys
@@ -173,6 +174,57 @@ def abl_timing_event(i):        # resident + a TIMING event record (what torch.c
         torch.cuda.Event(enable_timing=True).record(s_cmp)
 
 
+def make_host_driven():
+    """NO cross-stream wait at all: the host orders the copies.  Per step: enqueue replay i (its inputs were confirmed on
+    the device one step earlier); wait for replay i-1; only then issue its download and the upload of sample i+1 into the
+    runner that replay i-1 has just released; wait for both.  The compute stream always has the next replay queued ~0.7 ms
+    ahead and carries one event record per replay."""
+    ev_in = [torch.cuda.Event() for _ in range(2)]
+    ev_done = [torch.cuda.Event() for _ in range(2)]
+    ev_out = [torch.cuda.Event() for _ in range(2)]
+    state = {"primed": False}
+
+    def upload(i):
+        k = i % 2
+        r = runners[k]
+        h_img, h_proj, h_min, h_max = host_in[i % len(host_in)]
+        with torch.cuda.stream(s_in):
+            raw_dev[k].copy_(h_img, non_blocking=True)
+            ops.image_pyramid(raw_dev[k], H, W, all_levels=False, out0=r.imgs[0])
+            r.proj_stack.copy_(h_proj, non_blocking=True)
+            r.depth_min.copy_(h_min, non_blocking=True)
+            r.depth_max.copy_(h_max, non_blocking=True)
+            ev_in[k].record(s_in)
+
+    def step(i):
+        k = i % 2
+        r = runners[k]
+        if not state["primed"]:
+            torch.cuda.synchronize()
+            upload(i)
+            ev_in[k].synchronize()
+            state["primed"] = True
+            state["prev"] = None
+        with torch.cuda.stream(s_cmp):
+            r(r.imgs, r.projs, r.depth_min, r.depth_max)
+            ev_done[k].record(s_cmp)
+        p = state["prev"]
+        if p is not None:
+            ev_done[p].synchronize()               # replay i-1 is done (replay i runs now)
+            with torch.cuda.stream(s_out):
+                for h, d in zip(host_out[p], runners[p].out):
+                    h.copy_(d, non_blocking=True)
+                ev_out[p].record(s_out)
+        else:
+            ev_done[k].synchronize() if False else None
+        upload(i + 1) if p is not None or True else None   # runner (i+1) % 2 == p: released by the wait above (first step: never used yet)
+        ev_in[(i + 1) % 2].synchronize()
+        if p is not None:
+            ev_out[p].synchronize()
+        state["prev"] = k
+    return step
+
+
 def resident(i):
     r = runners[i % 2]
     with torch.cuda.stream(s_cmp):
@@ -248,7 +300,7 @@ except Exception as e:  # noqa: BLE001
 rows = [("resident", resident), ("events_only", make_three_stream(False, False)), ("h2d_only", make_three_stream(True, False)),
         ("d2h_only", make_three_stream(False, True)), ("full", make_three_stream(True, True)),
         ("full_pyr_cmp", make_three_stream(True, True, True)), ("serial", serial), ("resident", resident), ("full", make_three_stream(True, True))]
-rows += [("abl_record", abl_record), ("abl_rec_wait", abl_record_wait), ("abl_h2d_noev", abl_h2d_noevents), ("abl_timing_ev", abl_timing_event),
+rows += [("host_driven", make_host_driven()), ("resident", resident), ("host_driven", make_host_driven()), ("abl_record", abl_record), ("abl_rec_wait", abl_record_wait), ("abl_h2d_noev", abl_h2d_noevents), ("abl_timing_ev", abl_timing_event),
          ("resident", resident), ("host_sync", make_host_sync()), ("full", make_three_stream(True, True)), ("host_sync", make_host_sync())]
 print(f"{'choreography':<14} {'ms/map':>8} {'host ms/step':>13} {'maps/s':>8}")
 for name, fn in rows:
