@@ -142,19 +142,13 @@ def transfers_leg(args, dev, samples, world, u8: bool = False):
     ev_in = [torch.cuda.Event() for _ in range(2)]
     ev_done = [torch.cuda.Event() for _ in range(2)]
     ev_out = [torch.cuda.Event() for _ in range(2)]
-    started = [False, False]
-    trace = [] if os.environ.get("ITERMVS_TRACE_TRANSFERS") else None     # (step, 4 timing events): printed to stderr
+    state = {"prev": None}
 
-    def step(i: int) -> None:
+    def upload(i: int) -> None:
         k = i % 2
         r = runners[k]
         h_img, h_proj, h_min, h_max = host_in[i % len(host_in)]
-        tev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if trace is not None else None
         with torch.cuda.stream(s_in):
-            if started[k]:
-                s_in.wait_event(ev_done[k])                 # replay i-2 has consumed these static inputs
-            if tev:
-                tev[0].record(s_in)
             if u8:
                 raw_dev[k].copy_(h_img, non_blocking=True)
                 ops.image_pyramid(raw_dev[k], args.height, args.width, all_levels=False, out0=r.imgs[0])
@@ -164,34 +158,39 @@ def transfers_leg(args, dev, samples, world, u8: bool = False):
             r.depth_min.copy_(h_min, non_blocking=True)
             r.depth_max.copy_(h_max, non_blocking=True)
             ev_in[k].record(s_in)
-            if tev:
-                tev[1].record(s_in)
+
+    # The HOST orders the copies -- no stream ever waits on another stream's event.  (With hipStreamWaitEvent in front of every
+    # replay, and the copy streams waiting on the replay's event, the same work measured 1.25-1.35 ms per map against 1.13 ms
+    # resident; upload and replay side by side WITHOUT any ordering cost nothing: tools/transfer_lab.py, profiles/r03.)
+    # Per step: enqueue replay i (its inputs were confirmed on the device one step earlier); wait for replay i-1; only then
+    # issue its download and the upload of sample i+1 into the runner replay i-1 has released; wait for both.  The compute
+    # stream always has the next replay queued ~0.7 ms ahead and carries one event record per replay.
+    def step(i: int) -> None:
+        k = i % 2
+        r = runners[k]
+        if state["prev"] is None:                     # very first step: the first sample has to be on the device
+            torch.cuda.synchronize()
+            upload(i)
+            ev_in[k].synchronize()
         with torch.cuda.stream(s_cmp):
-            s_cmp.wait_event(ev_in[k])
-            if started[k]:
-                s_cmp.wait_event(ev_out[k])                 # outputs of replay i-2 are on the host
-            if tev:
-                tev[2].record(s_cmp)
             r(r.imgs, r.projs, r.depth_min, r.depth_max)    # static inputs: no staging copies, one graph launch
             ev_done[k].record(s_cmp)
-            if tev:
-                tev[3].record(s_cmp)
-                trace.append((i, tev))
-        with torch.cuda.stream(s_out):
-            s_out.wait_event(ev_done[k])
-            for h, d in zip(host_out[k], r.out):
-                h.copy_(d, non_blocking=True)
-            ev_out[k].record(s_out)
-        started[k] = True
+        p = state["prev"]
+        if p is not None:
+            ev_done[p].synchronize()                  # replay i-1 is done (replay i is running)
+            with torch.cuda.stream(s_out):
+                for h, d in zip(host_out[p], runners[p].out):
+                    h.copy_(d, non_blocking=True)
+                ev_out[p].record(s_out)
+        upload(i + 1)                                 # into runner (i+1) % 2: released by the wait above (or never used yet)
+        ev_in[(i + 1) % 2].synchronize()
+        if p is not None:
+            ev_out[p].synchronize()                   # depth + confidence of replay i-1 are on the host
+        state["prev"] = k
 
     regions = shard.timed_regions(step, args.steps, max(args.warmup, 4), args.repeats)
     elapsed = shard.median(regions)
     eng.check_projection_finite()
-    if trace:
-        base = trace[-8][1][0]
-        for i, tev in trace[-8:]:
-            print("transfers step %d: h2d %.3f..%.3f ms, replay %.3f..%.3f ms" % ((i,) + tuple(base.elapsed_time(e) for e in tev)),
-                  file=sys.stderr)
     h2d = sum(t.numel() * t.element_size() for t in host_in[0])
     d2h = sum(t.numel() * t.element_size() for t in host_out[0])
     return {"value": world * args.steps * args.batch / elapsed, "unit": "depth-maps/s", "ms_per_step": elapsed / args.steps * 1e3,
@@ -199,8 +198,9 @@ def transfers_leg(args, dev, samples, world, u8: bool = False):
             "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h,
             "images": "uint8 RGB, normalised on the GPU (itermvs_image_pyramid)" if u8 else "float32 level_0 tensor",
             "note": "pinned host inputs -> H2D on a copy stream into the static inputs of two alternating hipGraph runners, "
-                    "compute stream, D2H of depth + confidence into pinned host buffers on a third stream; "
-                    "same steps / barrier / max-over-ranks timing as `value`"}
+                    "compute stream, D2H of depth + confidence into pinned host buffers on a third stream, ordered by the host (the "
+                    "upload of sample i+1 and the download of map i-1 run beside replay i; no stream waits on another stream's "
+                    "event); same steps / barrier / max-over-ranks timing as `value`"}
 
 
 def main() -> None:

@@ -118,8 +118,8 @@ class Prefetcher:
     """Iterates a ScanFolderDataset shard with ONE sample always staged ahead on the device: a host thread decodes the
     images of the next ``depth`` samples into pinned memory; before item n is handed to the consumer, the upload and the
     pyramid kernel of item n+1 are already enqueued on a side HIP stream (their ``ready`` event recorded), so decode, H2D
-    and pyramid of the next reference view overlap the current depth map's kernels and its D2H.  The consumer's compute
-    stream waits on the item's event when the item is yielded.  ``close()`` (or leaving the iteration early) stops the
+    and pyramid of the next reference view overlap the current depth map's kernels and its D2H.  The host waits on the
+    item's (long completed) event before the item is yielded; no stream waits on another stream.  ``close()`` (or leaving the iteration early) stops the
     worker thread."""
 
     def __init__(self, dataset, indices: Sequence[int], dev, depth: int = 2):
@@ -195,7 +195,10 @@ class Prefetcher:
                 if nxt is not None:
                     self.staged_ahead += 1
                 cur = torch.cuda.current_stream(self.dev)
-                cur.wait_event(ready)
+                # the HOST waits for the (long finished: staged one item ahead) upload instead of making the compute stream
+                # wait on the side stream's event: a cross-stream wait in front of a depth map's launches measured +60..+150 us
+                # per map on MI355X (tools/transfer_lab.py), a host wait on a completed event costs nothing
+                ready.synchronize()
                 for t in list(tensors[0].values()) + list(tensors[1].values()) + [tensors[2], tensors[3]]:
                     t.record_stream(cur)           # allocated on the side stream, used on this one
                 yield s, tensors
