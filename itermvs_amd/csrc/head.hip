@@ -500,7 +500,8 @@ extern "C" int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_
     // one tile shared by the four waves of a persistent workgroup, two workgroups per CU
     const int cus = itermvs_num_cus();
     const int tiles = a.tiles_x * H * B;
-    const int grid = tiles < 2 * cus ? tiles : 2 * cus;
+    static const int wgs_per_cu = [] { const char* e = itermvs_tuning_env("ITERMVS_HEAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
+    const int grid = tiles < wgs_per_cu * cus ? tiles : wgs_per_cu * cus;
     hipLaunchKernelGGL(head_coop_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles);
     return itermvs_launch_status();
 }

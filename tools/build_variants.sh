@@ -22,4 +22,10 @@ for tw in ${TW_VARIANTS:-8 32}; do
   /opt/rocm/bin/hipcc $FLAGS -DITERMVS_CORR_TW=$tw -I$C -c $C/corr.hip -o $T/corr_tw$tw.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_tw$tw.o -o $V/libitermvs_tw$tw.so
 done
+# tuning: the whole library with -DITERMVS_TUNING (reads the ITERMVS_* overrides)
+if [ "${TUNING_LIB:-0}" = "1" ]; then
+  mkdir -p $T/tuning
+  for f in $C/*.hip; do b=$(basename $f .hip); /opt/rocm/bin/hipcc $FLAGS -DITERMVS_TUNING -I$C -c $f -o $T/tuning/$b.o & done; wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $T/tuning/*.o -o $V/libitermvs_tuning.so
+fi
 ls -la $V

@@ -8,6 +8,7 @@
 #         trace        rocprofv3 --kernel-trace --stats of a minimal bench run + per-step timeline
 #         pmc          counter passes (tools/pmc_kernels.sh) + summary json
 #         py:<script+args>   any tools/*.py script                        -> gpurun_out/<tag>_py_<n>.log
+#         sh:<command>       any shell command (use + for spaces)         -> gpurun_out/<tag>_sh_<n>.log
 #         ubench:<name>      build and run tools/ubench/<name>.hip        -> gpurun_out/<tag>_ubench_<name>.log
 # Every step runs under its own `timeout`; outputs land in gpurun_out/ (copy what should be judged into profiles/).
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -30,6 +31,7 @@ for step in "$@"; do
                cp $(ls ${O}_prof/*/*kernel_stats.csv | head -1) ${O}_kernel_stats.csv; tail -16 ${O}_timeline.txt ;;
     pmc)       bash tools/pmc_kernels.sh $TAG > ${O}_pmc.log 2>&1; tail -5 ${O}_pmc.log ;;
     py:*)      timeout 900 python tools/$arg > ${O}_py_$n.log 2>&1; tail -40 ${O}_py_$n.log ;;
+    sh:*)      (timeout 900 bash -c "$arg") > ${O}_sh_$n.log 2>&1; tail -40 ${O}_sh_$n.log ;;
     ubench:*)  (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $arg $arg.hip 2>&1 | tail -3 && timeout 300 ./$arg) > ${O}_ubench_$arg.log 2>&1; cat ${O}_ubench_$arg.log ;;
     *)         echo "unknown step $step" ;;
   esac
