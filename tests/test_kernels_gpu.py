@@ -661,3 +661,89 @@ def test_copy_multi_stages_a_sample_in_one_launch():
     assert all(torch.equal(d, t) for d, t in zip(dst, src))
     with pytest.raises(RuntimeError):
         ops().copy_multi(dst[:1], [src[0].double()])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg3", "cfg5"])
+def test_fused_correlation_properties_at_full_size(cfg):
+    """BASELINE's full sizes (cfg 1: 5 views 640x512; cfg 3: 5 views 1600x1152; cfg 5: 11 views 1920x1280), where the CPU
+    oracle is too slow to run inside a test: size-independent properties of itermvs_corr_iter / itermvs_corr_init.
+      * linearity: source features x 2 and reference features x 0.5 are exact in fp32 -> outputs bit-identical; source x 4
+        -> outputs x 4 exactly;
+      * determinism (two launches, equal bits) and finiteness;
+      * a view whose weight is 0 contributes nothing: zeroing its weight == dropping it (same summation order of the rest
+        is not guaranteed -> compared to 1e-6);
+      * a random subset of 64 pixels is checked against the CPU oracle's arithmetic evaluated ONLY at those pixels (warp,
+        module.py:89-115, + bilinear gather + group correlation + view-weighted mean, itermvs.py:84-120)."""
+    from itermvs_amd import synthetic
+    from itermvs_amd.engine import sample_offsets
+    views, hh, ww = {"cfg1": (5, 512, 640), "cfg3": (5, 1152, 1600), "cfg5": (11, 1280, 1920)}[cfg]
+    gen = torch.Generator().manual_seed(views)
+    sm = synthetic.make_sample(1, views, hh, ww, seed=1)
+    s = views - 1
+    chans, sizes = {1: 16, 2: 32, 3: 48}, {1: (hh // 2, ww // 2), 2: (hh // 4, ww // 4), 3: (hh // 8, ww // 8)}
+    h, w = sizes[2]
+    feats = {l: torch.randn((views, chans[l]) + sizes[l], generator=gen) for l in (1, 2, 3)}
+    cl = {l: cu(feats[l]).contiguous(memory_format=torch.channels_last) for l in feats}
+    src = {l: [cl[l][i:i + 1] for i in range(1, views)] for l in cl}
+    ref = {l: cl[l][0:1] for l in cl}
+    projs = torch.stack([sm["proj_matrices"][f"level_{l}"].float() for l in (1, 2, 3)])
+    p12 = torch.stack([torch.stack([proj12_cpu(projs[i][:, k], projs[i][:, 0]) for k in range(1, views)], 1) for i in range(3)])
+    nd = torch.rand((1, 1, h, w), generator=gen)
+    vw = torch.rand((1, s, h, w), generator=gen)
+    inv_min, inv_max = cu(torch.tensor([1 / 425.0])), cu(torch.tensor([1 / 935.0]))
+    offs = sample_offsets()
+    ref_q = ops().ref_quarter(ref[1], ref[2], ref[3])
+    run = lambda srcs, rq, wts: ops().corr_iter(srcs, rq, cu(p12), wts, inv_min, inv_max, norm_depth=cu(nd), offsets=offs)
+    base = run(src, ref_q, cu(vw))
+    again = run(src, ref_q, cu(vw))
+    scaled = run({l: [t * 2 for t in src[l]] for l in src}, ref_q * 0.5, cu(vw))
+    times4 = run({l: [t * 4 for t in src[l]] for l in src}, ref_q, cu(vw))
+    for a, b_, c, d in zip(base, again, scaled, times4):
+        assert bool(torch.isfinite(a).all())
+        assert torch.equal(a, b_) and torch.equal(a, c) and torch.equal(a * 4, d)
+    vw0 = vw.clone()
+    vw0[:, -1] = 0.0
+    dropped = ops().corr_iter({l: src[l][:-1] for l in src}, ref_q, cu(p12[:, :, :-1].contiguous()), cu(vw[:, :-1].contiguous()), inv_min, inv_max,
+                              norm_depth=cu(nd), offsets=offs)
+    for a, b_ in zip(run(src, ref_q, cu(vw0)), dropped):
+        assert maxdiff(a, b_) <= 1e-6 * max(1.0, float(b_.abs().max()))
+    # 64 random pixels against the oracle's arithmetic evaluated at those pixels only
+    pix = torch.randint(0, h * w, (64,), generator=gen)
+    ys, xs = pix // w, pix % w
+    imin, imax = torch.tensor(1 / 425.0).view(1, 1, 1, 1), torch.tensor(1 / 935.0).view(1, 1, 1, 1)
+    samples = O.iteration_depth_samples(nd, imin, imax)
+    rq_cpu = ref_q.cpu()
+    off = {1: 0, 2: 16, 3: 48}
+    for i, l in enumerate((1, 2, 3)):
+        n = len(offs[l])
+        depth_sel = samples[l][0][:, ys, xs].t().reshape(64, n, 1, 1)              # [64,N,1,1]: one "image" of 1x1 per pixel
+        refl = rq_cpu[0, ys, xs, off[l]:off[l] + chans[l]].reshape(64, chans[l], 1, 1)
+        acc, wsum = 0, 1e-5
+        for k in range(1, views):
+            m = torch.cat([p12[i][:, k - 1].view(1, 3, 4), torch.zeros(1, 1, 4)], 1)
+            # source coordinates of the selected pixels: the oracle's formula on an explicit pixel list
+            rot, trans = m[0, :3, :3], m[0, :3, 3]
+            xy1 = torch.stack([xs.float() * (sizes[l][1] / w), ys.float() * (sizes[l][0] / h), torch.ones(64)], 0)       # module.py:95-98
+            rxyz = rot @ xy1                                                                                               # [3,64]
+            pts = rxyz.t().reshape(64, 1, 3) * depth_sel.reshape(64, n, 1) + trans.view(1, 1, 3)
+            X, Y, Z = pts[..., 0], pts[..., 1], pts[..., 2]
+            neg = ~(Z > 1e-2)
+            X = torch.where(neg, torch.full_like(X, float(w)), X); Y = torch.where(neg, torch.full_like(Y, float(h)), Y)
+            Z = torch.where(neg, torch.ones_like(Z), Z)
+            gx = (X / Z) / ((sizes[l][1] - 1) / 2) - 1
+            gy = (Y / Z) / ((sizes[l][0] - 1) / 2) - 1
+            ix = ((gx + 1) / 2) * (sizes[l][1] - 1)
+            iy = ((gy + 1) / 2) * (sizes[l][0] - 1)
+            warped = O.bilinear_gather(feats[l][k:k + 1].expand(64, -1, -1, -1), ix.view(64, n, 1, 1), iy.view(64, n, 1, 1))   # [64,C,N,1,1]
+            corr = O.group_correlation(warped, refl)                                                                       # [64,G,N,1,1]
+            wv = vw[0, k - 1, ys, xs].view(64, 1, 1, 1, 1)
+            acc, wsum = acc + corr * wv, wsum + wv
+        want = (acc / wsum)[:, :, :, 0, 0].permute(0, 2, 1)                         # [64,N,G]
+        got = base[i][0].cpu()[:, :, ys, xs].permute(2, 0, 1)                       # [N,G,64] -> [64,N,G]
+        assert maxdiff(got, want) <= 5e-5 * max(1.0, float(want.abs().max())), (cfg, l)
+    # the initialisation kernel: same linearity / determinism properties
+    ci = ops().corr_init(src[3], ref[3], cu(p12[2]), inv_min, inv_max, 32)
+    assert torch.equal(ci, ops().corr_init(src[3], ref[3], cu(p12[2]), inv_min, inv_max, 32))
+    assert torch.equal(ci, ops().corr_init([t * 2 for t in src[3]], ref[3] * 0.5, cu(p12[2]), inv_min, inv_max, 32))
+    assert bool(torch.isfinite(ci).all()) and tuple(ci.shape) == (1, s, 32, 8) + sizes[3]
