@@ -741,7 +741,9 @@ def test_fused_correlation_properties_at_full_size(cfg):
             acc, wsum = acc + corr * wv, wsum + wv
         want = (acc / wsum)[:, :, :, 0, 0].permute(0, 2, 1)                         # [64,N,G]
         got = base[i][0].cpu()[:, :, ys, xs].permute(2, 0, 1)                       # [N,G,64] -> [64,N,G]
-        assert maxdiff(got, want) <= 5e-5 * max(1.0, float(want.abs().max())), (cfg, l)
+        # unit-variance NOISE features at coordinates up to 960 px: one fp32 ulp of a coordinate (6e-5 px) moves a bilinear
+        # blend by ~1e-4 (measured 8.0e-5 at the cfg-3 size); the smooth-feature gates elsewhere hold 5e-5
+        assert maxdiff(got, want) <= 2e-4 * max(1.0, float(want.abs().max())), (cfg, l)
     # the initialisation kernel: same linearity / determinism properties
     ci = ops().corr_init(src[3], ref[3], cu(p12[2]), inv_min, inv_max, 32)
     assert torch.equal(ci, ops().corr_init(src[3], ref[3], cu(p12[2]), inv_min, inv_max, 32))
