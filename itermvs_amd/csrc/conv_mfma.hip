@@ -156,9 +156,11 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const MfmaArgs a) {
 // In the generic epilogue above every output element gathers its four coarse taps from global memory (192 gather loads
 // per lane against 28 operand loads and 48 MFMAs: 49 us for a layer whose traffic is worth 23 us, and 2.3x its bytes
 // moved through the L1).  Here a workgroup owns a 4 x 64 output tile (one row per wave, four 16-pixel slots); the
-// (4/2 + 2) x (64/2 + 2) coarse patch of all 48 channels is staged ONCE in LDS, border-replicated, so the taps of every
-// element are LDS reads at (i0, j0), (i0, j0 + 1), (i0 + 1, j0), (i0 + 1, j0 + 1) -- the arithmetic and its order are
-// those of the generic epilogue (== bilinear_up_kernel), results are bit-identical.
+// (4/2 + 2) x (64/2 + 2) coarse patch of all 48 channels is staged ONCE in LDS, border-replicated (so every tap pair is
+// (j, j + 1) / (i, i + 1) in patch coordinates), the operand roles of the MFMA are swapped so that a lane holds four
+// consecutive pixels of one channel (dwordx4 stores, eight LDS reads for its twelve taps), and the operand / patch loads
+// are batched (two memory round trips per tile).  The arithmetic and its order are those of the generic epilogue
+// (== bilinear_up_kernel): results are bit-identical.  Measured 49 -> 36 us (level 1), 17.9 -> 14 us (level 2).
 // ---------------------------------------------------------------------------------------------
 constexpr int kLatTH = 4, kLatTW = 64;                       // output tile (rows = waves)
 constexpr int kLatPH = kLatTH / 2 + 2, kLatPW = kLatTW / 2 + 2;   // coarse patch 4 x 34
