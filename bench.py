@@ -112,11 +112,13 @@ def cpu_baseline(args, target_seconds: float = 15.0):
             "s_per_depth_map": dt / n}
 
 
-def transfers_leg(args, dev, samples, world, u8: bool = False):
+def transfers_leg(args, dev, samples, world, u8: bool = False, in_flight: int = 1):
     """depth-maps/s with PCIe in the loop: H2D of the sample (imgs level_0, cameras, depth range) and D2H of the two output
-    maps, overlapped with compute through two graph runners' static buffers (double buffering) and three HIP streams.
+    maps, overlapped with compute through the static buffers of ``in_flight + 1`` graph runners.
     ``u8``: the images travel as the decoded uint8 RGB arrays (what eval.py --dataset folder uploads, 5x fewer bytes) and
-    itermvs_image_pyramid normalises them into the runner's static input on the copy stream."""
+    itermvs_image_pyramid normalises them into the runner's static input on the copy stream.
+    ``in_flight``: depth maps queued on the GPU while the host waits for the oldest one; 1 = the protocol form (one compute
+    stream), more = one compute stream per runner (the serving configuration, reported under `pipelined`)."""
     import torch
     from itermvs_amd import ops, shard, synthetic
     from itermvs_amd.engine import GraphedRunner, InferenceEngine
@@ -127,7 +129,8 @@ def transfers_leg(args, dev, samples, world, u8: bool = False):
     eng = InferenceEngine(m.weights(), args.iters, args.feature_dtype)
     imgs0, projs0, dmin0, dmax0 = samples[0]
     pj = {l: projs0[f"level_{l}"].float() for l in (1, 2, 3)}
-    runners = [GraphedRunner(eng, imgs0["level_0"].float(), pj, dmin0.float(), dmax0.float()) for _ in range(2)]
+    nr = in_flight + 1
+    runners = [GraphedRunner(eng, imgs0["level_0"].float(), pj, dmin0.float(), dmax0.float()) for _ in range(nr)]
     host_in = []
     for imgs, projs, dmin, dmax in samples:
         img = imgs["level_0"].float().cpu()
@@ -138,14 +141,15 @@ def transfers_leg(args, dev, samples, world, u8: bool = False):
                         dmin.float().cpu().pin_memory(), dmax.float().cpu().pin_memory()))
     host_out = [tuple(torch.empty(o.shape, dtype=o.dtype).pin_memory() for o in r.out) for r in runners]
     raw_dev = [torch.empty(host_in[0][0].shape, dtype=torch.uint8, device=dev) for _ in runners] if u8 else None
-    s_in, s_cmp, s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
-    ev_in = [torch.cuda.Event() for _ in range(2)]
-    ev_done = [torch.cuda.Event() for _ in range(2)]
-    ev_out = [torch.cuda.Event() for _ in range(2)]
-    state = {"prev": None}
+    s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    s_cmp = [torch.cuda.Stream(device=dev) for _ in range(nr if in_flight > 1 else 1)]
+    ev_in = [torch.cuda.Event() for _ in range(nr)]
+    ev_done = [torch.cuda.Event() for _ in range(nr)]
+    ev_out = [torch.cuda.Event() for _ in range(nr)]
+    state = {"primed": False}
 
     def upload(i: int) -> None:
-        k = i % 2
+        k = i % nr
         r = runners[k]
         h_img, h_proj, h_min, h_max = host_in[i % len(host_in)]
         with torch.cuda.stream(s_in):
@@ -162,32 +166,32 @@ def transfers_leg(args, dev, samples, world, u8: bool = False):
     # The HOST orders the copies -- no stream ever waits on another stream's event.  (With hipStreamWaitEvent in front of every
     # replay, and the copy streams waiting on the replay's event, the same work measured 1.25-1.35 ms per map against 1.13 ms
     # resident; upload and replay side by side WITHOUT any ordering cost nothing: tools/transfer_lab.py, profiles/r03.)
-    # Per step: enqueue replay i (its inputs were confirmed on the device one step earlier); wait for replay i-1; only then
-    # issue its download and the upload of sample i+1 into the runner replay i-1 has released; wait for both.  The compute
-    # stream always has the next replay queued ~0.7 ms ahead and carries one event record per replay.
+    # Per step: enqueue replay i (its inputs were confirmed on the device earlier); wait for the OLDEST replay in flight,
+    # i - in_flight; only then issue its download and the upload of sample i+1 into the runner it has released; wait for both.
+    # The GPU always has `in_flight` replays queued and each compute stream carries one event record per replay.
     def step(i: int) -> None:
-        k = i % 2
+        k = i % nr
         r = runners[k]
-        if state["prev"] is None:                     # very first step: the first sample has to be on the device
+        if not state["primed"]:                       # very first step: the first sample has to be on the device
             torch.cuda.synchronize()
             upload(i)
             ev_in[k].synchronize()
-        with torch.cuda.stream(s_cmp):
+            state.update(primed=True, first=i)
+        with torch.cuda.stream(s_cmp[k % len(s_cmp)]):
             r(r.imgs, r.projs, r.depth_min, r.depth_max)    # static inputs: no staging copies, one graph launch
-            ev_done[k].record(s_cmp)
-        p = state["prev"]
-        if p is not None:
-            ev_done[p].synchronize()                  # replay i-1 is done (replay i is running)
+            ev_done[k].record()
+        p = i - in_flight                              # the oldest replay in flight
+        if p >= state["first"]:
+            pk = p % nr
+            ev_done[pk].synchronize()                  # replay p is done (the younger ones are running / queued)
             with torch.cuda.stream(s_out):
-                for h, d in zip(host_out[p], runners[p].out):
+                for h, d in zip(host_out[pk], runners[pk].out):
                     h.copy_(d, non_blocking=True)
-                ev_out[p].record(s_out)
-        upload(i + 1)                                 # into runner (i+1) % 2: released by the wait above (or never used yet)
-        ev_in[(i + 1) % 2].synchronize()
-        if p is not None:
-            ev_out[p].synchronize()                   # depth + confidence of replay i-1 are on the host
-        state["prev"] = k
-
+                ev_out[pk].record(s_out)
+        upload(i + 1)                                  # runner (i + 1) % nr == p % nr: released by the wait above (or never used yet)
+        ev_in[(i + 1) % nr].synchronize()
+        if p >= state["first"]:
+            ev_out[p % nr].synchronize()               # depth + confidence of replay p are on the host
     regions = shard.timed_regions(step, args.steps, max(args.warmup, 4), args.repeats)
     elapsed = shard.median(regions)
     eng.check_projection_finite()
@@ -195,12 +199,12 @@ def transfers_leg(args, dev, samples, world, u8: bool = False):
     d2h = sum(t.numel() * t.element_size() for t in host_out[0])
     return {"value": world * args.steps * args.batch / elapsed, "unit": "depth-maps/s", "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
-            "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h,
+            "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h, "depth_maps_in_flight": in_flight,
             "images": "uint8 RGB, normalised on the GPU (itermvs_image_pyramid)" if u8 else "float32 level_0 tensor",
-            "note": "pinned host inputs -> H2D on a copy stream into the static inputs of two alternating hipGraph runners, "
-                    "compute stream, D2H of depth + confidence into pinned host buffers on a third stream, ordered by the host (the "
-                    "upload of sample i+1 and the download of map i-1 run beside replay i; no stream waits on another stream's "
-                    "event); same steps / barrier / max-over-ranks timing as `value`"}
+            "note": "pinned host inputs -> H2D on a copy stream into the static inputs of alternating hipGraph runners, "
+                    "compute stream(s), D2H of depth + confidence into pinned host buffers on a third stream, ordered by the host "
+                    "(the upload of the next sample and the download of the oldest map run beside the replays in flight; no "
+                    "stream waits on another stream's event); same steps / barrier / max-over-ranks timing as `value`"}
 
 
 def main() -> None:
@@ -401,6 +405,9 @@ def main() -> None:
         pipelined = {"streams": ns, "value": world * psteps * args.batch / pel, "unit": "depth-maps/s",
                      "steps": psteps, "ms_per_step": pel / psteps * 1e3}
         del pm
+        if not args.no_transfers and args.batch == 1:
+            # the serving configuration: host buffers in / out with `ns` depth maps in flight (one compute stream each)
+            pipelined["with_transfers"] = transfers_leg(args, dev, samples, world, u8=True, in_flight=ns)
 
     # the SURVEY section 8(d) form of the metric: host buffers in, host buffers out (eval.py:130-137).  Pinned host
     # samples are copied into the static inputs of two alternating graph runners on a copy stream while the previous depth
