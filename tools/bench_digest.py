@@ -16,5 +16,7 @@ for k in ("pipelined", "with_transfers", "roofline_conv", "cpu_baseline"):
         extra = ""
         if k == "with_transfers" and "uint8_images" in v:
             extra = f"  uint8 {v['uint8_images']['value']:.1f} ({v['uint8_images']['ms_per_step']:.3f} ms)"
+        if k == "pipelined" and "with_transfers" in v:
+            extra = f"  with transfers {v['with_transfers']['value']:.1f} ({v['with_transfers']['depth_maps_in_flight']} in flight)"
         print(f"{k}: {v.get('value', v.get('achieved')):.2f} {v.get('unit', '')} {('ms/step %.3f' % v['ms_per_step']) if 'ms_per_step' in v else ''}{extra}")
 print("workload:", d["config"]["workload"])
