@@ -280,7 +280,7 @@ def test_smoke_entry():
     ge.smoke()
 
 
-@pytest.mark.parametrize("cfg,fdt", [("cfg3", "fp32"), ("cfg5", "fp32"), ("cfg5", "fp16")])
+@pytest.mark.parametrize("cfg,fdt", [("cfg3", "fp32"), ("cfg3v6", "fp32"), ("cfg5", "fp32"), ("cfg5", "fp16")])
 def test_full_size_configs_cross_backend(cfg, fdt):
     """BASELINE cfg 3 (1600x1152, 5 views, 4 iterations) and cfg 5 (1920x1280, 11 views, 8 iterations):
     too large for the CPU oracle in a test, so parity is checked through size-independent properties --
@@ -291,7 +291,8 @@ def test_full_size_configs_cross_backend(cfg, fdt):
     the elements, so the chaos floor between them is higher than in fp32 -- the bounds below are the measured ones."""
     from itermvs_amd import synthetic
     from itermvs_amd.engine import InferenceEngine
-    views, h, w, iters = {"cfg3": (5, 1152, 1600, 4), "cfg5": (11, 1280, 1920, 8)}[cfg]
+    # cfg 3 is quoted with "5 src views" in BASELINE.json (6 images) while the reference's DTU script runs 5 images: both
+    views, h, w, iters = {"cfg3": (5, 1152, 1600, 4), "cfg3v6": (6, 1152, 1600, 4), "cfg5": (11, 1280, 1920, 8)}[cfg]
     model = make_model("seed0", iters)
     s = synthetic.make_sample(batch=1, num_views=views, height=h, width=w, seed=3)
     imgs, pm, dmin, dmax = to_dev(s)
