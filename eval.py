@@ -159,20 +159,49 @@ def save_depth(args) -> int:
 
 def save_depth_folder(args, dataset, mine, model, dev) -> int:
     """the folder input side: a host thread decodes the next views while the GPU works; uint8 upload + pyramid kernel on a
-    side stream (itermvs_amd.scan_dataset.Prefetcher); one reference view per forward like the reference's batch_size 1"""
+    side stream (itermvs_amd.scan_dataset.Prefetcher); one reference view per forward like the reference's batch_size 1.
+    The loop is software-pipelined by one depth map on ONE stream: forward n and the asynchronous download of its two maps
+    (and of the engine's NaN flag, module.py:83,87) are enqueued, then the host writes the PFMs of map n-1 while the GPU
+    works on n -- the reference's loop (eval.py:128-151) leaves the GPU idle for every file it writes."""
     from itermvs_amd.scan_dataset import Prefetcher
     done = 0
+    host = [None, None]                                        # two sets of pinned result buffers, used alternately
+    events = [torch.cuda.Event(), torch.cuda.Event()]
+    model.check_nan = False                                    # the flag travels with the results instead of stalling the stream
+
+    def finish(job) -> None:
+        sample, k, n, t0 = job
+        events[k].synchronize()                                # forward n-1 and its downloads are done; forward n is running
+        depth, conf, flag = host[k]
+        if int(flag[0]) != 0:
+            raise AssertionError("nan in proj (singular or non-finite camera matrix, module.py:83,87)")
+        print("Iter {}/{}, time = {:.3f}".format(n, len(mine), time.time() - t0))
+        name = sample["filename"]
+        save_pfm(os.path.join(args.outdir, name.format("depth_est", ".pfm")), np.squeeze(depth.numpy()[0], 0))
+        save_pfm(os.path.join(args.outdir, name.format("confidence", ".pfm")), np.squeeze(conf.numpy()[0], 0))
+
     with torch.no_grad():
+        prev = None
         for n, (sample, (imgs, projs, dmin, dmax)) in enumerate(Prefetcher(dataset, mine, dev)):
             t0 = time.time()
             out = model(imgs, projs, dmin, dmax)
-            depth = out["depths_upsampled"].cpu().numpy()
-            conf = out["confidence_upsampled"].cpu().numpy()
-            model.check_projection_finite()
-            print("Iter {}/{}, time = {:.3f}".format(n, len(mine), time.time() - t0))
-            name = sample["filename"]
-            save_pfm(os.path.join(args.outdir, name.format("depth_est", ".pfm")), np.squeeze(depth[0], 0))
-            save_pfm(os.path.join(args.outdir, name.format("confidence", ".pfm")), np.squeeze(conf[0], 0))
+            k = n % 2
+            d, c = out["depths_upsampled"], out["confidence_upsampled"]
+            if host[k] is None or host[k][0].shape != d.shape:
+                host[k] = (torch.empty(d.shape, dtype=d.dtype).pin_memory(), torch.empty(c.shape, dtype=c.dtype).pin_memory(),
+                           torch.zeros((1,), dtype=torch.int32).pin_memory())
+            host[k][0].copy_(d, non_blocking=True)
+            host[k][1].copy_(c, non_blocking=True)
+            flag = model.projection_flag()
+            if flag is not None:
+                host[k][2].copy_(flag, non_blocking=True)
+            events[k].record()
+            if prev is not None:
+                finish(prev)
+                done += 1
+            prev = (sample, k, n, t0)
+        if prev is not None:
+            finish(prev)
             done += 1
     shard.barrier()
     return done

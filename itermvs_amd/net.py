@@ -126,6 +126,12 @@ class Pipeline(nn.Module):
         if self._engine is not None:
             self._engine.check_projection_finite()
 
+    def projection_flag(self):
+        """the engine's device-side NaN flag (int32[1], OR-ed with 1 by every forward that composed a NaN projection;
+        module.py:83,87) or None before the first test-mode forward -- for drivers that download it with the results
+        instead of calling check_projection_finite() (which synchronises)"""
+        return None if self._engine is None else self._engine.nan_flag
+
     def _apply(self, fn, *a, **k):
         self.invalidate()
         return super()._apply(fn, *a, **k)
