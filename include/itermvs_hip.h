@@ -194,7 +194,8 @@ int itermvs_corr_init(const itermvs_corr_init_params* p, void* stream);
  *   grad_ref_q    [B,H,W,C1+C2+C3] dL/d ref_q, written completely.
  * itermvs_corr_init_backward: `p` = the forward's parameter block (p->ref must be channels-last here, N <= 32);
  *   grad_out      [B,S,N,8,H,W]  dL/d out;   grad_src: S device pointers as above (zero-filled);
- *   grad_ref      dL/d ref, addressed with the strides of p->ref, written completely.
+ *   grad_ref      dL/d ref, addressed with the strides of p->ref: ZERO-FILLED by the caller, accumulated into (several
+ *                 workgroups per pixel: one per view and chunk of 8 hypotheses).
  * ------------------------------------------------------------------------------------------ */
 int itermvs_corr_iter_backward(const itermvs_corr_iter_params* p, const float* const grad_out[3],
                                float* const* const grad_src[3], float* grad_ref_q, void* stream);

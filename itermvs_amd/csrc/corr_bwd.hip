@@ -11,12 +11,24 @@
 //     dL/dsrc_s[tap_t][c]  += E_s,n,g(c) / cpg * ref[c] * w_t                scatter-add, fp32 hardware atomics
 // No [B,C,N,H,W] warped volume exists in training either.
 //
-// Decomposition = the forward's "views across waves" form (corr.hip): a quad owns one (pixel, view); quad lane u projects
-// hypothesis hb+u once and the quad shares the footprint with DPP broadcasts; E is staged in LDS per chunk of views so every
-// lane can pick the group of each of its channels; dL/dref is accumulated in LDS (ds_add_f32) and stored once per block.
+// Decomposition.  The scatter is bound by the rate of atomic REQUESTS, not of lanes: MI355X retires ~21 G 64-byte atomic
+// segments per second whatever the collisions (tools/ubench/atomic_rate.hip: 84 G lane-atomics/s when a wave-instruction
+// touches 16 segments, 335 G/s when it touches 4 full ones; LDS float atomics ~200 G/s, so an LDS window in front of the
+// scatter loses).  Hence a ROW of 16 lanes owns one pixel and lane t of the row owns channel 16*blk + t of every
+// 16-channel block: each atomic instruction of a wave covers four complete 64-byte segments (one per row) -- the round-2
+// form (a quad per (pixel, view), a float4 of channels per lane, one channel per instruction) touched 16 segments of four
+// dwords and ran at exactly the 84 G/s figure (1.1-1.5 ms per launch at the cfg-4 shape).  All 16 lanes of a row project
+// the same (pixel, hypothesis) -- redundant arithmetic that is free under the atomic bound -- and walk the row's
+// (view, hypothesis) steps with the NEXT step's tap loads issued before the current step's atomics, so a wave never waits
+// for its own atomics (memory operations of a wave retire in order).  E is staged in LDS per chunk of views (iteration
+// branch) or per (view, 8 hypotheses) (initialisation branch: those units are spread over blockIdx.y, the machine needs
+// >= 8k waves in flight and 1/8-res maps have few pixels); dL/dref stays in registers (iteration: stored once) or is
+// added to the zero-filled gradient of the reference view (initialisation: several blocks per pixel).
 #include "corr_common.hpp"
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include <type_traits>
 
 namespace itermvs {
 
@@ -27,7 +39,7 @@ struct BwdLevel {
     const float* depth;             // explicit hypotheses [B,N,P] or nullptr
     const float* gout;              // iteration: [B,N,8,P]; initialisation: [B,S,N,8,P]
     const float* ref;               // reference features of this level, element (b, c, y, x) at b*rsb + c + y*rsy + x*rsx
-    float* gref;                    // same addressing as ref, written (not accumulated)
+    float* gref;                    // same addressing as ref; iteration: written, initialisation: accumulated (zero-filled by the caller)
     int64_t rsb, rsy, rsx;
     const float* proj;              // [B,S,12] of this level
     float offs[ITERMVS_MAX_HYP];
@@ -43,20 +55,32 @@ struct BwdArgs {
     const float* inv_max;
     int B, S, H, W;
     int init;                       // 1: initialisation branch (per-view gout, hypotheses uniform in inverse depth)
-    int vch;                        // views per chunk: 4 (N <= 8), 2 (N <= 16), 1 (N <= 32)
+    int vch;                        // iteration: views per staged chunk (vch * N <= 32)
+    int hyp_chunks;                 // initialisation: chunks of 8 hypotheses per view (grid.y = S * hyp_chunks)
 };
 
-constexpr int kBwdLdsE = 4 * ITERMVS_MAX_HYP * ITERMVS_GROUPS * (kVwTile + 1);   // staged E: vch * N * 8 rows
-constexpr int kBwdLdsFloats = kBwdLdsE + kVwTile * 49 + kVwTile;                   // + dL/dref [px][C+1] + wsum [px]
+constexpr int kBwdTile = 16;                                           // pixels per block = rows of 16 lanes
+constexpr int kBwdLS = kBwdTile + 1;
+constexpr int kBwdRows = 4 * ITERMVS_MAX_HYP * ITERMVS_GROUPS;         // staged E rows: (views) x (hypotheses) x 8 <= 256
+constexpr int kBwdLdsFloats = kBwdRows * kBwdLS + kBwdTile + ITERMVS_MAX_SRC * 12;   // + wsum [px] + the views' 3x4 matrices
+
+// one (view, hypothesis) of a row's pixel: tap offsets (elements, incl. the lane's channel), weights, the loaded taps
+template <int NB>
+struct BwdStep {
+    uint32_t o[4];
+    float w[4];
+    float tap[4 * NB];
+};
 
 template <int CPG, int FT>
 __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel& L, float* __restrict__ lds) {
-    using K = VwChunk<CPG>;
-    constexpr int TILE = kVwTile, LS = TILE + 1, C = 8 * CPG, CS = C + 1;
-    const int N = L.N, rows = N * ITERMVS_GROUPS;
-    float* __restrict__ e_lds = lds;                       // [vch][rows][LS]
-    float* __restrict__ gref_lds = lds + kBwdLdsE;         // [TILE][CS]
-    float* __restrict__ wsum_lds = gref_lds + TILE * 49;   // [TILE]
+    constexpr int TILE = kBwdTile, LS = kBwdLS, C = 8 * CPG, NB = C / 16;
+    const int N = L.N;
+    float* __restrict__ e_lds = lds;                            // [rows][LS]
+    float* __restrict__ wsum_lds = lds + kBwdRows * LS;         // [TILE]
+    float* __restrict__ m_lds = wsum_lds + TILE;                // [S][12]: read back with LDS broadcasts -- as vector loads
+                                                                // they would put a vmcnt(0) (= wait for every atomic in
+                                                                // flight) in front of each step
     const int b = blockIdx.z;
     const int P = a.H * a.W;
     const int tile = xcd_tile((P + TILE - 1) / TILE);
@@ -65,14 +89,17 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
     const WarpGeom g = make_geom(a.W, a.H, L.W1, L.H1);
     const WarpRcp rc = make_rcp(g);
     const float inv_min = a.inv_min[b], inv_max = a.inv_max[b];
-    const float* proj = L.proj + (size_t)b * a.S * 12;
     const uint32_t sy = (uint32_t)L.sy, sx = (uint32_t)L.sx;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int j = lane & 3;
-    const uint32_t joff = (uint32_t)(j * 4);
+    const int px = threadIdx.x >> 4, t = threadIdx.x & 15;     // row = pixel of the tile, lane of the row = channel of a block
     const float inv_cpg = CPG == 2 ? 0.5f : (CPG == 4 ? 0.25f : 1.0f / 6.0f);
 
-    for (int i = threadIdx.x; i < TILE * CS; i += kThreads) gref_lds[i] = 0.0f;
+    // the views and hypotheses of this block
+    int s_begin = 0, s_end = a.S, vch = a.vch, n0 = 0, nh = N;
+    if (a.init) {
+        s_begin = blockIdx.y / a.hyp_chunks; s_end = s_begin + 1; vch = 1;
+        n0 = (blockIdx.y % a.hyp_chunks) * 8; nh = min(8, N - n0);
+    }
+
     if (threadIdx.x < TILE) {
         float ws = 1e-5f;   // itermvs.py:88
         const int p = p0 + threadIdx.x;
@@ -80,108 +107,119 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
             for (int s = 0; s < a.S; ++s) ws = ws + a.view_w[((size_t)b * a.S + s) * P + p];
         wsum_lds[threadIdx.x] = ws;
     }
+    if (threadIdx.x < a.S * 12) m_lds[threadIdx.x] = L.proj[(size_t)b * a.S * 12 + threadIdx.x];
     __syncthreads();
 
-    const int hbn = (N + 3) / 4;   // hypothesis batches of 4
-    for (int s0 = 0; s0 < a.S; s0 += a.vch) {
-        const int sbc = min(a.vch, a.S - s0);
-        // E of this chunk -> LDS (already divided by the channels per group)
-        for (int i = threadIdx.x; i < sbc * rows * TILE; i += kThreads) {
-            const int px = i % TILE, r = (i / TILE) % rows, v = i / (TILE * rows);
-            const int p = p0 + px;
+    const int p = p0 + px;
+    const bool ok = p < P;
+    const int pc = ok ? p : P - 1;                              // rows past the end compute on the last pixel and add nothing
+    const int y = pc / a.W, x = pc - y * a.W;
+    const float xs = (float)x * g.xr, ys = (float)y * g.yr;
+    // the reference features: the fp32 ref_q pack (iteration) or the level-3 features themselves (initialisation)
+    const int64_t roff = (int64_t)b * L.rsb + (int64_t)y * L.rsy + (int64_t)x * L.rsx + t;
+    float refv[NB], gacc[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        refv[blk] = a.init ? ld_feat<FT>(L.ref, roff + 16 * blk) : L.ref[roff + 16 * blk];
+        gacc[blk] = 0.0f;
+    }
+    const float ndv = (!L.depth && !a.init) ? a.nd[b * a.nd_sb + pc] : 0.0f;
+
+    for (int s0 = s_begin; s0 < s_end; s0 += vch) {
+        const int sbc = min(vch, s_end - s0);
+        const int rows = sbc * nh * ITERMVS_GROUPS;
+        // E of this chunk -> LDS (already divided by the channels per group); row r = ((view, hypothesis), group)
+        for (int i = threadIdx.x; i < rows * TILE; i += kThreads) {
+            const int ipx = i % TILE, r = i / TILE;
+            const int gi = r % ITERMVS_GROUPS, hn = (r / ITERMVS_GROUPS) % nh, v = r / (ITERMVS_GROUPS * nh);
+            const int ip = p0 + ipx;
             float e = 0.0f;
-            if (p < P) {
+            if (ip < P) {
+                const int n = n0 + hn;
                 if (a.init) {
-                    e = L.gout[(((size_t)b * a.S + s0 + v) * rows + r) * P + p] * inv_cpg;
+                    e = L.gout[((((size_t)b * a.S + s0 + v) * N + n) * ITERMVS_GROUPS + gi) * P + ip] * inv_cpg;
                 } else {
-                    const float w = a.view_w[((size_t)b * a.S + s0 + v) * P + p];
-                    e = L.gout[((size_t)b * rows + r) * P + p] * (w / wsum_lds[px]) * inv_cpg;
+                    const float w = a.view_w[((size_t)b * a.S + s0 + v) * P + ip];
+                    e = L.gout[(((size_t)b * N + n) * ITERMVS_GROUPS + gi) * P + ip] * (w / wsum_lds[ipx]) * inv_cpg;
                 }
             }
-            e_lds[(v * rows + r) * LS + px] = e;
+            e_lds[r * LS + ipx] = e;
         }
         __syncthreads();
-#pragma unroll 1
-        for (int r = wave; r < sbc * hbn * 2; r += kThreads / 64) {
-            const int pb = r & 1, hbi = (r >> 1) % hbn, v = (r >> 1) / hbn;   // wave-uniform
-            const float* fb = feat_base<FT>(L.src[s0 + v], (int64_t)b * L.sb);
-            float* gb = L.gsrc[s0 + v] + (int64_t)b * L.sb;
-            const float* m = proj + (s0 + v) * 12;
-            const int px = pb * 16 + (lane >> 2);
-            const int p = p0 + px;
-            if (p < P) {   // whole quads drop out together
-                const int y = p / a.W, x = p - y * a.W;
-                float refv[K::VEC];
-                // the reference features: the fp32 ref_q pack (iteration) or the level-3 features themselves (initialisation)
-                const int64_t roff = (int64_t)b * L.rsb + (int64_t)y * L.rsy + (int64_t)x * L.rsx + j * 4;
-                if (a.init) load_feat<K::VEC, FT>(feat_base<FT>(L.ref, roff), 0u, refv);
-                else load_vec<K::VEC>(L.ref + roff, refv);
-                float rx, ry, rz;
-                ray_dir(m, (float)x * g.xr, (float)y * g.yr, rx, ry, rz);
-                const int hb = hbi * 4;
-                const int n_own = min(hb + j, N - 1);
-                float d;
-                if (L.depth) {
-                    d = L.depth[((size_t)b * N + n_own) * P + p];
-                } else if (a.init) {   // itermvs.py:13-17
-                    const float frac = (float)n_own / (float)(N - 1);
-                    d = 1.0f / (inv_max + frac * (inv_min - inv_max));
-                } else {               // itermvs.py:291-293
-                    float off = L.offs[0];
-#pragma unroll
-                    for (int k = 1; k < ITERMVS_MAX_HYP; ++k) off = (n_own == k) ? L.offs[k] : off;
-                    float ns = a.nd[b * a.nd_sb + p] + off;
-                    ns = fminf(fmaxf(ns, 0.0f), 1.0f);
-                    d = unnormalize_depth(ns, inv_min, inv_max);
-                }
-                float ix, iy;
-                project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
-                const Footprint f = make_footprint(ix, iy, L.W1, L.H1, sy, sx);
-                const uint32_t o00 = f.r0 + f.c0, o01 = f.r0 + f.c1, o10 = f.r1 + f.c0, o11 = f.r1 + f.c1;
-                float gacc[K::VEC];
-#pragma unroll
-                for (int c = 0; c < K::VEC; ++c) gacc[c] = 0.0f;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (hb + u < N) {   // uniform
-                        const uint32_t q00 = quad_bcast(o00, u) + joff, q01 = quad_bcast(o01, u) + joff;
-                        const uint32_t q10 = quad_bcast(o10, u) + joff, q11 = quad_bcast(o11, u) + joff;
-                        const float nw = quad_bcast(f.nw, u), ne = quad_bcast(f.ne, u), sw = quad_bcast(f.sw, u), se = quad_bcast(f.se, u);
-                        TapData<K::VEC> t;
-                        load_feat<K::VEC, FT>(fb, q00, t.v00);
-                        load_feat<K::VEC, FT>(fb, q01, t.v01);
-                        load_feat<K::VEC, FT>(fb, q10, t.v10);
-                        load_feat<K::VEC, FT>(fb, q11, t.v11);
-                        const float* __restrict__ er = e_lds + (v * rows + (hb + u) * ITERMVS_GROUPS) * LS + px;
-#pragma unroll
-                        for (int c = 0; c < K::VEC; ++c) {
-                            const int ch = 16 * (c / 4) + 4 * j + (c % 4);      // channel of element c (chunk layout of corr.hip)
-                            const float e = er[(ch / CPG) * LS];
-                            const float wv = fmaf(se, t.v11[c], fmaf(sw, t.v10[c], fmaf(ne, t.v01[c], nw * t.v00[c])));
-                            gacc[c] = fmaf(e, wv, gacc[c]);
-                            const float gs = e * refv[c];
-                            const uint32_t co = (uint32_t)(16 * (c / 4) + (c % 4));
-                            // taps outside the map carry weight 0 (their offsets were clamped to 0): nothing to add
-                            if (nw != 0.0f) unsafeAtomicAdd(gb + (q00 + co), gs * nw);
-                            if (ne != 0.0f) unsafeAtomicAdd(gb + (q01 + co), gs * ne);
-                            if (sw != 0.0f) unsafeAtomicAdd(gb + (q10 + co), gs * sw);
-                            if (se != 0.0f) unsafeAtomicAdd(gb + (q11 + co), gs * se);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < K::VEC; ++c)
-                    atomicAdd(&gref_lds[px * CS + 16 * (c / 4) + 4 * j + (c % 4)], gacc[c]);
+
+        // step k = (view k / nh, hypothesis n0 + k % nh): project, footprint, issue the tap loads
+        // (`explicit_depth`: hypotheses read from L.depth -- a compile-time flag of the step loop, because a vector load on one
+        // branch of the step makes the compiler drain vmcnt, i.e. every atomic in flight, where the branches join)
+        auto prepare = [&](int k, BwdStep<NB>& st, auto explicit_depth) {
+            const int v = k / nh, n = n0 + (k - v * nh);                       // block-uniform
+            const float* m = m_lds + (s0 + v) * 12;
+            float rx, ry, rz;
+            ray_dir(m, xs, ys, rx, ry, rz);
+            float d;
+            if constexpr (decltype(explicit_depth)::value) {
+                d = L.depth[((size_t)b * N + n) * P + pc];
+            } else if (a.init) {   // itermvs.py:13-17
+                const float frac = (float)n / (float)(N - 1);
+                d = 1.0f / (inv_max + frac * (inv_min - inv_max));
+            } else {               // itermvs.py:291-293
+                float ns = ndv + L.offs[n];
+                ns = fminf(fmaxf(ns, 0.0f), 1.0f);
+                d = unnormalize_depth(ns, inv_min, inv_max);
             }
+            float ix, iy;
+            project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
+            const Footprint f = make_footprint(ix, iy, L.W1, L.H1, sy, sx);
+            st.o[0] = f.r0 + f.c0 + (uint32_t)t; st.o[1] = f.r0 + f.c1 + (uint32_t)t;
+            st.o[2] = f.r1 + f.c0 + (uint32_t)t; st.o[3] = f.r1 + f.c1 + (uint32_t)t;
+            st.w[0] = f.nw; st.w[1] = f.ne; st.w[2] = f.sw; st.w[3] = f.se;
+            const float* fb = feat_base<FT>(L.src[s0 + v], (int64_t)b * L.sb);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) st.tap[4 * blk + tp] = ld_feat<FT>(fb, st.o[tp] + 16u * blk);
+        };
+        auto process = [&](int k, const BwdStep<NB>& st) {
+            const int v = k / nh;
+            float* gb = L.gsrc[s0 + v] + (int64_t)b * L.sb;
+            const float* __restrict__ er = e_lds + k * ITERMVS_GROUPS * LS + px;   // row block of (view, hypothesis) k
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const int ch = 16 * blk + t;
+                const float e = er[(ch / CPG) * LS];
+                const float wv = fmaf(st.w[3], st.tap[4 * blk + 3], fmaf(st.w[2], st.tap[4 * blk + 2],
+                                      fmaf(st.w[1], st.tap[4 * blk + 1], st.w[0] * st.tap[4 * blk])));
+                gacc[blk] = fmaf(e, wv, gacc[blk]);
+                const float gs = e * refv[blk];
+                // Unconditional: a tap outside the map (weight 0, offset clamped to pixel 0) adds +0 there.  A branch around
+                // the atomic would cost more than the rare wasted request: with a data-dependent number of atomics the
+                // compiler can only wait for the next step's taps with vmcnt(0), i.e. for every atomic in flight.
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp)
+                    unsafeAtomicAdd(gb + (st.o[tp] + 16u * blk), st.w[tp] != 0.0f ? gs * st.w[tp] : 0.0f);
+            }
+        };
+        auto walk = [&](auto explicit_depth) {
+            const int steps = sbc * nh;
+            BwdStep<NB> cur, nxt;
+            prepare(0, cur, explicit_depth);
+#pragma unroll 1
+            for (int k = 0; k < steps; ++k) {
+                if (k + 1 < steps) prepare(k + 1, nxt, explicit_depth);   // the next step's loads are in flight before this step's atomics
+                process(k, cur);
+                cur = nxt;
+            }
+        };
+        if (ok) {                                        // rows past the last pixel add nothing
+            if (L.depth) walk(std::true_type{});
+            else walk(std::false_type{});
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < TILE * C; i += kThreads) {
-        const int px = i / C, c = i - px * C;
-        const int p = p0 + px;
-        if (p < P) {
-            const int y = p / a.W, x = p - y * a.W;
-            L.gref[(int64_t)b * L.rsb + (int64_t)y * L.rsy + (int64_t)x * L.rsx + c] = gref_lds[px * CS + c];
+    if (ok) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            if (a.init) unsafeAtomicAdd(L.gref + roff + 16 * blk, gacc[blk]);
+            else L.gref[roff + 16 * blk] = gacc[blk];
         }
     }
 }
@@ -189,7 +227,7 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
 template <int FT>
 __global__ void __launch_bounds__(kThreads) corr_bwd_kernel(const BwdArgs a) {
     __shared__ float lds[kBwdLdsFloats];
-    const BwdLevel& L = a.lv[blockIdx.y];
+    const BwdLevel& L = a.lv[a.init ? 0 : blockIdx.y];
     switch (L.C) {
         case 16: corr_bwd_level<2, FT>(a, L, lds); break;
         case 32: corr_bwd_level<4, FT>(a, L, lds); break;
@@ -252,10 +290,10 @@ extern "C" int itermvs_corr_iter_backward(const itermvs_corr_iter_params* p, con
     }
     a.view_w = p->view_w; a.nd = p->norm_depth; a.nd_sb = p->norm_depth_sb;
     a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max;
-    a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.init = 0; a.vch = 4;
+    a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.init = 0; a.vch = 4; a.hyp_chunks = 1;
     const int P = p->H * p->W;
     ITERMVS_RETURN_IF(p->src[1].dtype != p->src[0].dtype || p->src[2].dtype != p->src[0].dtype, ITERMVS_ERR_DTYPE);
-    return launch_bwd(a, p->src[0].dtype, dim3((((P + kVwTile - 1) / kVwTile + 7) / 8) * 8, 3, p->B), (hipStream_t)stream);
+    return launch_bwd(a, p->src[0].dtype, dim3((((P + kBwdTile - 1) / kBwdTile + 7) / 8) * 8, 3, p->B), (hipStream_t)stream);
 }
 
 extern "C" int itermvs_corr_init_backward(const itermvs_corr_init_params* p, const float* grad_out, float* const* grad_src,
@@ -282,8 +320,8 @@ extern "C" int itermvs_corr_init_backward(const itermvs_corr_init_params* p, con
     a.view_w = nullptr; a.nd = nullptr; a.nd_sb = 0;
     a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max;
     a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.init = 1;
-    a.vch = p->N <= 8 ? 4 : (p->N <= 16 ? 2 : 1);
+    a.vch = 1; a.hyp_chunks = (p->N + 7) / 8;
     const int P = p->H * p->W;
     ITERMVS_RETURN_IF(p->ref.dtype != p->src.dtype, ITERMVS_ERR_DTYPE);
-    return launch_bwd(a, p->src.dtype, dim3((((P + kVwTile - 1) / kVwTile + 7) / 8) * 8, 1, p->B), (hipStream_t)stream);
+    return launch_bwd(a, p->src.dtype, dim3((((P + kBwdTile - 1) / kBwdTile + 7) / 8) * 8, p->S * a.hyp_chunks, p->B), (hipStream_t)stream);
 }

@@ -304,20 +304,6 @@ struct IterArgs {
     int B, S, H, W, CQ;
 };
 
-constexpr int kVwTile = 32;   // pixels per block of the gradient kernel (corr_bwd.hip)
-constexpr int kVwViews = 4;   // views per chunk (= waves per block)
-
-// Gradient kernel (corr_bwd.hip): every level uses 4 lanes (one quad) per (pixel, view): lane j owns the float4 at channel 4j of every 16-channel block
-// (C=16: 1 block, C=32: 2, C=48: 3), so each load instruction of the quad covers one contiguous 64-byte run and one tap
-// address serves VEC/4 loads.  Two correlation groups are finalised per lane.
-template <int CPG>
-struct VwChunk {
-    static constexpr int VEC = 2 * CPG;   // floats per lane: 4 / 8 / 12
-    static constexpr int NG = 2;
-    // correlation group of result q of lane j
-    static __device__ __forceinline__ int group(int j, int q) { return CPG == 4 ? j + 4 * q : 2 * j + q; }
-};
-
 }  // namespace itermvs
 
 // argument checks shared by the forward and backward entry points

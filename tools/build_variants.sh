@@ -18,7 +18,7 @@ for w in ${LB_VARIANTS:-}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_w$w.o -o $V/libitermvs_w$w.so
 done
 # tw8 / tw32: the fused correlation kernels with 8 x 4 / 32 x 1 pixel tiles (default: 16 x 2)
-for tw in ${TW_VARIANTS:-8 32}; do
+for tw in ${TW_VARIANTS-8 32}; do
   /opt/rocm/bin/hipcc $FLAGS -DITERMVS_CORR_TW=$tw -I$C -c $C/corr.hip -o $T/corr_tw$tw.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_tw$tw.o -o $V/libitermvs_tw$tw.so
 done
@@ -28,4 +28,24 @@ if [ "${TUNING_LIB:-0}" = "1" ]; then
   for f in $C/*.hip; do b=$(basename $f .hip); /opt/rocm/bin/hipcc $FLAGS -DITERMVS_TUNING -I$C -c $f -o $T/tuning/$b.o & done; wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $T/tuning/*.o -o $V/libitermvs_tuning.so
 fi
-ls -la $V
+
+# bwd: corr_bwd.hip with other -D switches, e.g. BWD_VARIANTS="qt:-DITERMVS_BWD_QT=1"
+for spec in ${BWD_VARIANTS:-}; do
+  name=${spec%%:*}; defs=$(echo "${spec#*:}" | tr ',' ' ')
+  /opt/rocm/bin/hipcc $FLAGS $defs -I$C -c $C/corr_bwd.hip -o $T/corr_bwd_$name.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/*.o | grep -v "/corr_bwd.o") $T/corr_bwd_$name.o -o $V/libitermvs_bwd_$name.so
+done
+ls $V
+# bwd diagnostics (sed-made copies of corr_bwd.hip; results are WRONG, timing only):
+#   BWD_DIAG="noatomic noload wg8"   scatter without the atomics / without the tap loads / 8 workgroups per CU (<= 64 VGPRs)
+for d in ${BWD_DIAG:-}; do
+  case $d in
+    noatomic) sed 's|unsafeAtomicAdd(gb + (st.o\[tp\] + 16u \* blk), \(.*\));|{ float keep_ = \1; asm volatile("" :: "v"(keep_), "v"(st.o[tp])); }|' $C/corr_bwd.hip > $T/corr_bwd_$d.hip ;;
+    noload)   sed 's|st.tap\[4 \* blk + tp\] = ld_feat<FT>(fb, st.o\[tp\] + 16u \* blk);|st.tap[4 * blk + tp] = __int_as_float((int)st.o[tp]);|' $C/corr_bwd.hip > $T/corr_bwd_$d.hip ;;
+    wg[0-9])  sed "s|__launch_bounds__(kThreads) corr_bwd_kernel|__launch_bounds__(kThreads, ${d#wg}) corr_bwd_kernel|" $C/corr_bwd.hip > $T/corr_bwd_$d.hip ;;
+  esac
+  cmp -s $C/corr_bwd.hip $T/corr_bwd_$d.hip && { echo "variant $d: sed matched nothing"; exit 1; }
+  /opt/rocm/bin/hipcc $FLAGS -I$C -c $T/corr_bwd_$d.hip -o $T/corr_bwd_$d.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/*.o | grep -v "/corr_bwd.o") $T/corr_bwd_$d.o -o $V/libitermvs_bwd_$d.so
+done
+ls $V
