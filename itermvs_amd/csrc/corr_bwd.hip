@@ -57,6 +57,7 @@ struct BwdArgs {
     int init;                       // 1: initialisation branch (per-view gout, hypotheses uniform in inverse depth)
     int vch;                        // iteration: views per staged chunk (vch * N <= 32)
     int hyp_chunks;                 // initialisation: chunks of 8 hypotheses per view (grid.y = S * hyp_chunks)
+    int scatter;                    // 0: dL/dref only -- dL/dsrc comes from init_gather_kernel (plane hypotheses)
 };
 
 constexpr int kBwdTile = 16;                                           // pixels per block = rows of 16 lanes
@@ -178,7 +179,7 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
 #pragma unroll
                 for (int tp = 0; tp < 4; ++tp) st.tap[4 * blk + tp] = ld_feat<FT>(fb, st.o[tp] + 16u * blk);
         };
-        auto process = [&](int k, const BwdStep<NB>& st) {
+        auto process = [&](int k, const BwdStep<NB>& st, auto scatter) {
             const int v = k / nh;
             float* gb = L.gsrc[s0 + v] + (int64_t)b * L.sb;
             const float* __restrict__ er = e_lds + k * ITERMVS_GROUPS * LS + px;   // row block of (view, hypothesis) k
@@ -189,6 +190,7 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
                 const float wv = fmaf(st.w[3], st.tap[4 * blk + 3], fmaf(st.w[2], st.tap[4 * blk + 2],
                                       fmaf(st.w[1], st.tap[4 * blk + 1], st.w[0] * st.tap[4 * blk])));
                 gacc[blk] = fmaf(e, wv, gacc[blk]);
+                if constexpr (!decltype(scatter)::value) continue;      // dL/dref only (the gather kernel below does dL/dsrc)
                 const float gs = e * refv[blk];
                 // Unconditional: a tap outside the map (weight 0, offset clamped to pixel 0) adds +0 there.  A branch around
                 // the atomic would cost more than the rare wasted request: with a data-dependent number of atomics the
@@ -198,20 +200,21 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
                     unsafeAtomicAdd(gb + (st.o[tp] + 16u * blk), st.w[tp] != 0.0f ? gs * st.w[tp] : 0.0f);
             }
         };
-        auto walk = [&](auto explicit_depth) {
+        auto walk = [&](auto explicit_depth, auto scatter) {
             const int steps = sbc * nh;
             BwdStep<NB> cur, nxt;
             prepare(0, cur, explicit_depth);
 #pragma unroll 1
             for (int k = 0; k < steps; ++k) {
                 if (k + 1 < steps) prepare(k + 1, nxt, explicit_depth);   // the next step's loads are in flight before this step's atomics
-                process(k, cur);
+                process(k, cur, scatter);
                 cur = nxt;
             }
         };
         if (ok) {                                        // rows past the last pixel add nothing
-            if (L.depth) walk(std::true_type{});
-            else walk(std::false_type{});
+            if (L.depth) walk(std::true_type{}, std::true_type{});
+            else if (a.scatter) walk(std::false_type{}, std::true_type{});
+            else walk(std::false_type{}, std::false_type{});
         }
         __syncthreads();
     }
@@ -235,6 +238,152 @@ __global__ void __launch_bounds__(kThreads) corr_bwd_kernel(const BwdArgs a) {
     }
 }
 
+// ---- initialisation branch, generated hypotheses: dL/dsrc WITHOUT atomics -------------------------------------------------
+// The 32 hypotheses of the initialisation branch are fronto-parallel planes (itermvs.py:11-19: one depth per index, every
+// pixel), so for a (view, plane) the warp ref -> src is a homography G_n = K (d_n R D + t e3^T) (R | t = the 3x4 matrix of
+// the view, D = diag(W1/W, H1/H, 1), K = the grid_sample un-normalisation) -- and it can be inverted: a source pixel q
+// receives bilinear weight only from reference pixels whose image lies in the open square q +- 1, i.e. inside the
+// quadrilateral G_n^-1(square).  A ROW of 16 lanes owns one source pixel of one view: per plane it maps the corners of
+// the square grown to +-1.02 back to the reference grid, takes the integer bounding box (typically 3x3..4x4 pixels; the
+// growth and a +-0.02 pad absorb the rounding of the inverse -- ~1e-4 pixels, G_n^-1 is formed in fp64 --, the projective pre-image of a convex set that does not
+// cross the line at infinity is convex), lets lane t FORWARD-project candidate t with exactly the arithmetic of the scatter
+// (ray_dir / project_fast / make_taps) and keeps the candidates whose footprint really contains q; the survivors' E * ref
+// * weight are summed over channels (lane t = channel 16 blk + t) and planes in registers and stored once: no atomics,
+// no collisions, a deterministic result.  If the corners' denominators change sign (the plane's vanishing line crosses the
+// square) or G_n is singular, the row scans the whole reference grid for that plane -- slow, exact.
+// The scatter form above (1.07 ms at the cfg-4 shape: 126 M lane-atomics on few, heavily shared addresses) remains for
+// explicit per-pixel hypotheses; for generated ones it only computes dL/dref.
+template <int CPG, int FT>
+__device__ __forceinline__ void init_gather_level(const BwdArgs& a, const BwdLevel& L, float* __restrict__ lds) {
+    constexpr int C = 8 * CPG, NB = C / 16;
+    const int N = L.N, b = blockIdx.z, s = blockIdx.y;
+    const int P = a.H * a.W, P1 = L.H1 * L.W1;
+    const int q0 = xcd_tile((P1 + 15) / 16) * 16;
+    if (q0 >= P1) return;
+    const WarpGeom g = make_geom(a.W, a.H, L.W1, L.H1);
+    const WarpRcp rc = make_rcp(g);
+    const float inv_min = a.inv_min[b], inv_max = a.inv_max[b];
+    const float inv_cpg = CPG == 2 ? 0.5f : (CPG == 4 ? 0.25f : 1.0f / 6.0f);
+    float* __restrict__ ginv = lds;                        // [N][12]: G_n^-1 row-major, [9] = usable flag
+    float* __restrict__ m = lds + 32 * 12;                 // the view's 3x4 matrix
+    if (threadIdx.x < 12) m[threadIdx.x] = L.proj[((size_t)b * a.S + s) * 12 + threadIdx.x];
+    __syncthreads();
+    if ((int)threadIdx.x < N) {
+        const int n = threadIdx.x;
+        const float frac = (float)n / (float)(N - 1);
+        const double d = (double)(1.0f / (inv_max + frac * (inv_min - inv_max)));
+        const double kx = (double)g.w1m1 * 0.5 / (double)g.half_w, ky = (double)g.h1m1 * 0.5 / (double)g.half_h;
+        double G[9];
+        for (int r = 0; r < 3; ++r) {
+            const double k = r == 0 ? kx : (r == 1 ? ky : 1.0);
+            G[3 * r + 0] = k * d * (double)m[4 * r + 0] * (double)g.xr;
+            G[3 * r + 1] = k * d * (double)m[4 * r + 1] * (double)g.yr;
+            G[3 * r + 2] = k * (d * (double)m[4 * r + 2] + (double)m[4 * r + 3]);
+        }
+        const double c0 = G[4] * G[8] - G[5] * G[7], c1 = G[5] * G[6] - G[3] * G[8], c2 = G[3] * G[7] - G[4] * G[6];
+        const double det = G[0] * c0 + G[1] * c1 + G[2] * c2;
+        double nrm = 0.0;
+        for (int i = 0; i < 9; ++i) nrm += G[i] * G[i];
+        const bool usable = det == det && fabs(det) > 1e-13 * nrm * sqrt(nrm);
+        const double id = usable ? 1.0 / det : 0.0;
+        float* o = ginv + n * 12;
+        o[0] = (float)(c0 * id); o[1] = (float)((G[2] * G[7] - G[1] * G[8]) * id); o[2] = (float)((G[1] * G[5] - G[2] * G[4]) * id);
+        o[3] = (float)(c1 * id); o[4] = (float)((G[0] * G[8] - G[2] * G[6]) * id); o[5] = (float)((G[2] * G[3] - G[0] * G[5]) * id);
+        o[6] = (float)(c2 * id); o[7] = (float)((G[1] * G[6] - G[0] * G[7]) * id); o[8] = (float)((G[0] * G[4] - G[1] * G[3]) * id);
+        o[9] = usable ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, t = lane & 15, rowbase = lane & 48;
+    const int q = q0 + (threadIdx.x >> 4);
+    const bool ok = q < P1;
+    const int qc = ok ? q : P1 - 1;
+    const int v = qc / L.W1, u = qc - v * L.W1;            // the source pixel of this row
+    const float* __restrict__ gout = L.gout + ((size_t)b * a.S + s) * N * ITERMVS_GROUPS * P;
+    float acc[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) acc[blk] = 0.0f;
+
+#pragma unroll 1
+    for (int n = 0; n < N; ++n) {
+        const float* gi = ginv + n * 12;
+        const float frac = (float)n / (float)(N - 1);       // itermvs.py:13-17, the forward kernel's expression
+        const float d = 1.0f / (inv_max + frac * (inv_min - inv_max));
+        // the square's pre-image on the reference grid
+        bool reg = gi[9] != 0.0f;
+        float minx = 3.0e38f, maxx = -3.0e38f, miny = 3.0e38f, maxy = -3.0e38f, w2_first = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float cx = (float)u + ((c & 1) ? 1.02f : -1.02f), cy = (float)v + ((c & 2) ? 1.02f : -1.02f);
+            const float w0 = fmaf(gi[0], cx, fmaf(gi[1], cy, gi[2]));
+            const float w1 = fmaf(gi[3], cx, fmaf(gi[4], cy, gi[5]));
+            const float w2 = fmaf(gi[6], cx, fmaf(gi[7], cy, gi[8]));
+            if (c == 0) w2_first = w2;
+            reg = reg && (w2 * w2_first > 0.0f) && fabsf(w2) > 1e-6f * (fabsf(w0) + fabsf(w1) + fabsf(w2));
+            const float x = w0 / w2, y = w1 / w2;
+            minx = fminf(minx, x); maxx = fmaxf(maxx, x); miny = fminf(miny, y); maxy = fmaxf(maxy, y);
+        }
+        reg = reg && minx > -1.0e6f && maxx < 1.0e6f && miny > -1.0e6f && maxy < 1.0e6f;     // also false for NaN
+        int x_lo = 0, x_hi = a.W - 1, y_lo = 0, y_hi = a.H - 1;
+        if (reg) {
+            x_lo = max(0, (int)floorf(minx - 0.02f)); x_hi = min(a.W - 1, (int)ceilf(maxx + 0.02f));
+            y_lo = max(0, (int)floorf(miny - 0.02f)); y_hi = min(a.H - 1, (int)ceilf(maxy + 0.02f));
+        }
+        const int nx = max(x_hi - x_lo + 1, 0), ny = max(y_hi - y_lo + 1, 0);
+        const int nc = ok ? nx * ny : 0;
+        for (int k0 = 0; __any(k0 < nc); k0 += 16) {        // candidates, 16 per round and row
+            const int idx = k0 + t;
+            const int iy_ = idx / max(nx, 1), ix_ = idx - iy_ * max(nx, 1);
+            const int cx = x_lo + ix_, cy = min(y_lo + iy_, a.H - 1);
+            float rx, ry, rz, sx_, sy_;
+            ray_dir(m, (float)cx * g.xr, (float)cy * g.yr, rx, ry, rz);
+            project_fast(g, rc, m, rx, ry, rz, d, sx_, sy_);
+            const Taps tp = make_taps(sx_, sy_, L.W1, L.H1);
+            float wq = 0.0f;                                 // the weight this candidate gives to (u, v); zero-weight taps are clamped to 0
+            wq += (tp.x0 == u && tp.y0 == v) ? tp.nw : 0.0f;
+            wq += (tp.x1 == u && tp.y0 == v) ? tp.ne : 0.0f;
+            wq += (tp.x0 == u && tp.y1 == v) ? tp.sw : 0.0f;
+            wq += (tp.x1 == u && tp.y1 == v) ? tp.se : 0.0f;
+            if (idx >= nc) wq = 0.0f;
+            unsigned rowmask = (unsigned)(__ballot(wq != 0.0f) >> rowbase) & 0xffffu;
+            while (__any(rowmask != 0u)) {                   // contributing candidates of the row, one per round
+                const bool act = rowmask != 0u;
+                const int src_lane = rowbase + (act ? __ffs(rowmask) - 1 : 0);
+                rowmask &= rowmask - 1u;
+                const float wv = __shfl(wq, src_lane, 64);
+                const int px_ = __shfl(cx, src_lane, 64), py_ = __shfl(cy, src_lane, 64);
+                if (act) {
+                    const int pc = py_ * a.W + px_;
+                    const int64_t roff = (int64_t)b * L.rsb + (int64_t)py_ * L.rsy + (int64_t)px_ * L.rsx + t;
+#pragma unroll
+                    for (int blk = 0; blk < NB; ++blk) {
+                        const int ch = 16 * blk + t;
+                        const float e = gout[((size_t)n * ITERMVS_GROUPS + ch / CPG) * P + pc] * inv_cpg;
+                        const float r = ld_feat<FT>(L.ref, roff + 16 * blk);
+                        acc[blk] = fmaf(e * r, wv, acc[blk]);
+                    }
+                }
+            }
+        }
+    }
+    if (ok) {
+        float* __restrict__ gb = L.gsrc[s] + (int64_t)b * L.sb + (int64_t)v * L.sy + (int64_t)u * L.sx + t;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) gb[16 * blk] += acc[blk];      // this row is the only writer of the pixel
+    }
+}
+
+template <int FT>
+__global__ void __launch_bounds__(kThreads) init_gather_kernel(const BwdArgs a) {
+    __shared__ float lds[33 * 12];
+    const BwdLevel& L = a.lv[0];
+    switch (L.C) {
+        case 16: init_gather_level<2, FT>(a, L, lds); break;
+        case 32: init_gather_level<4, FT>(a, L, lds); break;
+        default: init_gather_level<6, FT>(a, L, lds); break;
+    }
+}
+
 }  // namespace itermvs
 
 using namespace itermvs;
@@ -244,6 +393,16 @@ static int launch_bwd(const BwdArgs& a, int dtype, dim3 grid, hipStream_t stream
         case ITERMVS_F32: hipLaunchKernelGGL(corr_bwd_kernel<ITERMVS_F32>, grid, dim3(kThreads), 0, stream, a); break;
         case ITERMVS_F16: hipLaunchKernelGGL(corr_bwd_kernel<ITERMVS_F16>, grid, dim3(kThreads), 0, stream, a); break;
         case ITERMVS_BF16: hipLaunchKernelGGL(corr_bwd_kernel<ITERMVS_BF16>, grid, dim3(kThreads), 0, stream, a); break;
+        default: return ITERMVS_ERR_DTYPE;
+    }
+    return itermvs_launch_status();
+}
+
+static int launch_gather(const BwdArgs& a, int dtype, dim3 grid, hipStream_t stream) {
+    switch (dtype) {
+        case ITERMVS_F32: hipLaunchKernelGGL(init_gather_kernel<ITERMVS_F32>, grid, dim3(kThreads), 0, stream, a); break;
+        case ITERMVS_F16: hipLaunchKernelGGL(init_gather_kernel<ITERMVS_F16>, grid, dim3(kThreads), 0, stream, a); break;
+        case ITERMVS_BF16: hipLaunchKernelGGL(init_gather_kernel<ITERMVS_BF16>, grid, dim3(kThreads), 0, stream, a); break;
         default: return ITERMVS_ERR_DTYPE;
     }
     return itermvs_launch_status();
@@ -290,7 +449,7 @@ extern "C" int itermvs_corr_iter_backward(const itermvs_corr_iter_params* p, con
     }
     a.view_w = p->view_w; a.nd = p->norm_depth; a.nd_sb = p->norm_depth_sb;
     a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max;
-    a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.init = 0; a.vch = 4; a.hyp_chunks = 1;
+    a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.init = 0; a.vch = 4; a.hyp_chunks = 1; a.scatter = 1;
     const int P = p->H * p->W;
     ITERMVS_RETURN_IF(p->src[1].dtype != p->src[0].dtype || p->src[2].dtype != p->src[0].dtype, ITERMVS_ERR_DTYPE);
     return launch_bwd(a, p->src[0].dtype, dim3((((P + kBwdTile - 1) / kBwdTile + 7) / 8) * 8, 3, p->B), (hipStream_t)stream);
@@ -321,7 +480,11 @@ extern "C" int itermvs_corr_init_backward(const itermvs_corr_init_params* p, con
     a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max;
     a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.init = 1;
     a.vch = 1; a.hyp_chunks = (p->N + 7) / 8;
+    a.scatter = p->depth ? 1 : 0;      // generated hypotheses are planes: dL/dsrc by the atomic-free gather
     const int P = p->H * p->W;
     ITERMVS_RETURN_IF(p->ref.dtype != p->src.dtype, ITERMVS_ERR_DTYPE);
-    return launch_bwd(a, p->src.dtype, dim3((((P + kBwdTile - 1) / kBwdTile + 7) / 8) * 8, p->S * a.hyp_chunks, p->B), (hipStream_t)stream);
+    const int rc2 = launch_bwd(a, p->src.dtype, dim3((((P + kBwdTile - 1) / kBwdTile + 7) / 8) * 8, p->S * a.hyp_chunks, p->B), (hipStream_t)stream);
+    if (rc2 || a.scatter) return rc2;
+    const int P1 = p->src.H * p->src.W;
+    return launch_gather(a, p->src.dtype, dim3((((P1 + 15) / 16 + 7) / 8) * 8, p->S, p->B), (hipStream_t)stream);
 }

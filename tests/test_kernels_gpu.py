@@ -351,11 +351,24 @@ def test_corr_iter_backward_matches_autograd(b, v, dtype):
     assert maxdiff(rq.grad, ref_q.grad) <= 1e-4 * max(1.0, float(ref_q.grad.abs().max()))
 
 
+@pytest.mark.parametrize("cams", ["regular", "vanishing_line", "singular"])
 @pytest.mark.parametrize("b,v", [(1, 3), (2, 5)])
-def test_corr_init_backward_matches_autograd(b, v):
-    """itermvs_corr_init_backward vs autograd through the oracle (itermvs.py:48-51), 32 hypotheses uniform in inverse depth"""
+def test_corr_init_backward_matches_autograd(b, v, cams):
+    """itermvs_corr_init_backward vs autograd through the oracle (itermvs.py:48-51), 32 hypotheses uniform in inverse depth.
+    The gradient to the source views comes from the atomic-free gather through each plane's inverse homography
+    (csrc/corr_bwd.hip: init_gather_kernel); ``vanishing_line`` gives the first source view a camera whose depth changes
+    sign in the middle of the image (module.py:105-108 sends those pixels outside); ``singular`` gives it three identical
+    matrix rows (every reference pixel lands on source pixel (1, 1): no inverse homography exists and that kernel must fall
+    back to scanning the reference grid)."""
     h, w = 24, 40
     gen, feats, sizes, chans, p12, inv_min, inv_max = _bwd_case(b, v, h, w, 9)
+    if cams == "vanishing_line":
+        p12 = p12.clone()
+        p12[2][:, 0, 8] = -0.1            # Z = d * (-0.1 x + ..) + t_z: zero near x = 10 of the 20 columns
+    if cams == "singular":
+        p12 = p12.clone()
+        p12[2][:, 0, 0:4] = p12[2][:, 0, 8:12]
+        p12[2][:, 0, 4:8] = p12[2][:, 0, 8:12]
     f3 = feats[3]
     h3, w3 = sizes[3]
     depth = O.initial_depth_samples(inv_min.view(b, 1, 1, 1), inv_max.view(b, 1, 1, 1), h3, w3)
