@@ -37,11 +37,13 @@ for spec in ${BWD_VARIANTS:-}; do
 done
 ls $V
 # bwd diagnostics (sed-made copies of corr_bwd.hip; results are WRONG, timing only):
-#   BWD_DIAG="noatomic noload wg8"   scatter without the atomics / without the tap loads / 8 workgroups per CU (<= 64 VGPRs)
+#   BWD_DIAG="noatomic noload noalu wg6"   scatter without the atomics / without the tap loads / with a trivial footprint
+#                                          instead of the projection / 6 workgroups per CU
 for d in ${BWD_DIAG:-}; do
   case $d in
     noatomic) sed 's|unsafeAtomicAdd(gb + (st.o\[tp\] + 16u \* blk), \(.*\));|{ float keep_ = \1; asm volatile("" :: "v"(keep_), "v"(st.o[tp])); }|' $C/corr_bwd.hip > $T/corr_bwd_$d.hip ;;
     noload)   sed 's|st.tap\[4 \* blk + tp\] = ld_feat<FT>(fb, st.o\[tp\] + 16u \* blk);|st.tap[4 * blk + tp] = __int_as_float((int)st.o[tp]);|' $C/corr_bwd.hip > $T/corr_bwd_$d.hip ;;
+    noalu)    sed 's|^            project_fast(g, rc, m, rx, ry, rz, d, ix, iy);$|            ix = xs + 1.7f * (float)n; iy = ys + 0.3f; (void)d; (void)rx;|' $C/corr_bwd.hip > $T/corr_bwd_$d.hip ;;
     wg[0-9])  sed "s|__launch_bounds__(kThreads) corr_bwd_kernel|__launch_bounds__(kThreads, ${d#wg}) corr_bwd_kernel|" $C/corr_bwd.hip > $T/corr_bwd_$d.hip ;;
   esac
   cmp -s $C/corr_bwd.hip $T/corr_bwd_$d.hip && { echo "variant $d: sed matched nothing"; exit 1; }
