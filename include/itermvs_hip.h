@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ITERMVS_ABI_VERSION 5
+#define ITERMVS_ABI_VERSION 6
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -426,6 +426,23 @@ int itermvs_fuse_depth(const float* depth_ref, const float* conf_ref, const floa
  * ------------------------------------------------------------------------------------------ */
 int itermvs_image_pyramid(const uint8_t* src, int32_t V, int32_t Hs, int32_t Ws, int32_t H, int32_t W, float* level0,
                           float* level1, float* level2, float* level3, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm (+ ReLU) of FeatureNet's ConvBnReLU / ConvBn layers (models/module.py:33-50 under
+ * train.py:194-243; torch.nn.BatchNorm2d in train() mode): x, y, dy, dx are dense NCHW fp32 [N,C,H*W].
+ *   forward : batch mean / biased variance per channel -> y = [relu]((x - mean) / sqrt(var + eps) * gamma + beta);
+ *             save_mean, save_invstd [C] are written for the backward; running_mean / running_var (may be NULL) are
+ *             updated in place with `momentum` (running_var with the unbiased variance, like torch).
+ *   backward: dx, dgamma, dbeta from dy (the gradient w.r.t. y; the ReLU mask is recomputed from x).
+ * `workspace`: itermvs_bn_workspace_floats(N, C, HW) floats of scratch (partials; same size for both directions).
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_bn_workspace_floats(int32_t N, int32_t C, int32_t HW);
+int itermvs_bn_train_forward(const float* x, float* y, int32_t N, int32_t C, int32_t HW, const float* gamma, const float* beta,
+                             float eps, float momentum, int32_t relu, float* running_mean, float* running_var,
+                             float* save_mean, float* save_invstd, float* workspace, void* stream);
+int itermvs_bn_train_backward(const float* x, const float* dy, float* dx, int32_t N, int32_t C, int32_t HW, const float* gamma,
+                              const float* beta, const float* save_mean, const float* save_invstd, int32_t relu,
+                              float* dgamma, float* dbeta, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optional per-launch timing (HIP events recorded on the launch stream around the kernels of

@@ -373,6 +373,71 @@ def corr_init_train(f3: Tensor, b: int, v: int, proj: Tensor, inv_min: Tensor, i
     return _CorrInitFn.apply(f3, _dev(proj, "proj").contiguous(), inv_min, inv_max, num_samples, b, v, s3)
 
 
+class _BnReluTrainFn(torch.autograd.Function):
+    """torch.nn.BatchNorm2d in train() mode (+ ReLU) as one op on the HIP kernels of csrc/bn.hip -- the ConvBnReLU / ConvBn
+    layers of FeatureNet under training (models/module.py:33-50): batch statistics, running stats updated in place, the
+    ReLU mask recomputed from x in the backward (nothing but x, two [C] vectors and the affine parameters is saved)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        n, c = x.shape[0], x.shape[1]
+        hw = x.numel() // (n * c)
+        lib = _lib.load()
+        ws = torch.empty((check_count(lib.itermvs_bn_workspace_floats(n, c, hw), "itermvs_bn_workspace_floats"),), device=x.device,
+                         dtype=torch.float32)
+        y = torch.empty_like(x)
+        mean = torch.empty((c,), device=x.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        check(lib.itermvs_bn_train_forward(x.data_ptr(), y.data_ptr(), n, c, hw, gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                           float(momentum), int(relu), _ptr(running_mean), _ptr(running_var), mean.data_ptr(),
+                                           invstd.data_ptr(), ws.data_ptr(), _stream()), "itermvs_bn_train_forward")
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.relu = int(relu)
+        for t in (running_mean, running_var):       # written by the kernel: tell autograd's version counters
+            if t is not None:                       # (itermvs_amd.net invalidates its packed inference engine on them)
+                torch.autograd.graph.increment_version(t)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        n, c = x.shape[0], x.shape[1]
+        hw = x.numel() // (n * c)
+        lib = _lib.load()
+        dy = dy.contiguous()
+        ws = torch.empty((check_count(lib.itermvs_bn_workspace_floats(n, c, hw), "itermvs_bn_workspace_floats"),), device=x.device,
+                         dtype=torch.float32)
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        check(lib.itermvs_bn_train_backward(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, c, hw, gamma.data_ptr(), beta.data_ptr(),
+                                            mean.data_ptr(), invstd.data_ptr(), ctx.relu, dgamma.data_ptr(), dbeta.data_ptr(),
+                                            ws.data_ptr(), _stream()), "itermvs_bn_train_backward")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def check_count(value: int, what: str) -> int:
+    """a C entry point that returns a non-negative count or a negative error code"""
+    if value < 0:
+        check(value, what)
+    return value
+
+
+def bn_relu_train(x: Tensor, gamma: Tensor, beta: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor],
+                  eps: float = 1e-5, momentum: float = 0.1, relu: bool = True) -> Tensor:
+    """``relu(F.batch_norm(x, running_mean, running_var, gamma, beta, training=True, momentum, eps))`` (``relu=False``: without
+    the ReLU) on dense NCHW fp32 ``x``; differentiable w.r.t. x, gamma, beta; the running statistics are updated in place."""
+    x = _dev(x, "x")
+    if x.dim() < 2:
+        raise RuntimeError("bn_relu_train: expected [N,C,...]")
+    for t, name in ((gamma, "gamma"), (beta, "beta")):
+        if _dev(t, name).shape != (x.shape[1],):
+            raise RuntimeError(f"bn_relu_train: {name} must have shape [{x.shape[1]}]")
+    for t, name in ((running_mean, "running_mean"), (running_var, "running_var")):
+        if t is not None and (_dev(t, name).shape != (x.shape[1],) or not t.is_contiguous()):
+            raise RuntimeError(f"bn_relu_train: {name} must be a contiguous [{x.shape[1]}] tensor")
+    return _BnReluTrainFn.apply(x.contiguous(), gamma.contiguous(), beta.contiguous(), running_mean, running_var, eps, momentum, relu)
+
+
 def corr_iter_kernel_name() -> str:
     """name of the device kernel itermvs_corr_iter launches (rocprofv3's Kernel_Name contains it)"""
     return "corr_iter_kernel"

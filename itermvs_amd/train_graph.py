@@ -48,10 +48,13 @@ class _Net:
     def cbr(self, x, p, stride=1, relu=True):
         w = self.w
         y = F.conv2d(x, w[p + "conv.weight"], stride=stride, padding=1)
-        y = F.batch_norm(y, w[p + "bn.running_mean"], w[p + "bn.running_var"], w[p + "bn.weight"], w[p + "bn.bias"],
-                         training=self.bn_training, momentum=0.1, eps=1e-5)
-        if self.bn_training:
+        if self.bn_training:        # batch statistics + ReLU in one HIP op (csrc/bn.hip), running stats updated in place
+            y = ops.bn_relu_train(y, w[p + "bn.weight"], w[p + "bn.bias"], w[p + "bn.running_mean"], w[p + "bn.running_var"],
+                                  eps=1e-5, momentum=0.1, relu=relu)
             w[p + "bn.num_batches_tracked"].add_(1)
+            return y
+        y = F.batch_norm(y, w[p + "bn.running_mean"], w[p + "bn.running_var"], w[p + "bn.weight"], w[p + "bn.bias"],
+                         training=False, momentum=0.1, eps=1e-5)
         return F.relu(y) if relu else y
 
     def block(self, x, p, stride):

@@ -510,6 +510,44 @@ def test_head_regress_edges_and_ties():
     assert maxdiff(nd, nd_ref) <= 1e-6
 
 
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("shape", [(4, 8, 64, 80), (3, 16, 33, 20), (2, 64, 8, 10), (1, 5, 130, 131), (20, 8, 128, 160)],
+                         ids=["vec", "vec-short-slab", "tiny-planes", "scalar-odd", "many-slabs"])
+def test_bn_relu_train_matches_torch(shape, relu):
+    """itermvs_bn_train_forward / _backward (csrc/bn.hip) vs torch.nn.functional.batch_norm(training=True) [+ relu] in fp64 on
+    the CPU: output, running statistics (unbiased variance, momentum 0.1) and the gradients w.r.t. x, gamma, beta
+    (models/module.py:33-50 in train() mode).  Shapes cover the float4 and the scalar form, planes shorter and longer than
+    one 8192-float slab, channel means far from zero."""
+    gen = torch.Generator().manual_seed(5)
+    n, c, h, w = shape
+    x = torch.randn(shape, generator=gen) * (1.0 + torch.arange(c).view(1, c, 1, 1)) + 3.0 * torch.arange(c).view(1, c, 1, 1)
+    gamma, beta = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen)
+    rm, rv = torch.randn(c, generator=gen), torch.rand(c, generator=gen) + 0.5
+    dy = torch.randn(shape, generator=gen)
+    xg = cu(x).requires_grad_(True)
+    gg, bg = cu(gamma).requires_grad_(True), cu(beta).requires_grad_(True)
+    rmg, rvg = cu(rm), cu(rv)
+    v0 = rmg._version
+    yg = ops().bn_relu_train(xg, gg, bg, rmg, rvg, eps=1e-5, momentum=0.1, relu=relu)
+    assert rmg._version > v0                               # the in-place update of the running statistics is visible to autograd
+    yg.backward(cu(dy))
+    # reference in fp64; the ReLU mask of the backward is taken from the GPU's own output (a pre-activation within fp32
+    # rounding of zero may fall on either side -- the forward comparison bounds what that can change)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rmd, rvd = rm.double().clone(), rv.double().clone()
+    pre = F.batch_norm(xd, rmd, rvd, gd, bd, training=True, momentum=0.1, eps=1e-5)
+    yd = F.relu(pre) if relu else pre
+    mask = (yg.detach().cpu() > 0).double() if relu else torch.ones_like(pre)
+    (pre * mask).backward(dy.double())
+    scale = lambda t: max(1.0, float(t.detach().abs().max()))       # noqa: E731
+    assert maxdiff(yg, yd.detach().float()) <= 2e-5 * scale(yd)
+    assert maxdiff(rmg, rmd.float()) <= 1e-5 * scale(rmd) and maxdiff(rvg, rvd.float()) <= 1e-5 * scale(rvd)
+    assert maxdiff(xg.grad, xd.grad.float()) <= 2e-4 * scale(xd.grad)
+    assert maxdiff(gg.grad, gd.grad.float()) <= 2e-4 * scale(gd.grad)
+    assert maxdiff(bg.grad, bd.grad.float()) <= 2e-4 * scale(bd.grad)
+
+
 @pytest.mark.parametrize("tag", ["seed0", "dtu"])
 def test_gru_gates(tag):
     g = golden(f"e2e_small_{tag}.npz")
