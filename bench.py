@@ -456,6 +456,7 @@ def main() -> None:
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "repeats": args.repeats, "ms_per_step_min": min(regions) / args.steps * 1e3,
             "ms_per_step_max": max(regions) / args.steps * 1e3,
+            "ms_per_step_regions": [round(r / args.steps * 1e3, 5) for r in regions],     # every timed region, in order (`value` = their median)
             # SURVEY 8(d) / eval.py:130-137 form of the same metric: pinned host buffers in (uint8 images as decoded from
             # disk, cameras, depth range), pinned host buffers out (depth + confidence), copies overlapped with compute
             "value_with_transfers": None,
