@@ -51,3 +51,11 @@ for d in ${BWD_DIAG:-}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/*.o | grep -v "/corr_bwd.o") $T/corr_bwd_$d.o -o $V/libitermvs_bwd_$d.so
 done
 ls $V
+# level masks: corr_iter_kernel with only the levels of the mask doing work (timing only), e.g. LEVEL_MASKS="1 2 4"
+for mk in ${LEVEL_MASKS-}; do
+  sed "s|    const int lvl = blockIdx.y;|    const int lvl = blockIdx.y; if (!(($mk >> lvl) \& 1)) return;|" $C/corr.hip > $T/corr_lm$mk.hip
+  cmp -s $C/corr.hip $T/corr_lm$mk.hip && { echo "level mask: sed matched nothing"; exit 1; }
+  /opt/rocm/bin/hipcc $FLAGS -I$C -c $T/corr_lm$mk.hip -o $T/corr_lm$mk.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_lm$mk.o -o $V/libitermvs_lm$mk.so
+done
+ls $V
