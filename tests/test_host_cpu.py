@@ -59,6 +59,14 @@ def test_argument_validation_error_codes():
     assert lib.itermvs_corr_init(C.byref(p), None) == -5                           # ERR_ALIGN
     p.S = 17
     assert lib.itermvs_corr_init(C.byref(p), None) == -4                           # ERR_VIEWS
+    # training BatchNorm entry points: scratch size = one (count, mean, M2) triple per 8192-float slab + 3 floats per channel
+    assert lib.itermvs_bn_workspace_floats(20, 8, 512 * 640) == 8 * 20 * 40 * 3 + 8 * 3
+    assert lib.itermvs_bn_workspace_floats(3, 16, 33 * 20) == 16 * 3 * 1 * 3 + 16 * 3
+    assert lib.itermvs_bn_workspace_floats(0, 8, 64) == -2
+    assert lib.itermvs_bn_train_forward(None, addr, 1, 1, 64, addr, addr, 1e-5, 0.1, 1, None, None, addr, addr, addr, None) == -1
+    assert lib.itermvs_bn_train_forward(addr, addr, 1, 1, 1, addr, addr, 1e-5, 0.1, 1, None, None, addr, addr, addr, None) == -2   # one value per channel
+    assert lib.itermvs_bn_train_backward(addr, None, addr, 1, 1, 64, addr, addr, addr, addr, 1, addr, addr, addr, None) == -1
+    assert lib.itermvs_bn_train_backward(addr, addr, addr, 1, 70000, 64, addr, addr, addr, addr, 1, addr, addr, addr, None) == -2   # C > 65535
     for code in range(-7, 1):
         assert len(lib.itermvs_error_string(code)) > 0
 
