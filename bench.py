@@ -471,6 +471,7 @@ def main() -> None:
                        "batch_per_gpu": args.batch, "streams_per_gpu": args.streams, "feature_dtype": args.feature_dtype,
                        "launch": "eager" if args.eager else "one hipGraph per depth map",
                        "parallelism": f"ref-view sharding x{world}, no collective",
+                       "process_group": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                        "algorithmic_MB_per_depth_map": b_map / 1e6},
             "roofline": roofline,
             "roofline_conv": conv_roofline,

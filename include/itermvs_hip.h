@@ -27,6 +27,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the prototypes of this header are its ONLY dynamic symbols
+ * (tests/test_host_cpu.py holds `nm -D` to that). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define ITERMVS_ABI_VERSION 6
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
@@ -259,13 +265,14 @@ int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_
                        float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * ConvGRU gates -- models/module.py:59-66 (the three 3x3 dilated convolutions stay in MIOpen)
+ * ConvGRU gates -- models/module.py:59-66 (element-wise form for the traced / training path; in the inference
+ * engine the gate math rides in the epilogue of the dilated 3x3 convolutions, itermvs_conv2d act 4/5)
  * itermvs_gru_rh :  rh[b,c,p] = sigmoid(zr[b,32+c,p]) * h[b,c,p]           (r * h, :63-64)
  * itermvs_gru_out:  h[b,c,p]  = (1-z) * h + z * tanh(q),  z = sigmoid(zr[b,c,p])   (:62,64,65)
  * zr = [B,2*hid,P] (z pre-activations then r pre-activations), q = [B,hid,P];
  * h / rh are addressed as base + b*sb + c*P + p so they can live inside the [B,43,P]
  * concatenated GRU input buffers.  itermvs_gru_out updates h in place and, when h_copy != NULL,
- * also stores the new state contiguously at h_copy[B,hid,P] (input of the MIOpen head convs).
+ * also stores the new state contiguously at h_copy[B,hid,P] (input of the depth / confidence head convolutions).
  * ------------------------------------------------------------------------------------------ */
 int itermvs_gru_rh(const float* zr, const float* h, int64_t h_sb, float* rh, int64_t rh_sb,
                    int32_t B, int32_t hid, int32_t P, void* stream);
@@ -462,6 +469,10 @@ int itermvs_profile_collect(int32_t* kind, float* ms, int32_t max_samples);
  * their graph and returns how many were read. */
 int itermvs_profile_graph_count(void);
 int itermvs_profile_graph_read(int32_t first, int32_t count, int32_t* kind, float* ms);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 """itermvs_amd -- MI355X-native IterMVS matching hot path.
 
-Python host code on PyTorch-ROCm (device memory, streams, MIOpen convolutions,
-torch.distributed) around ``libitermvs_hip.so``: hand-written gfx950 HIP kernels
+Python host code on PyTorch-ROCm (device memory, streams, hipGraph capture, torch.distributed;
+MIOpen only behind the autograd convolutions of the training graph) around ``libitermvs_hip.so``: hand-written gfx950 HIP kernels
 behind a C ABI (include/itermvs_hip.h).  The package mirrors the reference's
 ``models`` interface for this path (``Pipeline``, ``full_loss``,
 ``differentiable_warping`` ...), see INTEGRATION.md.

@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(256) prob_regress_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// ConvGRU gate math (element-wise; the dilated 3x3 convolutions run in MIOpen)
+// ConvGRU gate math, element-wise form (the inference engine fuses it into the epilogue of the dilated 3x3 convolutions,
+// conv_epilogue.hpp; this form serves the traced / training path whose convolutions run in PyTorch-ROCm autograd)
 // ---------------------------------------------------------------------------------------------
 __global__ void gru_rh_kernel(const float* __restrict__ zr, const float* __restrict__ h, int64_t h_sb,
                               float* __restrict__ rh, int64_t rh_sb, int B, int hid, int P) {

@@ -16,14 +16,15 @@ import torch
 import torch.distributed as dist
 
 
-def flat_allreduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int = None) -> int:
+def flat_allreduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int = None, force: bool = False) -> int:
     """Average ``p.grad`` over all ranks with one all-reduce over one flat buffer.
-    Returns the number of gradient elements reduced (0 when not running distributed)."""
+    Returns the number of gradient elements reduced (0 when not running distributed, or in a world of one rank unless
+    ``force`` -- the 1-rank RCCL test runs the collective anyway)."""
     if not (dist.is_available() and dist.is_initialized()):
         return 0
     world = world_size or dist.get_world_size()
     grads: List[torch.Tensor] = [p.grad for p in params if p.grad is not None]
-    if not grads or world == 1:
+    if not grads or (world == 1 and not force):
         return 0
     flat = torch.cat([g.reshape(-1) for g in grads])
     if flat.is_cuda and dist.get_backend() == "gloo":

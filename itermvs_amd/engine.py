@@ -25,6 +25,8 @@ CorrNet inputs); ``run`` is their composition, the teacher-forced parity tests d
 """
 from __future__ import annotations
 
+import itertools
+import weakref
 from typing import Dict, List, Mapping, Tuple
 
 import torch
@@ -94,6 +96,7 @@ class InferenceEngine:
         self.offsets = sample_offsets()
         self._ws: Dict[tuple, dict] = {}
         self._ws_owner = None
+        self._owner_tokens = itertools.count(1)      # never reused, unlike id(): a new runner cannot alias an old workspace
         # OR-ed with 1 by itermvs_compose_proj when a composed projection is NaN (module.py:83,87 assert on the host);
         # read and cleared by check_projection_finite()
         self.nan_flag = torch.zeros((1,), device=dev, dtype=torch.int32)
@@ -227,6 +230,11 @@ class InferenceEngine:
             ws["b"] = b
             self._ws[key] = ws
         return ws
+
+    def _release_owner(self, token: int) -> None:
+        """drop the private workspaces of a GraphedRunner that went away (its finalizer calls this)"""
+        for key in [k for k in self._ws if k[3] == token]:
+            del self._ws[key]
 
     # -- stages (each reads / writes the workspace; see the module docstring) ---------------------
     def stage_init(self, ws: dict, src3: List[Tensor], ref3: Tensor, proj3: Tensor, inv_min: Tensor, inv_max: Tensor,
@@ -383,6 +391,12 @@ class InferenceEngine:
             raise AssertionError("nan in proj (singular or non-finite camera matrix, module.py:83,87)")
 
 
+def _release_workspace(engine_ref, token: int) -> None:
+    engine = engine_ref()
+    if engine is not None:
+        engine._release_owner(token)
+
+
 class GraphedRunner:
     """One depth map per replay with no host work: ``InferenceEngine.run`` captured into ONE hipGraph
     (torch.cuda.CUDAGraph) on a private stream, with static input / output buffers.
@@ -404,7 +418,12 @@ class GraphedRunner:
         self.depth_min, self.depth_max = depth_min.clone(), depth_max.clone()
         self.key = (tuple(imgs.shape), tuple(depth_min.shape))
         self.stream.wait_stream(torch.cuda.current_stream(imgs.device))
-        engine._ws_owner = id(self)                             # this runner's private workspace (see _workspace)
+        # this runner's private workspace (see _workspace), released with the runner: the finalizer holds the engine weakly
+        # and the token by value, so a dropped runner frees its GRU / correlation buffers instead of leaving them in
+        # engine._ws for the engine's lifetime
+        self._ws_token = next(engine._owner_tokens)
+        engine._ws_owner = self._ws_token
+        weakref.finalize(self, _release_workspace, weakref.ref(engine), self._ws_token)
         try:
             with torch.cuda.stream(self.stream):
                 for _ in range(2):                              # warm-up: allocates the workspaces, primes caches

@@ -80,6 +80,7 @@ class Pipeline(nn.Module):
         self._engine = None
         self._runners = {}
         self._engine_version = None
+        self._version_tensors = None
         self.use_graphs = False        # test mode: replay one hipGraph per depth map instead of launching kernel by kernel
         # module.py:83,87 assert on NaN projections inside every forward.  Eager test mode does the same (one 4-byte read
         # after the launches are enqueued); the graph mode never stalls the host: call check_projection_finite() when the
@@ -105,9 +106,18 @@ class Pipeline(nn.Module):
         self._engine = None
         self._runners = {}
         self._engine_version = None
+        self._version_tensors = None
 
     def _weights_version(self) -> int:
-        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+        # polled on every test-mode forward (hipGraph replays included): the ~250 tensors are collected once per packed
+        # engine instead of walking the nn.Module generators each time
+        ts = self._version_tensors
+        if ts is None:
+            ts = self._version_tensors = tuple(self.parameters()) + tuple(self.buffers())
+        v = 0
+        for t in ts:
+            v += t._version
+        return v
 
     def load_checkpoint_state(self, state: Mapping[str, torch.Tensor], strict: bool = True):
         """Load a reference checkpoint's ``state_dict['model']`` (keys may carry ``module.``)."""

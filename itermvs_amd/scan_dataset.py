@@ -166,14 +166,20 @@ class Prefetcher:
                 break
         self.thread.join(timeout=5)
 
-    def _stage(self):
+    _PENDING = object()      # _stage(block=False): nothing decoded yet
+
+    def _stage(self, block: bool = True):
         """next decoded sample -> (sample, device tensors, ready event) with the upload + pyramid enqueued on the side
-        stream; None at the end of the shard"""
+        stream; None at the end of the shard; ``_PENDING`` when ``block`` is False and the decoder has nothing ready"""
         while True:
             try:
-                s = self.q.get(timeout=1.0)
+                # not blocking = a 5 ms grace period: the decoder blocked on a full queue needs a moment to hand over the
+                # item it already holds after the consumer took the previous one
+                s = self.q.get(timeout=1.0 if block else 0.005)
                 break
             except queue.Empty:
+                if not block:
+                    return self._PENDING
                 if not self.thread.is_alive() and self.q.empty():
                     raise RuntimeError("Prefetcher: the decoder thread ended without delivering the end-of-shard marker")
         if s is None:
@@ -191,8 +197,11 @@ class Prefetcher:
             nxt = self._stage()
             while nxt is not None:
                 s, tensors, ready = nxt
-                nxt = self._stage()                # item n+1 is on its way to the device before item n is consumed
-                if nxt is not None:
+                # item n+1 goes on its way to the device before item n is consumed -- when it is already decoded.  When
+                # decoding is the slower side the consumer gets item n NOW (the GPU must not idle for one decode per item)
+                # and n+1 is staged after the yield
+                nxt = self._stage(block=False)
+                if nxt is not None and nxt is not self._PENDING:
                     self.staged_ahead += 1
                 cur = torch.cuda.current_stream(self.dev)
                 # the HOST waits for the (long finished: staged one item ahead) upload instead of making the compute stream
@@ -202,5 +211,7 @@ class Prefetcher:
                 for t in list(tensors[0].values()) + list(tensors[1].values()) + [tensors[2], tensors[3]]:
                     t.record_stream(cur)           # allocated on the side stream, used on this one
                 yield s, tensors
+                if nxt is self._PENDING:
+                    nxt = self._stage()
         finally:
             self.close()

@@ -33,14 +33,19 @@ def env_rank_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_distributed(backend: str = None) -> Tuple[int, int, int]:
-    """Join the process group when launched by ``torch.distributed.run``; no-op for 1 process."""
+def init_distributed(backend: str = None, force: bool = False) -> Tuple[int, int, int]:
+    """Join the process group when launched by ``torch.distributed.run`` (any world size: a 1-rank launch through the
+    launcher exercises the same RCCL initialisation and collectives as an 8-rank one); a plain ``python`` process of
+    world 1 stays without a process group unless ``force``."""
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    launched = "TORCHELASTIC_RUN_ID" in os.environ
+    if (world > 1 or force or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)           # RCCL binds the communicator to the current device
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 

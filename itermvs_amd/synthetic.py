@@ -185,3 +185,21 @@ def make_training_sample(num_views: int = 5, height: int = 512, width: int = 640
     m0 = (torch.rand(gt0.shape, generator=gen) > hole_fraction).float()
     return sample, {"level_0": gt0, "level_2": gt0[:, :, ::4, ::4].contiguous()}, \
         {"level_0": m0, "level_2": m0[:, :, ::4, ::4].contiguous()}
+
+
+def make_training_batch(batch: int, num_views: int = 5, height: int = 512, width: int = 640, seed: int = 0,
+                        hole_fraction: float = 0.0):
+    """A training batch of ``batch`` DIFFERENT scenes / reference views in the reference's collated schema
+    (train.py:89-90 with ``--batch_size``; datasets/dtu_yao.py:227-232): every tensor of :func:`make_training_sample`
+    concatenated along dim 0; sample ``i`` is seeded ``seed + i``.
+    -> (imgs, proj_matrices, depth_min [B], depth_max [B], depth_gt {'level_0','level_2'}, mask {...})."""
+    if batch < 1:
+        raise ValueError("batch must be >= 1")
+    parts = [make_training_sample(num_views, height, width, seed=seed + i, hole_fraction=hole_fraction) for i in range(batch)]
+    cat = lambda pick: torch.cat([pick(p) for p in parts], 0)  # noqa: E731
+    s0 = parts[0][0]
+    imgs = {k: cat(lambda p: p[0]["imgs"][k]) for k in s0["imgs"]}
+    projs = {k: cat(lambda p: p[0]["proj_matrices"][k]) for k in s0["proj_matrices"]}
+    gt = {k: cat(lambda p: p[1][k]) for k in parts[0][1]}
+    mask = {k: cat(lambda p: p[2][k]) for k in parts[0][2]}
+    return imgs, projs, cat(lambda p: p[0]["depth_min"]), cat(lambda p: p[0]["depth_max"]), gt, mask

@@ -38,9 +38,10 @@ def test_train_driver_steps_and_checkpoint(tmp_path):
     import eval as E
     import train as T
     args = T.build_parser().parse_args(["--regress", "--n_views", "3", "--img_wh", "96", "64", "--iteration", "2",
-                                        "--logdir", str(tmp_path)])
+                                        "--batch_size", "2", "--logdir", str(tmp_path)])
     dev = torch.device("cuda")
     torch.manual_seed(1)
+    assert T.synthetic_batch(args, 0, 0, dev)[0]["level_0"].shape[0] == 2            # --batch_size reaches the batch
     from itermvs_amd.net import Pipeline
     model = Pipeline(iteration=2, test=False).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)

@@ -25,6 +25,17 @@ def test_library_exports_every_declared_symbol():
     assert int(m.group(1)) == _lib.ABI_VERSION
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    """-fvisibility=hidden + csrc/exports.map: the dynamic symbol table IS the header (no mangled launch helpers, no
+    kernel handle variables): what a binding can see is exactly what include/itermvs_hip.h documents"""
+    import subprocess
+    from itermvs_amd import _lib
+    so = os.path.join(ROOT, "itermvs_amd", "libitermvs_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], check=True, capture_output=True, text=True).stdout
+    names = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert names == set(_lib.PROTOTYPES), sorted(names ^ set(_lib.PROTOTYPES))[:10]
+
+
 def test_struct_layout_matches_header_sizes():
     """ctypes mirrors of the C structs: sizes follow from the header's field lists."""
     from itermvs_amd import _lib

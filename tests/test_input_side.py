@@ -2,6 +2,8 @@
 (dtu_yao_eval.py:105-126), and the GPU image pyramid against its (unpinned: cv2 absent) CPU restatement."""
 import os
 
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -153,6 +155,7 @@ def test_prefetcher_stages_one_sample_ahead(tmp_path):
     seen, ahead = [], []
     for sample, (imgs, projs, dmin, dmax) in pf:
         ahead.append(pf.staged_ahead)
+        time.sleep(0.15)                         # a consumer slower than the decoder: the next item is always decoded in time
         torch.cuda.current_stream().synchronize()
         want = to_device(ds[len(seen)], dev)
         assert torch.equal(imgs["level_0"], want[0]["level_0"]) and torch.equal(projs["level_2"], want[1]["level_2"])
@@ -161,6 +164,17 @@ def test_prefetcher_stages_one_sample_ahead(tmp_path):
     assert len(seen) == 4 and len(set(seen)) == 4
     assert ahead == [1, 2, 3, 3]                 # while item n was consumed, item n+1 was already staged (none after the last)
     assert not pf.thread.is_alive()
+    # a decoder SLOWER than the consumer: item n is handed out as soon as it is decoded, not after item n+1's decode
+    class Slow:
+        def __init__(self, inner): self.inner = inner
+        def __len__(self): return len(self.inner)
+        def __getitem__(self, i):
+            time.sleep(0.3)
+            return self.inner[i]
+    t0, stamps = time.perf_counter(), []
+    for _ in Prefetcher(Slow(ds), [0, 1, 2], dev, depth=1):
+        stamps.append(time.perf_counter() - t0)
+    assert len(stamps) == 3 and stamps[0] < 0.5 and stamps[1] < 0.85, stamps     # 0.3 s per decode, none waited for twice
     # leaving early: close() drains the queue and the worker exits instead of blocking on a full queue
     pf2 = Prefetcher(ds, [0, 1, 2, 3], dev, depth=1)
     for _ in pf2:

@@ -46,6 +46,24 @@ def test_train_recipe_and_checkpoint_format(tmp_path):
     assert args.regress and args.resume and args.lr == 0.002 and args.epochs == 16
 
 
+def test_train_driver_builds_the_batch_it_is_asked_for():
+    """train.py --batch_size N (train.py:89-90, train_dtu.sh: 4): B = N different samples per rank, the reference's collated
+    training schema (datasets/dtu_yao.py:227-232); ranks and steps never see the same scene"""
+    import train as T
+    args = T.build_parser().parse_args(["--batch_size", "3", "--n_views", "3", "--img_wh", "96", "64"])
+    imgs, projs, dmin, dmax, gt, mask = T.synthetic_batch(args, 0, 0, torch.device("cpu"), world=2)
+    assert imgs["level_0"].shape == (3, 3, 3, 64, 96) and imgs["level_3"].shape == (3, 3, 3, 8, 12)
+    assert projs["level_1"].shape == (3, 3, 4, 4) and dmin.shape == dmax.shape == (3,)
+    assert gt["level_0"].shape == mask["level_0"].shape == (3, 1, 64, 96) and gt["level_2"].shape == (3, 1, 16, 24)
+    assert not torch.equal(imgs["level_0"][0], imgs["level_0"][1])                # different scenes inside the batch
+    other = T.synthetic_batch(args, 0, 1, torch.device("cpu"), world=2)[0]["level_0"]
+    nxt = T.synthetic_batch(args, 1, 0, torch.device("cpu"), world=2)[0]["level_0"]
+    for a in imgs["level_0"]:
+        assert not any(torch.equal(a, b) for b in list(other) + list(nxt))       # nor across ranks / steps
+    one = T.synthetic_batch(T.build_parser().parse_args(["--n_views", "3", "--img_wh", "96", "64"]), 0, 0, torch.device("cpu"))
+    assert one[0]["level_0"].shape[0] == 1                                       # the default stays --batch_size 1
+
+
 def test_eval_flags_and_synthetic_dataset_schema():
     import eval as E
     args = E.build_parser().parse_args(["--n_views", "3", "--img_wh", "96", "64", "--iteration", "2", "--num_samples", "3"])

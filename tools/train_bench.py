@@ -37,17 +37,10 @@ def main() -> None:
     model.feature_dtype = args.feature_dtype
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
-    ones = [synthetic.make_scene_sample(num_views=args.views, height=args.wh[1], width=args.wh[0], seed=i) for i in range(args.batch)]
-    cat = lambda f: torch.cat([f(o) for o in ones], 0)  # noqa: E731   (B different scenes / reference views)
-    s = {"imgs": {k: cat(lambda o: o["imgs"][k]) for k in ones[0]["imgs"]},
-         "proj_matrices": {k: cat(lambda o: o["proj_matrices"][k]) for k in ones[0]["proj_matrices"]},
-         "depth_min": cat(lambda o: o["depth_min"]), "depth_max": cat(lambda o: o["depth_max"]), "depth_gt": cat(lambda o: o["depth_gt"])}
-    imgs = {k: v.to(dev) for k, v in s["imgs"].items()}
-    projs = {k: v.to(dev) for k, v in s["proj_matrices"].items()}
-    dmin, dmax = s["depth_min"].to(dev), s["depth_max"].to(dev)
-    gt0 = s["depth_gt"].to(dev)
-    gt = {"level_0": gt0, "level_2": gt0[:, :, ::4, ::4].contiguous()}
-    mask = {k: torch.ones_like(v) for k, v in gt.items()}
+    # the batch train.py builds for --batch_size (B different scenes / reference views)
+    imgs, projs, dmin, dmax, gt, mask = synthetic.make_training_batch(args.batch, num_views=args.views, height=args.wh[1], width=args.wh[0])
+    to = lambda d: {k: v.to(dev) for k, v in d.items()}  # noqa: E731
+    imgs, projs, gt, mask, dmin, dmax = to(imgs), to(projs), to(gt), to(mask), dmin.to(dev), dmax.to(dev)
     params = list(model.parameters())
 
     def fwd():

@@ -62,15 +62,13 @@ def parse_lrepochs(spec: str):
     return [int(e) for e in epochs.split(",")], 1.0 / float(factor)
 
 
-def synthetic_batch(args, step: int, rank: int, dev):
-    s = synthetic.make_scene_sample(num_views=args.n_views, height=args.img_wh[1], width=args.img_wh[0],
-                                    seed=step * 131 + rank)
-    gt0 = s["depth_gt"]
-    gt2 = gt0[:, :, ::4, ::4].contiguous()
-    return ({k: v.to(dev) for k, v in s["imgs"].items()}, {k: v.to(dev) for k, v in s["proj_matrices"].items()},
-            s["depth_min"].to(dev), s["depth_max"].to(dev),
-            {"level_0": gt0.to(dev), "level_2": gt2.to(dev)},
-            {"level_0": torch.ones_like(gt0).to(dev), "level_2": torch.ones_like(gt2).to(dev)})
+def synthetic_batch(args, step: int, rank: int, dev, world: int = 1):
+    """``--batch_size`` samples per GPU (train.py:89-90; train_dtu.sh: 4), every (step, rank, slot) a different scene."""
+    seed = ((step * world + rank) * args.batch_size) * 131
+    imgs, projs, dmin, dmax, gt, mask = synthetic.make_training_batch(
+        args.batch_size, num_views=args.n_views, height=args.img_wh[1], width=args.img_wh[0], seed=seed)
+    to = lambda d: {k: v.to(dev) for k, v in d.items()}  # noqa: E731
+    return to(imgs), to(projs), dmin.to(dev), dmax.to(dev), to(gt), to(mask)
 
 
 def save_checkpoint(path: str, epoch: int, model: torch.nn.Module, optimizer) -> None:
@@ -129,7 +127,7 @@ def validate(model, args, rank: int, world: int, dev) -> dict:
     """train.py:177-190 (test): every rank scores its share of the validation steps; the means are averaged over ranks"""
     total, n = {}, 0
     for step in range(args.steps_per_epoch):
-        sc = val_step(model, synthetic_batch(args, 10_000_019 + step, rank, dev), args.regress, args.iteration)
+        sc = val_step(model, synthetic_batch(args, 10_000_019 + step, rank, dev, world), args.regress, args.iteration)
         for k, v in sc.items():
             total[k] = total.get(k, 0.0) + v
         n += 1
@@ -174,7 +172,7 @@ def main() -> None:
     for epoch in range(start_epoch, args.epochs):
         for step in range(args.steps_per_epoch):
             t0 = time.time()
-            loss, err = train_step(model, optimizer, synthetic_batch(args, epoch * args.steps_per_epoch + step, rank, dev),
+            loss, err = train_step(model, optimizer, synthetic_batch(args, epoch * args.steps_per_epoch + step, rank, dev, world),
                                    args.regress)
             if rank == 0 and step % args.summary_freq == 0:
                 print("Epoch {}/{}, Iter {}/{}, train loss = {:.3f}, abs depth error = {:.3f} mm, time = {:.3f}".format(
