@@ -303,6 +303,32 @@ def golden_train_cfg4(weights):
 
 
 # ----------------------------------------------------------------------------
+# 6c. The same step at B = 2 (two different scenes, 5 views, 640x512, 4 iterations): the batched form train_dtu.sh runs
+#     (--batch_size 4 over the reference's DataParallel replicas = B >= 2 per forward), and the reference's `batch == 2`
+#     branch of differentiable_warping (module.py:78-84) at full size.  Loss, gradient norms and gradient slices.
+# ----------------------------------------------------------------------------
+def golden_train_cfg4_b2(weights):
+    imgs, projs, dmin, dmax, gt, mask = synthetic.make_training_batch(2, num_views=5, height=512, width=640, seed=2,
+                                                                      hole_fraction=0.1)
+    arrays = {"iteration": np.int64(4), "batch": np.int64(2)}
+    for regress in (True, False):
+        model = build_reference(weights, 4, test=False)
+        out = model(imgs, projs, dmin, dmax)
+        loss = ref_net.full_loss(out["depths"], out["depths_upsampled"], out["confidences"], gt, mask, dmin, dmax, regress)
+        loss.backward()
+        tag = "regress" if regress else "noregress"
+        arrays[f"{tag}.loss"] = np.float64(loss.item())
+        record_gradients(model, arrays, tag)
+        if regress:
+            d = out["depths_upsampled"][0]
+            arrays["train.depth_sub"] = npy(d[:, :, ::8, ::8])
+            arrays["train.depth_abs_err_median"] = np.float64((d - gt["level_0"]).abs().median().item())
+            arrays["train.initial_sub"] = npy(out["depths"]["initial"][0][:, :, ::4, ::4])
+        print(f"  train cfg4 B=2 {tag}: loss {loss.item():.6f}")
+    save("train_cfg4_b2.npz", **arrays)
+
+
+# ----------------------------------------------------------------------------
 # 7. PFM bytes as written by the reference's datasets/data_io.py (run separately: this part needs only numpy)
 # ----------------------------------------------------------------------------
 def golden_pfm():
@@ -343,6 +369,8 @@ def main():
         golden_train(w0)
     if want("train_cfg4"):
         golden_train_cfg4(w0)
+    if want("train_cfg4_b2"):
+        golden_train_cfg4_b2(w0)
     if want("pfm"):
         golden_pfm()
 

@@ -252,3 +252,30 @@ def test_train_step_cfg4_full_size(weights_seed0):
     d = out["depths_upsampled"][0].detach()
     rel = (d[:, :, ::8, ::8] - g["train.depth_sub"]).abs() / g["train.depth_sub"]
     assert float(rel.median()) <= 1e-6 and float((rel > 1e-4).float().mean()) <= 0.02
+
+
+def test_train_step_cfg4_batch2(weights_seed0):
+    """the same step at B = 2 (two scenes; the reference's `batch == 2` branch of differentiable_warping, module.py:78-84, at
+    full size): loss, gradient norms and sliced gradients of tests/golden/train_cfg4_b2.npz"""
+    from itermvs_amd import synthetic
+    g = golden("train_cfg4_b2.npz")
+    imgs, projs, dmin, dmax, gt, mk = synthetic.make_training_batch(int(g.np("batch")), num_views=5, height=512, width=640,
+                                                                    seed=2, hole_fraction=0.1)
+    torch.set_num_threads(min(16, max(8, torch.get_num_threads())))
+    w = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in weights_seed0.items()}
+    out = O.pipeline_forward(w, imgs, projs, dmin, dmax, iteration=int(g.np("iteration")), test=False, training=True)
+    loss = O.full_loss(out["depths"], out["depths_upsampled"], out["confidences"], gt, mk, dmin, dmax, True)
+    ref = float(g.np("regress.loss"))
+    assert abs(loss.item() - ref) <= 2e-4 * abs(ref), (loss.item(), ref)
+    loss.backward()
+    for n, want in zip([str(n) for n in g.np("regress.grad_names")], g.np("regress.grad_norms")):
+        got = w[n].grad
+        if want < 0:
+            assert got is None or float(got.norm()) == 0.0, n
+        else:
+            assert abs(float(got.norm()) - want) <= 5e-3 * max(want, 1e-3), (n, float(got.norm()), want)
+    rep = check_gradient_slices(g, "regress", {n: w[n].grad for n in w if w[n].requires_grad}, rel_l2=1e-2, min_cos=0.9999)
+    print(f"oracle train cfg4 B=2: gradient slices {rep}")
+    d = out["depths_upsampled"][0].detach()
+    rel = (d[:, :, ::8, ::8] - g["train.depth_sub"]).abs() / g["train.depth_sub"]
+    assert float(rel.median()) <= 1e-6 and float((rel > 1e-4).float().mean()) <= 0.02

@@ -183,3 +183,135 @@ def test_every_stage_on_the_oracles_inputs(wtag, kind, views, height, width, ite
     print(f"teacher-forced {wtag}/{kind} {width}x{height}: " + ", ".join(
         f"{k}={v:.1e}" if isinstance(v, float) else f"{k}={v}" for k, v in report.items()))
     assert not FAILS, "; ".join(FAILS)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Teacher-forced BACKWARD at BASELINE cfg 4's size (round 4).  The training graph is chaotic end to end (an arg-max flip moves
+# a regression window), so the end-to-end gradient gates of tests/test_train_gpu.py carry a measured chaos floor.  Here the
+# fused correlation autograd Functions (the only hand-written backward on the path besides BatchNorm) are fed the pinned
+# ORACLE's own tensors of a cfg-4 training step -- its FeatureNet pyramids (bf16-rounded for cfg 4 "as stated"), its view
+# weights, its normalised depth going into a GRU iteration, and the UPSTREAM gradient dL/d(aggregated correlation) that the
+# oracle's full_loss backward delivers to that Evaluation call -- and their input gradients are compared with torch autograd
+# through the oracle's warp + group correlation + view-weighted mean on the same tensors.  Nothing feeds back: the
+# tolerance is 1e-4 x scale at 640x512 with B = 2, like the 24x40 kernel tests.
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_corr_views(feat_pv, ref, p12_l, depth, size):
+    """per-view group correlations [B,G,N,h,w] of one level: feat_pv [B,V,C,H1,W1], the oracle's differentiable pieces"""
+    b, v = feat_pv.shape[:2]
+    out = []
+    for s in range(1, v):
+        m = torch.cat([p12_l[:, s - 1].view(b, 3, 4), torch.zeros(b, 1, 4)], 1)
+        with torch.no_grad():
+            ix, iy, _ = O.warp_source_coords(m, depth, size[0], size[1])
+        out.append(O.group_correlation(O.bilinear_gather(feat_pv[:, s], ix, iy), ref))
+    return out
+
+
+@pytest.fixture(scope="module")
+def cfg4_backward_trace():
+    """one cfg-4 shaped training step of the CPU oracle at B = 2 (5 views, 640x512, 4 iterations, seed-0 weights, the batch
+    train.py --batch_size 2 builds), for fp32 and bf16 feature storage: traced tensors + the upstream gradients of every
+    Evaluation call (retain_grad on the aggregated correlations)"""
+    from itermvs_amd import synthetic
+    torch.set_num_threads(min(32, max(8, torch.get_num_threads())))
+    imgs, projs, dmin, dmax, gt, mk = synthetic.make_training_batch(2, num_views=5, height=512, width=640, seed=2, hole_fraction=0.1)
+    out = {}
+    for name, storage in (("fp32", None), ("bf16", torch.bfloat16)):
+        w = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in load_weights("seed0").items()}
+        tr = {}
+        res = O.pipeline_forward(w, imgs, projs, dmin, dmax, iteration=4, test=False, training=True, trace=tr, feature_storage=storage)
+        for it in tr["iters"]:
+            for a in it["aggs"]:
+                a.retain_grad()
+        O.full_loss(res["depths"], res["depths_upsampled"], res["confidences"], gt, mk, dmin, dmax, True).backward()
+        out[name] = dict(
+            feats={l: tr["feats_gathered"][l].detach() for l in (1, 2, 3)},
+            view_w=tr["view_weights"].detach(),
+            iters=[dict(nd_in=it["nd_in"].detach(), aggs=[a.detach() for a in it["aggs"]], up=[a.grad.detach() for a in it["aggs"]])
+                   for it in tr["iters"]])
+    p = torch.stack([projs[f"level_{l}"] for l in (1, 2, 3)])
+    p12 = torch.stack([torch.stack([O.compose_projection(p[i][:, s], p[i][:, 0])[:, :3, :4].reshape(-1, 12) for s in range(1, 5)], 1)
+                       for i in range(3)])
+    return out, p12, (1.0 / dmin), (1.0 / dmax)
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+@pytest.mark.parametrize("it", [0, 2])
+def test_corr_iter_backward_on_the_oracles_training_tensors(cfg4_backward_trace, storage, it):
+    """itermvs_corr_iter_backward at 640x512, B = 2, 4 source views: dL/dsrc (scatter) and dL/dref_q (gather) for the
+    oracle's upstream gradient of GRU iteration ``it`` (0: hypotheses around the first, noisy depth map; 2: a smooth one)"""
+    from itermvs_amd import ops
+    from itermvs_amd.engine import sample_offsets
+    traces, p12, inv_min, inv_max = cfg4_backward_trace
+    t = traces[storage]
+    b, v = 2, 5
+    feats = {l: t["feats"][l].clone().requires_grad_(True) for l in (1, 2, 3)}                  # [B*V,C,H,W], values as stored
+    pv = {l: feats[l].view(b, v, *feats[l].shape[1:]) for l in (1, 2, 3)}
+    rq = O.ref_feature_quarter({l: t["feats"][l].view(b, v, *feats[l].shape[1:])[:, 0] for l in (1, 2, 3)})   # (no graph: a leaf below)
+    ref_q = torch.cat([rq[1], rq[2], rq[3]], 1).permute(0, 2, 3, 1).contiguous().requires_grad_(True)   # [B,h,w,96]
+    assert ref_q.is_leaf
+    h, w = ref_q.shape[1:3]
+    nd, vw = t["iters"][it]["nd_in"], t["view_w"]
+    samples = O.iteration_depth_samples(nd, inv_min.view(b, 1, 1, 1), inv_max.view(b, 1, 1, 1))
+    off, chans, loss = {1: 0, 2: 16, 3: 48}, {1: 16, 2: 32, 3: 48}, 0
+    for i, l in enumerate((1, 2, 3)):
+        refl = ref_q[..., off[l]:off[l] + chans[l]].permute(0, 3, 1, 2)
+        acc, wsum = 0, 1e-5
+        for s, corr in enumerate(_oracle_corr_views(pv[l], refl, p12[i], samples[l], feats[l].shape[2:])):
+            wv = vw[:, s].view(b, 1, 1, h, w)
+            acc, wsum = acc + corr * wv, wsum + wv
+        agg = acc / wsum
+        want_agg = t["iters"][it]["aggs"][i]
+        assert float((agg.detach() - want_agg).abs().max()) <= 1e-5 * max(1.0, float(want_agg.abs().max()))   # the traced call, restated
+        loss = loss + (agg * t["iters"][it]["up"][i]).sum()
+    loss.backward()
+    dev = lambda x: x.to("cuda")
+    fg = {l: dev(t["feats"][l]).contiguous(memory_format=torch.channels_last).requires_grad_(True) for l in (1, 2, 3)}
+    stored = None if storage == "fp32" else {l: fg[l].detach().to(torch.bfloat16) for l in fg}
+    if stored is not None:
+        assert all(torch.equal(stored[l].float(), fg[l].detach()) for l in fg)                   # the oracle's storage model == bf16 values
+    rqd = dev(ref_q.detach()).requires_grad_(True)
+    outs = ops.corr_iter_train(fg, b, v, rqd, dev(p12), dev(vw), dev(inv_min), dev(inv_max), dev(nd), sample_offsets(), stored=stored)
+    worst = 0.0
+    for o, i in zip(outs, range(3)):
+        want = t["iters"][it]["aggs"][i].permute(0, 2, 1, 3, 4)
+        worst = max(worst, float((o.detach().cpu() - want).abs().max()) / max(1.0, float(want.abs().max())))
+    assert worst <= 5e-5, worst                                                                  # forward, like the inference gate
+    sum((o * dev(t["iters"][it]["up"][i].permute(0, 2, 1, 3, 4))).sum() for i, o in enumerate(outs)).backward()
+    rep = {}
+    for l in (1, 2, 3):
+        g_ref = feats[l].grad
+        scale = max(1e-30, float(g_ref.abs().max()))
+        rep[l] = float((fg[l].grad.cpu() - g_ref).abs().max()) / scale
+        assert rep[l] <= 1e-4, (l, rep[l], scale)
+        assert float(fg[l].grad.view(b, v, -1)[:, 0].abs().max()) == 0.0                        # reference view: through ref_q only
+    scale = max(1e-30, float(ref_q.grad.abs().max()))
+    rep["ref_q"] = float((rqd.grad.cpu() - ref_q.grad).abs().max()) / scale
+    assert rep["ref_q"] <= 1e-4, rep
+    print(f"teacher-forced backward, iteration {it}, {storage}: forward {worst:.1e}, gradients (max abs / scale) {rep}")
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_corr_init_backward_on_the_oracles_training_features(cfg4_backward_trace, storage):
+    """itermvs_corr_init_backward at the cfg-4 size (level 3: 64x80, 32 planes, B = 2, 4 source views) on the oracle's
+    FeatureNet output; upstream gradient: seeded noise (the per-view volumes are not a traced seam of the oracle)"""
+    from itermvs_amd import ops
+    traces, p12, inv_min, inv_max = cfg4_backward_trace
+    b, v = 2, 5
+    f3 = traces[storage]["feats"][3].clone().requires_grad_(True)
+    h3, w3 = f3.shape[2:]
+    depth = O.initial_depth_samples(inv_min.view(b, 1, 1, 1), inv_max.view(b, 1, 1, 1), h3, w3)
+    gw = torch.randn((b, v - 1, 32, 8, h3, w3), generator=torch.Generator().manual_seed(5))
+    pv = f3.view(b, v, *f3.shape[1:])
+    corrs = _oracle_corr_views(pv, pv[:, 0], p12[2], depth, (h3, w3))
+    sum((c.permute(0, 2, 1, 3, 4) * gw[:, s]).sum() for s, c in enumerate(corrs)).backward()
+    fg = f3.detach().to("cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    stored = None if storage == "fp32" else fg.detach().to(torch.bfloat16)
+    out = ops.corr_init_train(fg, b, v, p12[2].to("cuda"), inv_min.to("cuda"), inv_max.to("cuda"), 32, stored=stored)
+    want = torch.stack([c.detach().permute(0, 2, 1, 3, 4) for c in corrs], 1)
+    assert float((out.detach().cpu() - want).abs().max()) <= 5e-5 * max(1.0, float(want.abs().max()))
+    (out * gw.to("cuda")).sum().backward()
+    scale = float(f3.grad.abs().max())
+    err = float((fg.grad.cpu() - f3.grad).abs().max()) / scale
+    assert err <= 1e-4, (err, scale)
+    print(f"teacher-forced init backward, {storage}: {err:.1e} of the gradient scale {scale:.3g}")

@@ -120,6 +120,52 @@ def test_train_step_cfg4_full_size(regress):
         assert float(rel.median()) <= 1e-5 and float((rel > 1e-4).float().mean()) <= 0.05
 
 
+@pytest.mark.parametrize("regress", [True, False])
+def test_train_step_cfg4_batch2(regress):
+    """The cfg-4 step BATCHED (train_dtu.sh: --batch_size 4 over DataParallel replicas, i.e. B >= 2 per forward;
+    train.py:89-90): B = 2 different scenes, 5 views, 640x512, 4 iterations, against the reference's loss, gradient norms and
+    sliced gradient tensors of the same batch (tests/golden/train_cfg4_b2.npz; the reference takes its `batch == 2` branch
+    of differentiable_warping there, module.py:78-84).  The batch is the one `train.py --batch_size 2` builds."""
+    from itermvs_amd import synthetic
+    from itermvs_amd.net import Pipeline, full_loss
+    g = golden("train_cfg4_b2.npz")
+    tag = "regress" if regress else "noregress"
+    b = int(g.np("batch"))
+    imgs, projs, dmin, dmax, gt, mk = synthetic.make_training_batch(b, num_views=5, height=512, width=640, seed=2, hole_fraction=0.1)
+    model = Pipeline(iteration=int(g.np("iteration")), test=False)
+    model.load_state_dict(load_weights("seed0"))
+    model = model.to(DEV).train()
+    dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    out = model(dev(imgs), dev(projs), dmin.to(DEV), dmax.to(DEV))
+    assert out["depths_upsampled"][0].shape == (b, 1, 512, 640)
+    loss = full_loss(out["depths"], out["depths_upsampled"], out["confidences"], dev(gt), dev(mk), dmin.to(DEV), dmax.to(DEV), regress)
+    ref = float(g.np(f"{tag}.loss"))
+    loss.backward()
+    assert abs(loss.item() - ref) <= 2e-3 * abs(ref), (loss.item(), ref)
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for name, want in zip([str(x) for x in g.np(f"{tag}.grad_names")], g.np(f"{tag}.grad_norms")):
+        got = params[name].grad
+        if want < 0:
+            assert got is None or float(got.norm()) == 0.0, name
+        else:
+            assert got is not None, name
+            err = abs(float(got.norm()) - want) / max(want, 1e-3)
+            worst = max(worst, err)
+            assert err <= 6e-2, (name, float(got.norm()), want)
+    torch.set_num_threads(min(32, max(8, torch.get_num_threads())))
+    sample = {"imgs": imgs, "proj_matrices": projs, "depth_min": dmin, "depth_max": dmax}
+    floor, _, _ = gradient_chaos_floor(load_weights("seed0"), sample, gt, mk, int(g.np("iteration")), regress)
+    rep = check_gradient_slices(g, tag, {n: p.grad for n, p in params.items()}, rel_l2=GRAD_REL_L2_CFG4, min_cos=GRAD_MIN_COS_CFG4,
+                                floor=floor, floor_factor=1.0, min_checked=10)
+    print(f"train cfg4 B={b} {tag}: loss {loss.item():.6f} (reference {ref:.6f}); worst grad-norm deviation {worst:.2e}; "
+          f"gradient slices {rep}")
+    if regress:
+        d = out["depths_upsampled"][0].detach().cpu()
+        rel = (d[:, :, ::8, ::8] - g["train.depth_sub"]).abs() / g["train.depth_sub"]
+        assert float(rel.median()) <= 1e-5 and float((rel > 1e-4).float().mean()) <= 0.05
+
+
 def _gpu_step(model, sample, gt, mk, regress=True):
     dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
     dmin, dmax = sample["depth_min"].to(DEV), sample["depth_max"].to(DEV)
