@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define ITERMVS_ABI_VERSION 6
+#define ITERMVS_ABI_VERSION 7
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -155,7 +155,10 @@ typedef struct itermvs_corr_iter_params {
     itermvs_level_src src[3];                  /* [level-1]; channels-last (sc == 1)      */
     const float* ref_q;                        /* [B,H,W,C1+C2+C3] from itermvs_ref_quarter */
     const float* proj;                         /* [3,B,S,12] from itermvs_compose_proj    */
-    const float* view_w;                       /* [B,S,H,W] contiguous                    */
+    const float* view_w;                       /* view weights, element (b,s,y,x) at view_w[b*view_w_sb + s*view_w_ss + (y*W+x)*view_w_sp] */
+    int64_t view_w_sb, view_w_ss, view_w_sp;   /* all 0 = contiguous [B,S,H,W]; the engine stores them INTERLEAVED [B,H,W,S]
+                                                * (ss = 1, sp = S): the S weights of a pixel are one vector load of a lane
+                                                * quad.  itermvs_corr_iter_backward needs the contiguous form. */
     const float* depth[3];                     /* explicit hypotheses [B,N_l,H,W] or NULL */
     const float* norm_depth;                   /* normalised depth at norm_depth[b*norm_depth_sb + y*W + x]; used where depth[l] == NULL */
     int64_t norm_depth_sb;                     /* batch stride (elements) of norm_depth   */
@@ -215,9 +218,10 @@ int itermvs_view_aggregate(const float* corr, const float* w, int32_t S, int32_t
                            int32_t P, float* out, void* stream);
 /* itermvs_view_aggregate_up -- the same, and in the SAME launch (extra blocks: two independent pieces of work that only
  * read w) the x2 bilinear up-sampling of the view weights the iterations use (models/itermvs.py:56-57,71):
- *   w [B,S,H3,W3] -> w_up [B,S,2*H3,2*W3]. */
+ *   w [B,S,H3,W3] -> w_up [B,S,2*H3,2*W3], or, with w_up_interleaved != 0, the same values stored [B,2*H3,2*W3,S] (the
+ *   layout itermvs_corr_iter reads fastest: view_w_ss = 1, view_w_sp = S). */
 int itermvs_view_aggregate_up(const float* corr, const float* w, int32_t S, int32_t B, int32_t N, int32_t H3, int32_t W3,
-                              float* out, float* w_up, void* stream);
+                              float* out, float* w_up, int32_t w_up_interleaved, void* stream);
 
 /* itermvs_softmax_max -- models/itermvs.py:347-348 (PixelViewWeight tail)
  *   out[m,p] = max_n softmax_n(x[m,n,p]);  x [M,N,P] contiguous, out [M,P]. */

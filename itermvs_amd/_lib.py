@@ -14,7 +14,7 @@ MAX_SRC = 16
 MAX_HYP = 8
 GROUPS = 8
 F32, F16, BF16 = 0, 1, 2      # itermvs_dtype: storage type of feature maps
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitermvs_hip.so")
@@ -40,6 +40,7 @@ class CorrIterParams(C.Structure):
                 ("N", C.c_int32 * 3), ("impl", C.c_int32),
                 ("src", LevelSrc * 3),
                 ("ref_q", C.c_void_p), ("proj", C.c_void_p), ("view_w", C.c_void_p),
+                ("view_w_sb", C.c_int64), ("view_w_ss", C.c_int64), ("view_w_sp", C.c_int64),
                 ("depth", C.c_void_p * 3), ("norm_depth", C.c_void_p), ("norm_depth_sb", C.c_int64),
                 ("offsets", (C.c_float * MAX_HYP) * 3),
                 ("inv_depth_min", C.c_void_p), ("inv_depth_max", C.c_void_p),
@@ -81,7 +82,7 @@ PROTOTYPES = {
     "itermvs_ref_quarter_compose": (C.c_int, [C.POINTER(FMap)] * 3 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "itermvs_view_aggregate_up": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+                                            C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "itermvs_final_upsample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                          C.c_void_p]),

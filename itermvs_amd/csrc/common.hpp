@@ -179,8 +179,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 // F.interpolate(x, scale_factor=s, 'bilinear') for integer s, optional tanh: output element t of [M, H*s, W*s]
 // (bilinear_up_kernel, and the launches that carry it beside another piece of work)
+// `interleave` > 0: M = B * interleave maps, stored pixel-major [B, H*s, W*s, interleave] instead of planar
 __device__ __forceinline__ void bilinear_up_body(const float* __restrict__ x, int M, int H, int W, int scale, int act,
-                                                 float* __restrict__ out, int64_t t) {
+                                                 float* __restrict__ out, int64_t t, int interleave = 0) {
     const int OH = H * scale, OW = W * scale;
     if (t >= (int64_t)M * OH * OW) return;
     const int ox = (int)(t % OW);
@@ -202,7 +203,12 @@ __device__ __forceinline__ void bilinear_up_body(const float* __restrict__ x, in
     const float bot = xm[(size_t)y1 * W + x0] * lx0 + xm[(size_t)y1 * W + x1] * lx1;
     float v = top * ly0 + bot * ly1;
     if (act == 1) v = tanhf(v);
-    out[t] = v;
+    if (interleave > 0) {
+        const int bb = m / interleave, ss = m - bb * interleave;
+        out[(((int64_t)bb * OH + oy) * OW + ox) * interleave + ss] = v;
+    } else {
+        out[t] = v;
+    }
 }
 
 }  // namespace itermvs

@@ -77,7 +77,8 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
             d = unnormalize_depth(ns, inv_min, inv_max);
         }
         float refv[K::VEC];
-        load_vec<K::VEC>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff + j * 4, refv);
+        if constexpr (FT == ITERMVS_F32) load_vec<K::VEC>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff + j * 4, refv);
+        else load_ref16<CPG>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff, j, refv);      // 16-byte lanes (corr_common.hpp)
 
         const float xs = (float)x * g.xr, ys = (float)y * g.yr;
         float acc[K::NG];
@@ -97,7 +98,9 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
                 ray_dir(m, xs, ys, rx, ry, rz);
                 project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
                 mine = make_footprint(ix, iy, L.W1, L.H1, sy, sx);
-                w_mine = a.view_w[((size_t)b * a.S + s0 + j) * P + p];
+                // planar [B,S,H,W]: a scattered dword per lane; interleaved [B,H,W,S] (the engine's layout): the quad's four
+                // views are one 16-byte run and the wave's pixels one 64-byte run
+                w_mine = a.view_w[(int64_t)b * a.vw_sb + (int64_t)(s0 + j) * a.vw_ss + (int64_t)p * a.vw_sp];
             }
             const int nb = min(4, a.S - s0);          // wave-uniform
 #pragma unroll
@@ -106,7 +109,8 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
                     const Footprint tp = quad_footprint(mine, k);
                     const float wv = quad_bcast(w_mine, k);
                     float corr[K::NG];
-                    chunk_corr<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), joff, tp, refv, corr);
+                    if constexpr (FT == ITERMVS_F32) chunk_corr<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), joff, tp, refv, corr);
+                    else chunk_corr16<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), j, tp, refv, corr);
 #pragma unroll
                     for (int q = 0; q < K::NG; ++q) acc[q] = acc[q] + corr[q] * wv;  // itermvs.py:115
                     wsum = wsum + wv;                                                // itermvs.py:116
@@ -114,7 +118,8 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
             }
         }
 #pragma unroll
-        for (int q = 0; q < K::NG; ++q) lds[(n * ITERMVS_GROUPS + K::group(j, q)) * LS + px] = acc[q] / wsum;
+        for (int q = 0; q < K::NG; ++q)
+            lds[(n * ITERMVS_GROUPS + (FT == ITERMVS_F32 ? K::group(j, q) : group16<CPG>(j, q))) * LS + px] = acc[q] / wsum;
     }
     __syncthreads();
     const int rows = N * ITERMVS_GROUPS;
@@ -203,13 +208,24 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
         if (x >= a.W || y >= a.H) continue;
         const int p = y * a.W + x;
         float refv[K::VEC];
-        if (a.ref.sc == 1) {       // channels-last reference (the engine's layout): the chunk is VEC/4 vector loads off one address
-            load_feat<K::VEC, FT>(feat_base<FT>((const float*)a.ref.data, (int64_t)b * a.ref.sb),
-                                  (uint32_t)(y * (int)a.ref.sy + x * (int)a.ref.sx) + (uint32_t)(j * 4), refv);
-        } else {
+        if constexpr (FT == ITERMVS_F32) {
+            if (a.ref.sc == 1) {       // channels-last reference (the engine's layout): the chunk is VEC/4 vector loads off one address
+                load_feat<K::VEC, FT>(feat_base<FT>((const float*)a.ref.data, (int64_t)b * a.ref.sb),
+                                      (uint32_t)(y * (int)a.ref.sy + x * (int)a.ref.sx) + (uint32_t)(j * 4), refv);
+            } else {
 #pragma unroll
-            for (int c = 0; c < K::VEC; ++c)
-                refv[c] = ld_feat<FT>((const float*)a.ref.data, b * a.ref.sb + chunk_channel<K::VEC>(j, c) * a.ref.sc + y * a.ref.sy + x * a.ref.sx);
+                for (int c = 0; c < K::VEC; ++c)
+                    refv[c] = ld_feat<FT>((const float*)a.ref.data, b * a.ref.sb + chunk_channel<K::VEC>(j, c) * a.ref.sc + y * a.ref.sy + x * a.ref.sx);
+            }
+        } else {                       // 16-byte lanes (corr_common.hpp): another channel -> lane assignment
+            if (a.ref.sc == 1 && !(a.ref.sx & 7) && !(a.ref.sy & 7) && !(a.ref.sb & 7)) {
+                load_ref16_stored<CPG, FT>(reinterpret_cast<const char*>(feat_base<FT>((const float*)a.ref.data, (int64_t)b * a.ref.sb)),
+                                           2u * (uint32_t)(y * (int)a.ref.sy + x * (int)a.ref.sx), j, refv);
+            } else {
+#pragma unroll
+                for (int c = 0; c < K::VEC; ++c)
+                    refv[c] = ld_feat<FT>((const float*)a.ref.data, b * a.ref.sb + chunk16_channel<CPG>(j, c) * a.ref.sc + y * a.ref.sy + x * a.ref.sx);
+            }
         }
         // lane j projects hypothesis grp*LPT + j once; the quad then walks its LPT hypotheses and
         // every lane takes the footprint of hypothesis k from lane k (DPP quad_perm moves)
@@ -236,10 +252,12 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
             if (k < cnt) {
                 const Footprint tp = quad_footprint(mine, k);
                 float corr[K::NG];
-                chunk_corr<CPG, FT>(fsrc, joff, tp, refv, corr);
+                if constexpr (FT == ITERMVS_F32) chunk_corr<CPG, FT>(fsrc, joff, tp, refv, corr);
+                else chunk_corr16<CPG, FT>(fsrc, j, tp, refv, corr);
                 const int nl = grp * K::LPT + k;
 #pragma unroll
-                for (int q = 0; q < K::NG; ++q) lds[(nl * ITERMVS_GROUPS + K::group(j, q)) * LS + px] = corr[q];
+                for (int q = 0; q < K::NG; ++q)
+                    lds[(nl * ITERMVS_GROUPS + (FT == ITERMVS_F32 ? K::group(j, q) : group16<CPG>(j, q))) * LS + px] = corr[q];
             }
         }
     }
@@ -280,9 +298,10 @@ __global__ void __launch_bounds__(kThreads) corr_init_kernel(const InitArgs a) {
 // Blocks [0, n_agg) aggregate; the blocks after them (itermvs_view_aggregate_up) up-sample the view weights x2 for the
 // iterations (itermvs.py:56-57,71): both only read `w`, one launch instead of two.
 __global__ void view_aggregate_kernel(const float* __restrict__ corr, const float* __restrict__ w, int S, int B, int NG,
-                                      int P, float* __restrict__ out, int n_agg, int H3, int W3, float* __restrict__ w_up, int vec4) {
+                                      int P, float* __restrict__ out, int n_agg, int H3, int W3, float* __restrict__ w_up, int vec4,
+                                      int up_interleaved) {
     if ((int)blockIdx.x >= n_agg) {
-        bilinear_up_body(w, B * S, H3, W3, 2, 0, w_up, (int64_t)(blockIdx.x - n_agg) * blockDim.x + threadIdx.x);
+        bilinear_up_body(w, B * S, H3, W3, 2, 0, w_up, (int64_t)(blockIdx.x - n_agg) * blockDim.x + threadIdx.x, up_interleaved ? S : 0);
         return;
     }
     const int64_t per = (int64_t)NG * P;
@@ -447,6 +466,12 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
     a.ref_q = p->ref_q; a.proj = p->proj; a.view_w = p->view_w; a.nd = p->norm_depth; a.nd_sb = p->norm_depth_sb;
     a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max;
     a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.CQ = coff;
+    if (p->view_w_sb == 0 && p->view_w_ss == 0 && p->view_w_sp == 0) {      // default: planar [B,S,H,W]
+        a.vw_sp = 1; a.vw_ss = (int64_t)p->H * p->W; a.vw_sb = a.vw_ss * p->S;
+    } else {
+        ITERMVS_RETURN_IF(p->view_w_ss < 1 || p->view_w_sp < 1 || p->view_w_sb < 0, ITERMVS_ERR_LAYOUT);
+        a.vw_sb = p->view_w_sb; a.vw_ss = p->view_w_ss; a.vw_sp = p->view_w_sp;
+    }
     // One form: source views walked inside the lane.  (A views-across-waves form issued 14 % fewer vector instructions but
     // missed the vector L1 31 % more often -- 33.4 vs 28.9 us, profiles/r02 -- and was removed; `impl` is reserved.)
     ITERMVS_RETURN_IF(p->impl != 0, ITERMVS_ERR_DIMS);
@@ -505,12 +530,12 @@ extern "C" int itermvs_view_aggregate(const float* corr, const float* w, int32_t
     const int64_t total = ((int64_t)B * N * ITERMVS_GROUPS * P) / (vec4 ? 4 : 1);
     const int na = (int)((total + 255) / 256);
     hipLaunchKernelGGL(view_aggregate_kernel, dim3((unsigned)na), dim3(256), 0, (hipStream_t)stream,
-                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, 0, 0, (float*)nullptr, vec4);
+                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, 0, 0, (float*)nullptr, vec4, 0);
     return itermvs_launch_status();
 }
 
 extern "C" int itermvs_view_aggregate_up(const float* corr, const float* w, int32_t S, int32_t B, int32_t N, int32_t H3, int32_t W3,
-                                         float* out, float* w_up, void* stream) {
+                                         float* out, float* w_up, int32_t w_up_interleaved, void* stream) {
     ITERMVS_RETURN_IF(!corr || !w || !out || !w_up, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(S < 1 || B < 1 || N < 1 || H3 < 1 || W3 < 1, ITERMVS_ERR_DIMS);
     const int P = H3 * W3;
@@ -518,7 +543,7 @@ extern "C" int itermvs_view_aggregate_up(const float* corr, const float* w, int3
     const int na = (int)(((int64_t)B * N * ITERMVS_GROUPS * P / (vec4 ? 4 : 1) + 255) / 256);
     const int nu = (int)(((int64_t)B * S * P * 4 + 255) / 256);
     hipLaunchKernelGGL(view_aggregate_kernel, dim3((unsigned)(na + nu)), dim3(256), 0, (hipStream_t)stream,
-                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, H3, W3, w_up, vec4);
+                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, H3, W3, w_up, vec4, w_up_interleaved ? 1 : 0);
     return itermvs_launch_status();
 }
 

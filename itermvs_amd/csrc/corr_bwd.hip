@@ -427,6 +427,10 @@ extern "C" int itermvs_corr_iter_backward(const itermvs_corr_iter_params* p, con
     ITERMVS_RETURN_IF(p->B < 1 || p->H < 1 || p->W < 1, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(p->S < 1 || p->S > ITERMVS_MAX_SRC, ITERMVS_ERR_VIEWS);
     ITERMVS_RETURN_IF(!p->ref_q || !p->proj || !p->view_w || !p->inv_depth_min || !p->inv_depth_max, ITERMVS_ERR_NULL);
+    // the gradient kernels read the view weights in the contiguous [B,S,H,W] form only
+    ITERMVS_RETURN_IF((p->view_w_sb || p->view_w_ss || p->view_w_sp) &&
+                      !(p->view_w_sp == 1 && p->view_w_ss == (int64_t)p->H * p->W && p->view_w_sb == (int64_t)p->S * p->H * p->W),
+                      ITERMVS_ERR_LAYOUT);
     BwdArgs a;
     const int cq = p->src[0].C + p->src[1].C + p->src[2].C;
     int coff = 0;

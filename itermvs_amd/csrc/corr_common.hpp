@@ -275,6 +275,187 @@ __device__ __forceinline__ void chunk_corr(const float* __restrict__ fbase, uint
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 16-bit feature storage (fp16 / bf16), 16-BYTE lanes.  A wave-level vector load occupies the CU's texture-address path for
+// one quad of lanes per cycle whatever the lanes' width (profiles/r03: with 8-byte lanes the fp16 kernels issued exactly the
+// fp32 kernels' load instructions and ran no faster), so with 2-byte elements every lane fetches 16 bytes = 8 channels and a
+// pixel's taps need HALF the load instructions of the fp32 layout:
+//   C = 32 (64 B per pixel): one quad load per tap; lane j owns channels 8j .. 8j+7 = correlation groups 2j, 2j+1
+//   C = 16 (32 B per pixel): one quad load per ROW of the footprint: lanes 0,1 fetch the x0 tap, lanes 2,3 the x1 tap (a
+//                            contiguous 64-byte run when x1 = x0 + 1), then the halves are exchanged inside the quad
+//                            (exchange16) so that lane j holds 4 channels of BOTH taps: channels cb(j) .. cb(j)+3
+//   C = 48 (96 B per pixel): per row two full loads (channels 0..31 of x0 and of x1) + one half-quad load of channels
+//                            32..47 of both taps: six loads per footprint instead of twelve; lane j owns channels
+//                            8j .. 8j+7 and 32 + cb(j) .. 32 + cb(j) + 3
+// cb(j) = 8 * (j & 1) + 4 * (j >> 1)   (lane 0: 0, lane 1: 8, lane 2: 4, lane 3: 12).
+// The arithmetic per channel (fma chain over the four taps), per channel pair and per group is EXACTLY that of the fp32
+// layout above (same operations, same association), only the lane that holds a channel differs: results are bit-identical
+// to the fp32 kernels run on the same values (tests/test_kernels_gpu.py::test_16bit_feature_storage_matches_...).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int chunk16_cb(int j) { return 8 * (j & 1) + 4 * (j >> 1); }
+
+// correlation groups lane j finalises (slot q = 0, 1) with 16-byte lanes
+template <int CPG>
+__device__ __forceinline__ int group16(int j, int q) {
+    if constexpr (CPG == 2) return chunk16_cb(j) / 2 + q;       // lane 0: 0,1   lane 1: 4,5   lane 2: 2,3   lane 3: 6,7
+    else if constexpr (CPG == 4) return 2 * j + q;
+    else return q == 0 ? (j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 3 : 4) : (j == 0 ? 1 : j == 1 ? 7 : j == 2 ? 6 : 5);   // see regroup48
+}
+
+// floats of the reference chunk a lane multiplies with (element offsets relative to the level's first channel):
+// VEC floats in the order the lane's channels are listed above
+template <int CPG>
+__device__ __forceinline__ void load_ref16(const float* __restrict__ r, int j, float (&refv)[2 * CPG]) {
+    if constexpr (CPG == 2) {
+        load_vec<4>(r + chunk16_cb(j), refv);
+    } else {
+        const float4 a = *reinterpret_cast<const float4*>(r + 8 * j), b = *reinterpret_cast<const float4*>(r + 8 * j + 4);
+        refv[0] = a.x; refv[1] = a.y; refv[2] = a.z; refv[3] = a.w; refv[4] = b.x; refv[5] = b.y; refv[6] = b.z; refv[7] = b.w;
+        if constexpr (CPG == 6) {
+            const float4 c = *reinterpret_cast<const float4*>(r + 32 + chunk16_cb(j));
+            refv[8] = c.x; refv[9] = c.y; refv[10] = c.z; refv[11] = c.w;
+        }
+    }
+}
+// channel of element c of lane j's 16-byte-lane chunk (load_ref16 order)
+template <int CPG>
+__device__ __forceinline__ int chunk16_channel(int j, int c) {
+    if constexpr (CPG == 2) return chunk16_cb(j) + c;
+    else return c < 8 ? 8 * j + c : 32 + chunk16_cb(j) + (c - 8);
+}
+// the same chunk from a 16-bit channels-last map (initialisation branch: the reference features are stored like the sources)
+template <int FT>
+__device__ __forceinline__ void cvt_pair(uint32_t d, float& lo, float& hi) {   // two packed 16-bit values -> fp32
+    if constexpr (FT == ITERMVS_BF16) { lo = __uint_as_float(d << 16); hi = __uint_as_float(d & 0xffff0000u); }
+    else { lo = cvt16<FT>(d); hi = cvt16<FT>(d >> 16); }
+}
+template <int CPG, int FT>
+__device__ __forceinline__ void load_ref16_stored(const char* __restrict__ base, uint32_t byte_off, int j, float (&refv)[2 * CPG]) {
+    if constexpr (CPG == 2) {
+        const uint2 t = *reinterpret_cast<const uint2*>(base + byte_off + 2u * (uint32_t)chunk16_cb(j));
+        cvt_pair<FT>(t.x, refv[0], refv[1]); cvt_pair<FT>(t.y, refv[2], refv[3]);
+    } else {
+        const uint4 t = *reinterpret_cast<const uint4*>(base + byte_off + 16u * (uint32_t)j);
+        cvt_pair<FT>(t.x, refv[0], refv[1]); cvt_pair<FT>(t.y, refv[2], refv[3]);
+        cvt_pair<FT>(t.z, refv[4], refv[5]); cvt_pair<FT>(t.w, refv[6], refv[7]);
+        if constexpr (CPG == 6) {
+            const uint2 u = *reinterpret_cast<const uint2*>(base + byte_off + 64u + 2u * (uint32_t)chunk16_cb(j));
+            cvt_pair<FT>(u.x, refv[8], refv[9]); cvt_pair<FT>(u.y, refv[10], refv[11]);
+        }
+    }
+}
+
+__device__ __forceinline__ uint4 load16_at(const char* __restrict__ base, uint32_t byte_off) {
+    return *reinterpret_cast<const uint4*>(base + byte_off);
+}
+__device__ __forceinline__ uint32_t quad_swap2(uint32_t x) {       // lane l <- lane l ^ 2 of its quad
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, ITERMVS_QP(2, 3, 0, 1), 0xf, 0xf, true);
+}
+// Half-quad load -> both taps of the lane's four channels.  `d` = the 16 bytes the lane loaded: lanes 0,1 hold channels
+// 0..7 / 8..15 of the LEFT tap (x0), lanes 2,3 the same channels of the RIGHT tap (x1).  Afterwards every lane holds, for
+// its channels cb(j) .. cb(j)+3, the left tap in (l0, l1) and the right tap in (r0, r1) (two packed 16-bit values per dword):
+//   low lanes  (0,1): left = own d.x, d.y              right = partner's d.x, d.y
+//   high lanes (2,3): left = partner's d.z, d.w        right = own d.z, d.w
+__device__ __forceinline__ void exchange16(const uint4& d, bool high, uint32_t& l0, uint32_t& l1, uint32_t& r0, uint32_t& r1) {
+    const uint32_t sx = quad_swap2(d.x), sy = quad_swap2(d.y), sz = quad_swap2(d.z), sw = quad_swap2(d.w);
+    l0 = high ? sz : d.x;
+    l1 = high ? sw : d.y;
+    r0 = high ? d.z : sx;
+    r1 = high ? d.w : sy;
+}
+
+// bilinear blend of four channels (two packed dwords per tap): the per-channel fma chain of chunk_corr
+template <int FT>
+__device__ __forceinline__ void blend4_pairs(const Footprint& tp, uint32_t a00, uint32_t b00, uint32_t a01, uint32_t b01,
+                                             uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11, float (&w)[4]) {
+    float v00[4], v01[4], v10[4], v11[4];
+    cvt_pair<FT>(a00, v00[0], v00[1]); cvt_pair<FT>(b00, v00[2], v00[3]);
+    cvt_pair<FT>(a01, v01[0], v01[1]); cvt_pair<FT>(b01, v01[2], v01[3]);
+    cvt_pair<FT>(a10, v10[0], v10[1]); cvt_pair<FT>(b10, v10[2], v10[3]);
+    cvt_pair<FT>(a11, v11[0], v11[1]); cvt_pair<FT>(b11, v11[2], v11[3]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        w[c] = fmaf(tp.se, v11[c], fmaf(tp.sw, v10[c], fmaf(tp.ne, v01[c], tp.nw * v00[c])));
+}
+
+// One view's group correlations for one lane with 16-byte lanes (see the table above).  `fb`: wave-uniform base of the view's
+// map; the footprint's offsets are BYTES.  `refv`: the lane's reference chunk in load_ref16 order.  corr[q] belongs to group
+// group16<CPG>(j, q).
+template <int CPG, int FT>
+__device__ __forceinline__ void chunk_corr16(const float* __restrict__ fbase, int j, const Footprint& tp,
+                                             const float (&refv)[2 * CPG], float (&corr)[2]) {
+    const char* __restrict__ fb = reinterpret_cast<const char*>(fbase);
+    const bool high = (j & 2) != 0;
+    if constexpr (CPG == 4) {
+        // a full 64-byte pixel per quad load: channels 8j .. 8j+7
+        const uint32_t jo = 16u * (uint32_t)j;
+        const uint4 t00 = load16_at(fb, tp.r0 + tp.c0 + jo), t01 = load16_at(fb, tp.r0 + tp.c1 + jo);
+        const uint4 t10 = load16_at(fb, tp.r1 + tp.c0 + jo), t11 = load16_at(fb, tp.r1 + tp.c1 + jo);
+        float wa[4], wb[4];
+        blend4_pairs<FT>(tp, t00.x, t00.y, t01.x, t01.y, t10.x, t10.y, t11.x, t11.y, wa);
+        blend4_pairs<FT>(tp, t00.z, t00.w, t01.z, t01.w, t10.z, t10.w, t11.z, t11.w, wb);
+        // one 4-channel group per half: a single fma chain (itermvs.py:103-104 order), like chunk_corr<4>
+        corr[0] = fmaf(wa[3], refv[3], fmaf(wa[2], refv[2], fmaf(wa[1], refv[1], wa[0] * refv[0]))) * 0.25f;
+        corr[1] = fmaf(wb[3], refv[7], fmaf(wb[2], refv[6], fmaf(wb[1], refv[5], wb[0] * refv[4]))) * 0.25f;
+    } else {
+        // half-quad addressing: lanes 0,1 -> column x0, lanes 2,3 -> column x1; 16 bytes at piece (j & 1)
+        const uint32_t col = (high ? tp.c1 : tp.c0) + 16u * (uint32_t)(j & 1);
+        if constexpr (CPG == 2) {
+            const uint4 d0 = load16_at(fb, tp.r0 + col), d1 = load16_at(fb, tp.r1 + col);
+            uint32_t a00, b00, a01, b01, a10, b10, a11, b11;
+            exchange16(d0, high, a00, b00, a01, b01);
+            exchange16(d1, high, a10, b10, a11, b11);
+            float w[4];
+            blend4_pairs<FT>(tp, a00, b00, a01, b01, a10, b10, a11, b11, w);
+            corr[0] = fmaf(w[1], refv[1], w[0] * refv[0]) * 0.5f;
+            corr[1] = fmaf(w[3], refv[3], w[2] * refv[2]) * 0.5f;
+        } else {
+            const uint32_t jo = 16u * (uint32_t)j;
+            float p[4], e[2];
+            {   // channels 8j .. 8j+7 of the four taps: pairs p0..p3
+                const uint4 t00 = load16_at(fb, tp.r0 + tp.c0 + jo), t01 = load16_at(fb, tp.r0 + tp.c1 + jo);
+                const uint4 t10 = load16_at(fb, tp.r1 + tp.c0 + jo), t11 = load16_at(fb, tp.r1 + tp.c1 + jo);
+                float wa[4], wb[4];
+                blend4_pairs<FT>(tp, t00.x, t00.y, t01.x, t01.y, t10.x, t10.y, t11.x, t11.y, wa);
+                blend4_pairs<FT>(tp, t00.z, t00.w, t01.z, t01.w, t10.z, t10.w, t11.z, t11.w, wb);
+                p[0] = fmaf(wa[1], refv[1], wa[0] * refv[0]);
+                p[1] = fmaf(wa[3], refv[3], wa[2] * refv[2]);
+                p[2] = fmaf(wb[1], refv[5], wb[0] * refv[4]);
+                p[3] = fmaf(wb[3], refv[7], wb[2] * refv[6]);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // the tail's loads stay behind the main block's blend (register pressure)
+            {   // channels 32 + cb(j) .. +3 of the four taps: pairs e0, e1
+                const uint4 d0 = load16_at(fb, tp.r0 + col + 64u), d1 = load16_at(fb, tp.r1 + col + 64u);
+                uint32_t a00, b00, a01, b01, a10, b10, a11, b11;
+                exchange16(d0, high, a00, b00, a01, b01);
+                exchange16(d1, high, a10, b10, a11, b11);
+                float w[4];
+                blend4_pairs<FT>(tp, a00, b00, a01, b01, a10, b10, a11, b11, w);
+                e[0] = fmaf(w[1], refv[9], w[0] * refv[8]);
+                e[1] = fmaf(w[3], refv[11], w[2] * refv[10]);
+            }
+            // regroup48.  P_k = channel pair (2k, 2k+1); lane j holds p_i = P_{4j+i} and (e0, e1) = P16,17 / P20,21 / P18,19 /
+            // P22,23 for j = 0 / 1 / 2 / 3.  Group g = P_{3g} , P_{3g+1}, P_{3g+2} with the association of chunk_corr<6>:
+            // even groups (A + B) + C, odd groups A + (B + C):
+            //   g0 = (P0+P1)+P2      lane 0: (p0+p1) + p2             g1 = P3+(P4+P5)      lane 0: p3 + [lane 1: p0+p1]
+            //   g2 = (P6+P7)+P8      lane 1: (p2+p3) + [lane 2: p0]   g3 = P9+(P10+P11)    lane 2: p1 + (p2+p3)
+            //   g4 = (P12+P13)+P14   lane 3: (p0+p1) + p2             g5 = P15+(P16+P17)   lane 3: p3 + [lane 0: e0+e1]
+            //   g6 = (P18+P19)+P20   lane 2: (e0+e1) + [lane 1: e0]   g7 = P21+(P22+P23)   lane 1: e1 + [lane 3: e0+e1]
+            const float s01 = p[0] + p[1], s23 = p[2] + p[3], se = e[0] + e[1];
+            const float send1 = j == 0 ? se : (j == 1 ? s01 : p[0]);
+            const float send2 = j == 1 ? e[0] : se;
+            const float r1 = quad_perm<ITERMVS_QP(1, 2, 1, 0)>(send1);      // lane 0 <- 1, lane 1 <- 2, lane 3 <- 0
+            const float r2 = quad_perm<ITERMVS_QP(0, 3, 1, 0)>(send2);      // lane 1 <- 3, lane 2 <- 1
+            const float xa = j == 2 ? p[1] : (j == 1 ? s23 : s01);
+            const float ya = j == 1 ? r1 : (j == 2 ? s23 : p[2]);
+            const float xb = (j == 0 || j == 3) ? p[3] : (j == 1 ? e[1] : se);
+            const float yb = (j == 0 || j == 3) ? r1 : r2;
+            corr[0] = div_rcp(xa + ya, 6.0f, 1.0f / 6.0f);
+            corr[1] = div_rcp(xb + yb, 6.0f, 1.0f / 6.0f);
+        }
+    }
+}
+
 // XCD-aware tile order: block k is observed to run on XCD k % 8 (a speed assumption only), so give
 // each XCD a contiguous band of pixel tiles; neighbouring tiles then share one L2 instead of having
 // every L2 fetch its own copy of the same source lines.  grid.x is a multiple of 8.
@@ -297,6 +478,7 @@ struct IterArgs {
     const float* ref_q;
     const float* proj;
     const float* view_w;
+    int64_t vw_sb, vw_ss, vw_sp;     // element strides of view_w: batch, view, pixel (p = y * W + x)
     const float* nd;
     int64_t nd_sb;
     const float* inv_min;
@@ -313,6 +495,8 @@ static inline int itermvs_check_level(const itermvs_level_src& s, int S) {
     ITERMVS_RETURN_IF(s.sc != 1, ITERMVS_ERR_LAYOUT);
     ITERMVS_RETURN_IF(s.dtype < ITERMVS_F32 || s.dtype > ITERMVS_BF16, ITERMVS_ERR_DTYPE);
     ITERMVS_RETURN_IF((s.sx % 4) || (s.sy % 4) || (s.sb % 4), ITERMVS_ERR_ALIGN);
+    // 16-bit storage is read with 16-byte lanes: every pixel vector starts on a 16-byte boundary
+    ITERMVS_RETURN_IF(s.dtype != ITERMVS_F32 && ((s.sx % 8) || (s.sy % 8) || (s.sb % 8)), ITERMVS_ERR_ALIGN);
     // 32-bit BYTE offsets of the taps inside one view's map
     ITERMVS_RETURN_IF(s.sx <= 0 || s.sy <= 0 || (int64_t)s.H * s.sy * (s.dtype == ITERMVS_F32 ? 4 : 2) >= (int64_t)1 << 32, ITERMVS_ERR_DIMS);
     for (int v = 0; v < S; ++v) {

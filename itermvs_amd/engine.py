@@ -249,7 +249,8 @@ class InferenceEngine:
         # 16-channel tensor is never stored), then softmax over the 32 hypotheses and its maximum
         logit = self._conv(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), pv + "conv.0.conv.", act="relu_dot", aux1=self.pvw_dot)
         vw = ops.softmax_max(logit.view(b * s, INIT_SAMPLES, h3, w3))
-        agg0, view_w = ops.view_aggregate_up(corr_v, vw.view(b, s, h3, w3))       # [B,32,8,h3,w3]; view weights x2: itermvs.py:56-57,71
+        # [B,32,8,h3,w3]; view weights x2 (itermvs.py:56-57,71), stored pixel-major [B,h,w,S] for the iteration kernel
+        agg0, view_w = ops.view_aggregate_up(corr_v, vw.view(b, s, h3, w3), interleaved=True)
         score0 = self.stage_score0(agg0)
         self.stage_hidden0(ws, score0)
         if trace is not None:

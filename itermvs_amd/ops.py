@@ -223,7 +223,14 @@ def corr_iter(src: Dict[int, Sequence[Tensor]], ref_q: Tensor, proj: Tensor, vie
         p.norm_depth = norm_depth.data_ptr()
         p.norm_depth_sb = norm_depth.stride(0)
     proj = _dev(proj, "proj").contiguous()
-    view_w = _dev(view_w, "view_w").contiguous()
+    # [B,S,H,W] with any batch / view / pixel strides whose rows are dense in the pixel stride: contiguous, or the
+    # interleaved [B,H,W,S] storage view_aggregate_up(interleaved=True) returns (one vector load per lane quad)
+    _dev(view_w, "view_w")
+    if tuple(view_w.shape) != (b, s, h, w):
+        raise RuntimeError(f"corr_iter: view_w must be [B,S,H,W] = {(b, s, h, w)}, got {tuple(view_w.shape)}")
+    if view_w.dtype != torch.float32 or view_w.stride(2) != w * view_w.stride(3) or min(view_w.stride()) < 1:
+        view_w = view_w.float().contiguous()
+    p.view_w_sb, p.view_w_ss, p.view_w_sp = view_w.stride(0), view_w.stride(1), view_w.stride(3)
     p.ref_q, p.proj, p.view_w = _dev(ref_q, "ref_q").data_ptr(), proj.data_ptr(), view_w.data_ptr()
     p.inv_depth_min, p.inv_depth_max = _dev(inv_min, "inv_min").data_ptr(), _dev(inv_max, "inv_max").data_ptr()
     lib = _lib.load()
@@ -483,16 +490,22 @@ def view_aggregate(corr: Tensor, w: Tensor) -> Tensor:
     return out
 
 
-def view_aggregate_up(corr: Tensor, w: Tensor) -> Tuple[Tensor, Tensor]:
+def view_aggregate_up(corr: Tensor, w: Tensor, interleaved: bool = False) -> Tuple[Tensor, Tensor]:
     """view_aggregate and, in the same launch, the x2 bilinear up-sampling of the view weights (itermvs.py:56-57,71):
-    corr [B,S,N,8,H,W], w [B,S,H,W] -> ([B,N,8,H,W], [B,S,2H,2W])."""
+    corr [B,S,N,8,H,W], w [B,S,H,W] -> ([B,N,8,H,W], [B,S,2H,2W]).  ``interleaved``: the up-sampled weights are STORED
+    [B,2H,2W,S] and returned as the permuted [B,S,2H,2W] view of that storage -- same values, the layout corr_iter reads with
+    one vector load per lane quad."""
     b, s, n, g, h, wd = corr.shape
     corr = _dev(corr, "corr").contiguous()
     w = _dev(w, "w").contiguous()
     out = torch.empty((b, n, g, h, wd), device=corr.device, dtype=torch.float32)
-    w_up = torch.empty((b, s, 2 * h, 2 * wd), device=corr.device, dtype=torch.float32)
-    check(_lib.load().itermvs_view_aggregate_up(corr.data_ptr(), w.data_ptr(), s, b, n, h, wd, out.data_ptr(), w_up.data_ptr(),
-                                                _stream()), "itermvs_view_aggregate_up")
+    if interleaved:
+        store = torch.empty((b, 2 * h, 2 * wd, s), device=corr.device, dtype=torch.float32)
+        w_up = store.permute(0, 3, 1, 2)
+    else:
+        store = w_up = torch.empty((b, s, 2 * h, 2 * wd), device=corr.device, dtype=torch.float32)
+    check(_lib.load().itermvs_view_aggregate_up(corr.data_ptr(), w.data_ptr(), s, b, n, h, wd, out.data_ptr(), store.data_ptr(),
+                                                1 if interleaved else 0, _stream()), "itermvs_view_aggregate_up")
     return out, w_up
 
 

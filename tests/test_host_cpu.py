@@ -41,7 +41,7 @@ def test_struct_layout_matches_header_sizes():
     from itermvs_amd import _lib
     assert C.sizeof(_lib.FMap) == 8 + 4 * 8 + 4 * 4
     assert C.sizeof(_lib.LevelSrc) == 16 * 8 + 4 * 8 + 4 * 4
-    assert C.sizeof(_lib.CorrIterParams) == 8 * 4 + 3 * C.sizeof(_lib.LevelSrc) + 3 * 8 + 3 * 8 + 8 + 8 + 3 * 8 * 4 + 2 * 8 + 3 * 8
+    assert C.sizeof(_lib.CorrIterParams) == 8 * 4 + 3 * C.sizeof(_lib.LevelSrc) + 3 * 8 + 3 * 8 + 3 * 8 + 8 + 8 + 3 * 8 * 4 + 2 * 8 + 3 * 8
     assert C.sizeof(_lib.CorrInitParams) == 6 * 4 + C.sizeof(_lib.LevelSrc) + C.sizeof(_lib.FMap) + 5 * 8
 
 

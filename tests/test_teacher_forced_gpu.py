@@ -284,7 +284,7 @@ def test_corr_iter_backward_on_the_oracles_training_tensors(cfg4_backward_trace,
         scale = max(1e-30, float(g_ref.abs().max()))
         rep[l] = float((fg[l].grad.cpu() - g_ref).abs().max()) / scale
         assert rep[l] <= 1e-4, (l, rep[l], scale)
-        assert float(fg[l].grad.view(b, v, -1)[:, 0].abs().max()) == 0.0                        # reference view: through ref_q only
+        assert float(fg[l].grad.reshape(b, v, -1)[:, 0].abs().max()) == 0.0                     # reference view: through ref_q only
     scale = max(1e-30, float(ref_q.grad.abs().max()))
     rep["ref_q"] = float((rqd.grad.cpu() - ref_q.grad).abs().max()) / scale
     assert rep["ref_q"] <= 1e-4, rep
