@@ -46,7 +46,8 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
     if (tile >= tiles_x * tiles_y) return;          // padding blocks of the XCD-aligned grid (uniform per block)
     const int tile_ty = tile / tiles_x, tile_tx = tile - tile_ty * tiles_x;
     const int x0 = tile_tx * TW, y0 = tile_ty * TH;
-    const int per_px = N * K::LPT;
+    constexpr int LPT = K::LPT, NGL = K::NG;      // lanes per (pixel, hypothesis), groups finalised per lane
+    const int per_px = N * LPT;
     const int items = TILE * per_px;
     const WarpGeom g = make_geom(a.W, a.H, L.W1, L.H1);
     const WarpRcp rc = make_rcp(g);
@@ -62,8 +63,8 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
     for (int item = threadIdx.x; item < items; item += kThreads) {
         const int px = px_shift >= 0 ? item >> px_shift : item / per_px;
         const int rem = item - px * per_px;
-        const int n = rem / K::LPT;
-        const int j = rem - n * K::LPT;      // the LPT lanes of one (pixel, hypothesis) are adjacent lanes
+        const int n = rem / LPT;
+        const int j = rem - n * LPT;         // the LPT lanes of one (pixel, hypothesis) are adjacent lanes
         const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
         if (x >= a.W || y >= a.H) continue;  // whole lane groups drop out together
         const int p = y * a.W + x;
@@ -81,15 +82,15 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
         else load_ref16<CPG>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff, j, refv);      // 16-byte lanes (corr_common.hpp)
 
         const float xs = (float)x * g.xr, ys = (float)y * g.yr;
-        float acc[K::NG];
+        float acc[NGL];
 #pragma unroll
-        for (int q = 0; q < K::NG; ++q) acc[q] = 0.0f;
+        for (int q = 0; q < NGL; ++q) acc[q] = 0.0f;
         float wsum = 1e-5f;  // itermvs.py:88
         const uint32_t joff = (uint32_t)(j * 4) * feat_bytes<FT>();
         // The projection, the bilinear footprint and the view weight of (pixel, hypothesis) in view s are the same for the
         // four chunk lanes: lane j evaluates them for view s0 + j, then the quad walks the batch of views and every lane
         // takes view s0 + k's from lane k with DPP quad_perm moves.
-        for (int s0 = 0; s0 < a.S; s0 += 4) {
+        for (int s0 = 0; s0 < a.S; s0 += LPT) {
             Footprint mine = {0u, 0u, 0u, 0u, 0.0f, 0.0f, 0.0f, 0.0f};
             float w_mine = 0.0f;
             if (s0 + j < a.S) {
@@ -102,23 +103,23 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
                 // views are one 16-byte run and the wave's pixels one 64-byte run
                 w_mine = a.view_w[(int64_t)b * a.vw_sb + (int64_t)(s0 + j) * a.vw_ss + (int64_t)p * a.vw_sp];
             }
-            const int nb = min(4, a.S - s0);          // wave-uniform
+            const int nb = min(LPT, a.S - s0);        // wave-uniform
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < LPT; ++k) {
                 if (k < nb) {
                     const Footprint tp = quad_footprint(mine, k);
                     const float wv = quad_bcast(w_mine, k);
-                    float corr[K::NG];
+                    float corr[NGL];
                     if constexpr (FT == ITERMVS_F32) chunk_corr<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), joff, tp, refv, corr);
                     else chunk_corr16<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), j, tp, refv, corr);
 #pragma unroll
-                    for (int q = 0; q < K::NG; ++q) acc[q] = acc[q] + corr[q] * wv;  // itermvs.py:115
+                    for (int q = 0; q < NGL; ++q) acc[q] = acc[q] + corr[q] * wv;  // itermvs.py:115
                     wsum = wsum + wv;                                                // itermvs.py:116
                 }
             }
         }
 #pragma unroll
-        for (int q = 0; q < K::NG; ++q)
+        for (int q = 0; q < NGL; ++q)
             lds[(n * ITERMVS_GROUPS + (FT == ITERMVS_F32 ? K::group(j, q) : group16<CPG>(j, q))) * LS + px] = acc[q] / wsum;
     }
     __syncthreads();
@@ -187,8 +188,9 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
     if (tile >= tiles_x * tiles_y) return;
     const int tile_ty = tile / tiles_x, tile_tx = tile - tile_ty * tiles_x;
     const int x0 = tile_tx * TW, y0 = tile_ty * TH;
-    const int ngrp = (nb + K::LPT - 1) / K::LPT;   // groups of LPT hypotheses
-    const int per_px = ngrp * K::LPT;
+    constexpr int LPT = K::LPT, NGL = K::NG;
+    const int ngrp = (nb + LPT - 1) / LPT;   // groups of LPT hypotheses
+    const int per_px = ngrp * LPT;
     const int items = TILE * per_px;
     const WarpGeom g = make_geom(a.W, a.H, a.W1, a.H1);
     const WarpRcp rc = make_rcp(g);
@@ -202,8 +204,8 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
     for (int item = threadIdx.x; item < items; item += kThreads) {
         const int px = px_shift >= 0 ? item >> px_shift : item / per_px;
         const int rem = item - px * per_px;
-        const int grp = rem / K::LPT;
-        const int j = rem - grp * K::LPT;
+        const int grp = rem / LPT;
+        const int j = rem - grp * LPT;
         const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
         if (x >= a.W || y >= a.H) continue;
         const int p = y * a.W + x;
@@ -218,9 +220,11 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
                     refv[c] = ld_feat<FT>((const float*)a.ref.data, b * a.ref.sb + chunk_channel<K::VEC>(j, c) * a.ref.sc + y * a.ref.sy + x * a.ref.sx);
             }
         } else {                       // 16-byte lanes (corr_common.hpp): another channel -> lane assignment
-            if (a.ref.sc == 1 && !(a.ref.sx & 7) && !(a.ref.sy & 7) && !(a.ref.sb & 7)) {
-                load_ref16_stored<CPG, FT>(reinterpret_cast<const char*>(feat_base<FT>((const float*)a.ref.data, (int64_t)b * a.ref.sb)),
-                                           2u * (uint32_t)(y * (int)a.ref.sy + x * (int)a.ref.sx), j, refv);
+            const char* rb = reinterpret_cast<const char*>(feat_base<FT>((const float*)a.ref.data, (int64_t)b * a.ref.sb));
+            const uint32_t ro = 2u * (uint32_t)(y * (int)a.ref.sy + x * (int)a.ref.sx);
+            const bool vec = a.ref.sc == 1 && !(a.ref.sx & 7) && !(a.ref.sy & 7) && !(a.ref.sb & 7);
+            if (vec) {
+                load_ref16_stored<CPG, FT>(rb, ro, j, refv);
             } else {
 #pragma unroll
                 for (int c = 0; c < K::VEC; ++c)
@@ -229,7 +233,7 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
         }
         // lane j projects hypothesis grp*LPT + j once; the quad then walks its LPT hypotheses and
         // every lane takes the footprint of hypothesis k from lane k (DPP quad_perm moves)
-        const int nl_mine = grp * K::LPT + j;
+        const int nl_mine = grp * LPT + j;
         Footprint mine = {0u, 0u, 0u, 0u, 0.0f, 0.0f, 0.0f, 0.0f};
         if (nl_mine < nb) {
             const int n = n0 + nl_mine;
@@ -246,17 +250,17 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
             mine = make_footprint(ix, iy, a.W1, a.H1, sy, sx);
         }
         const uint32_t joff = (uint32_t)(j * 4) * feat_bytes<FT>();
-        const int cnt = min(K::LPT, nb - grp * K::LPT);      // uniform per quad; whole quads take the branch together
+        const int cnt = min(LPT, nb - grp * LPT);      // uniform per lane group; whole groups take the branch together
 #pragma unroll
-        for (int k = 0; k < K::LPT; ++k) {
+        for (int k = 0; k < LPT; ++k) {
             if (k < cnt) {
                 const Footprint tp = quad_footprint(mine, k);
-                float corr[K::NG];
+                float corr[NGL];
                 if constexpr (FT == ITERMVS_F32) chunk_corr<CPG, FT>(fsrc, joff, tp, refv, corr);
                 else chunk_corr16<CPG, FT>(fsrc, j, tp, refv, corr);
-                const int nl = grp * K::LPT + k;
+                const int nl = grp * LPT + k;
 #pragma unroll
-                for (int q = 0; q < K::NG; ++q)
+                for (int q = 0; q < NGL; ++q)
                     lds[(nl * ITERMVS_GROUPS + (FT == ITERMVS_F32 ? K::group(j, q) : group16<CPG>(j, q))) * LS + px] = corr[q];
             }
         }

@@ -456,6 +456,12 @@ __device__ __forceinline__ void chunk_corr16(const float* __restrict__ fbase, in
     }
 }
 
+// (A PAIR form -- two lanes per (pixel, hypothesis), each owning a contiguous half of the channels: no exchange, no
+// regrouping, half the per-lane broadcast / address overhead, the same number of load instructions -- was measured and
+// removed: a quad of lanes then reads two separate 16-byte pieces per load, which the texture-address path serves at
+// half the rate.  fp16: 22.1 / 20.6 us vs 19.8 / 18.8 us (noise / smooth depth map); fp32: 35.7 / 33.7 vs 24.2 / 21.7 us;
+// profiles/r04/r04c_corr_lane_forms_ab.txt.  The lanes of a quad must cover ONE contiguous run.)
+
 // XCD-aware tile order: block k is observed to run on XCD k % 8 (a speed assumption only), so give
 // each XCD a contiguous band of pixel tiles; neighbouring tiles then share one L2 instead of having
 // every L2 fetch its own copy of the same source lines.  grid.x is a multiple of 8.

@@ -29,6 +29,12 @@ if [ "${TUNING_LIB:-0}" = "1" ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $T/tuning/*.o -o $V/libitermvs_tuning.so
 fi
 
+# corr: corr.hip with other -D switches, e.g. CORR_VARIANTS="pair:-DITERMVS_FT16_PAIR=1 pair_lb2:-DITERMVS_FT16_PAIR=1,-DITERMVS_CORR_WAVES=4"
+for spec in ${CORR_VARIANTS:-}; do
+  name=${spec%%:*}; defs=$(echo "${spec#*:}" | tr ',' ' ')
+  /opt/rocm/bin/hipcc $FLAGS $defs -I$C -c $C/corr.hip -o $T/corr_$name.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_$name.o -o $V/libitermvs_corr_$name.so
+done
 # bwd: corr_bwd.hip with other -D switches, e.g. BWD_VARIANTS="qt:-DITERMVS_BWD_QT=1"
 for spec in ${BWD_VARIANTS:-}; do
   name=${spec%%:*}; defs=$(echo "${spec#*:}" | tr ',' ' ')
