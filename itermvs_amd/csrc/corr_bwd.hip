@@ -57,13 +57,64 @@ struct BwdArgs {
     int init;                       // 1: initialisation branch (per-view gout, hypotheses uniform in inverse depth)
     int vch;                        // iteration: views per staged chunk (vch * N <= 32)
     int hyp_chunks;                 // initialisation: chunks of 8 hypotheses per view (grid.y = S * hyp_chunks)
-    int scatter;                    // 0: dL/dref only -- dL/dsrc comes from init_gather_kernel (plane hypotheses)
+    int scatter;                    // 1: dL/dsrc of every step; 2 (initialisation, generated planes): only of the (view, plane)
+                                    // pairs plane_inverse routes here, init_gather_kernel serves the others; 0: dL/dref only
 };
+
+// Inverse of the (view, plane) homography of the initialisation branch (see init_gather_level) and the decision which
+// kernel produces that pair's dL/dsrc.  G_n^-1 (row-major, formed in fp64) goes to o[0..8]; the return value is true when
+// the atomic-free gather can serve the WHOLE source image for this pair: G_n is invertible and the denominator of the
+// inverse mapping keeps one sign, with a margin, over the source image grown by a pixel square (it is affine in the pixel
+// coordinates, so its extremes sit at the four corners) -- i.e. the plane's vanishing line stays clear of the image.
+// Otherwise the pair is ROUTED to the atomic scatter of corr_bwd_kernel (the same decision is taken there, by the same
+// arithmetic): a degenerate camera costs the scatter's time for its planes, not a scan of the reference grid per source
+// pixel (O(P1 * N * P) projections: seconds at 1/8 of 1920x1280).
+__device__ __forceinline__ bool plane_inverse(const float* __restrict__ m, float d_f, const WarpGeom& g, int W1, int H1,
+                                              float* __restrict__ o) {
+    const double d = (double)d_f;
+    const double kx = (double)g.w1m1 * 0.5 / (double)g.half_w, ky = (double)g.h1m1 * 0.5 / (double)g.half_h;
+    double G[9];
+    for (int r = 0; r < 3; ++r) {
+        const double k = r == 0 ? kx : (r == 1 ? ky : 1.0);
+        G[3 * r + 0] = k * d * (double)m[4 * r + 0] * (double)g.xr;
+        G[3 * r + 1] = k * d * (double)m[4 * r + 1] * (double)g.yr;
+        G[3 * r + 2] = k * (d * (double)m[4 * r + 2] + (double)m[4 * r + 3]);
+    }
+    const double c0 = G[4] * G[8] - G[5] * G[7], c1 = G[5] * G[6] - G[3] * G[8], c2 = G[3] * G[7] - G[4] * G[6];
+    const double det = G[0] * c0 + G[1] * c1 + G[2] * c2;
+    double nrm = 0.0;
+    for (int i = 0; i < 9; ++i) nrm += G[i] * G[i];
+    const bool usable = det == det && fabs(det) > 1e-13 * nrm * sqrt(nrm);
+    const double id = usable ? 1.0 / det : 0.0;
+    float inv[9];
+    inv[0] = (float)(c0 * id); inv[1] = (float)((G[2] * G[7] - G[1] * G[8]) * id); inv[2] = (float)((G[1] * G[5] - G[2] * G[4]) * id);
+    inv[3] = (float)(c1 * id); inv[4] = (float)((G[0] * G[8] - G[2] * G[6]) * id); inv[5] = (float)((G[2] * G[3] - G[0] * G[5]) * id);
+    inv[6] = (float)(c2 * id); inv[7] = (float)((G[1] * G[6] - G[0] * G[7]) * id); inv[8] = (float)((G[0] * G[4] - G[1] * G[3]) * id);
+    bool whole = usable;
+    float w2_first = 0.0f;
+    for (int c = 0; c < 4; ++c) {
+        const float cx = (c & 1) ? (float)(W1 - 1) + 1.02f : -1.02f, cy = (c & 2) ? (float)(H1 - 1) + 1.02f : -1.02f;
+        const float w0 = fmaf(inv[0], cx, fmaf(inv[1], cy, inv[2]));
+        const float w1 = fmaf(inv[3], cx, fmaf(inv[4], cy, inv[5]));
+        const float w2 = fmaf(inv[6], cx, fmaf(inv[7], cy, inv[8]));
+        if (c == 0) w2_first = w2;
+        // ten times the margin the per-pixel test of the gather asks for: a pair that passes here passes there everywhere
+        whole = whole && (w2 * w2_first > 0.0f) && fabsf(w2) > 1e-5f * (fabsf(w0) + fabsf(w1) + fabsf(w2));
+    }
+    if (o)
+        for (int i = 0; i < 9; ++i) o[i] = inv[i];
+    return whole;
+}
+// depth of plane n of the initialisation branch (itermvs.py:13-17, the forward kernel's expression)
+__device__ __forceinline__ float plane_depth(int n, int N, float inv_min, float inv_max) {
+    const float frac = (float)n / (float)(N - 1);
+    return 1.0f / (inv_max + frac * (inv_min - inv_max));
+}
 
 constexpr int kBwdTile = 16;                                           // pixels per block = rows of 16 lanes
 constexpr int kBwdLS = kBwdTile + 1;
 constexpr int kBwdRows = 4 * ITERMVS_MAX_HYP * ITERMVS_GROUPS;         // staged E rows: (views) x (hypotheses) x 8 <= 256
-constexpr int kBwdLdsFloats = kBwdRows * kBwdLS + kBwdTile + ITERMVS_MAX_SRC * 12;   // + wsum [px] + the views' 3x4 matrices
+constexpr int kBwdLdsFloats = kBwdRows * kBwdLS + kBwdTile + ITERMVS_MAX_SRC * 12 + 8;   // + wsum [px] + the views' 3x4 matrices + routed[8]
 
 // one (view, hypothesis) of a row's pixel: tap offsets (elements, incl. the lane's channel), weights, the loaded taps
 template <int NB>
@@ -82,6 +133,8 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
     float* __restrict__ m_lds = wsum_lds + TILE;                // [S][12]: read back with LDS broadcasts -- as vector loads
                                                                 // they would put a vmcnt(0) (= wait for every atomic in
                                                                 // flight) in front of each step
+    float* __restrict__ routed_lds = m_lds + ITERMVS_MAX_SRC * 12;   // [8]: planes of this block whose dL/dsrc the gather kernel
+                                                                     // does NOT produce (a.scatter == 2, see plane_inverse)
     const int b = blockIdx.z;
     const int P = a.H * a.W;
     const int tile = xcd_tile((P + TILE - 1) / TILE);
@@ -110,6 +163,12 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
     }
     if (threadIdx.x < a.S * 12) m_lds[threadIdx.x] = L.proj[(size_t)b * a.S * 12 + threadIdx.x];
     __syncthreads();
+    if (a.scatter == 2) {          // initialisation branch, generated planes: which (view, plane) pairs of this block are routed here
+        if ((int)threadIdx.x < nh)
+            routed_lds[threadIdx.x] = plane_inverse(m_lds + s_begin * 12, plane_depth(n0 + (int)threadIdx.x, N, inv_min, inv_max), g,
+                                                    L.W1, L.H1, nullptr) ? 0.0f : 1.0f;
+        __syncthreads();
+    }
 
     const int p = p0 + px;
     const bool ok = p < P;
@@ -207,14 +266,20 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
 #pragma unroll 1
             for (int k = 0; k < steps; ++k) {
                 if (k + 1 < steps) prepare(k + 1, nxt, explicit_depth);   // the next step's loads are in flight before this step's atomics
-                process(k, cur, scatter);
+                if constexpr (decltype(scatter)::value == 2) {            // block-uniform: only the routed planes scatter
+                    if (routed_lds[k] != 0.0f) process(k, cur, std::true_type{});
+                    else process(k, cur, std::false_type{});
+                } else {
+                    process(k, cur, std::integral_constant<bool, decltype(scatter)::value != 0>{});
+                }
                 cur = nxt;
             }
         };
         if (ok) {                                        // rows past the last pixel add nothing
-            if (L.depth) walk(std::true_type{}, std::true_type{});
-            else if (a.scatter) walk(std::false_type{}, std::true_type{});
-            else walk(std::false_type{}, std::false_type{});
+            if (L.depth) walk(std::true_type{}, std::integral_constant<int, 1>{});
+            else if (a.scatter == 1) walk(std::false_type{}, std::integral_constant<int, 1>{});
+            else if (a.scatter == 2) walk(std::false_type{}, std::integral_constant<int, 2>{});
+            else walk(std::false_type{}, std::integral_constant<int, 0>{});
         }
         __syncthreads();
     }
@@ -249,8 +314,11 @@ __global__ void __launch_bounds__(kThreads) corr_bwd_kernel(const BwdArgs a) {
 // cross the line at infinity is convex), lets lane t FORWARD-project candidate t with exactly the arithmetic of the scatter
 // (ray_dir / project_fast / make_taps) and keeps the candidates whose footprint really contains q; the survivors' E * ref
 // * weight are summed over channels (lane t = channel 16 blk + t) and planes in registers and stored once: no atomics,
-// no collisions, a deterministic result.  If the corners' denominators change sign (the plane's vanishing line crosses the
-// square) or G_n is singular, the row scans the whole reference grid for that plane -- slow, exact.
+// no collisions, a deterministic result.  Pairs whose vanishing line comes within a pixel of the source image, or whose G_n
+// is singular, are not served here at all: plane_inverse routes them to the atomic scatter above (round 3 scanned the whole
+// reference grid per source pixel for them -- exact, but O(P1 * N * P) projections for a degenerate camera).  Inside a
+// served pair a square whose own corner test still fails (not observed; the pair test carries a 10x margin) falls back to
+// that scan for the one pixel.
 // The scatter form above (1.07 ms at the cfg-4 shape: 126 M lane-atomics on few, heavily shared addresses) remains for
 // explicit per-pixel hypotheses; for generated ones it only computes dL/dref.
 template <int CPG, int FT>
@@ -269,28 +337,8 @@ __device__ __forceinline__ void init_gather_level(const BwdArgs& a, const BwdLev
     if (threadIdx.x < 12) m[threadIdx.x] = L.proj[((size_t)b * a.S + s) * 12 + threadIdx.x];
     __syncthreads();
     if ((int)threadIdx.x < N) {
-        const int n = threadIdx.x;
-        const float frac = (float)n / (float)(N - 1);
-        const double d = (double)(1.0f / (inv_max + frac * (inv_min - inv_max)));
-        const double kx = (double)g.w1m1 * 0.5 / (double)g.half_w, ky = (double)g.h1m1 * 0.5 / (double)g.half_h;
-        double G[9];
-        for (int r = 0; r < 3; ++r) {
-            const double k = r == 0 ? kx : (r == 1 ? ky : 1.0);
-            G[3 * r + 0] = k * d * (double)m[4 * r + 0] * (double)g.xr;
-            G[3 * r + 1] = k * d * (double)m[4 * r + 1] * (double)g.yr;
-            G[3 * r + 2] = k * (d * (double)m[4 * r + 2] + (double)m[4 * r + 3]);
-        }
-        const double c0 = G[4] * G[8] - G[5] * G[7], c1 = G[5] * G[6] - G[3] * G[8], c2 = G[3] * G[7] - G[4] * G[6];
-        const double det = G[0] * c0 + G[1] * c1 + G[2] * c2;
-        double nrm = 0.0;
-        for (int i = 0; i < 9; ++i) nrm += G[i] * G[i];
-        const bool usable = det == det && fabs(det) > 1e-13 * nrm * sqrt(nrm);
-        const double id = usable ? 1.0 / det : 0.0;
-        float* o = ginv + n * 12;
-        o[0] = (float)(c0 * id); o[1] = (float)((G[2] * G[7] - G[1] * G[8]) * id); o[2] = (float)((G[1] * G[5] - G[2] * G[4]) * id);
-        o[3] = (float)(c1 * id); o[4] = (float)((G[0] * G[8] - G[2] * G[6]) * id); o[5] = (float)((G[2] * G[3] - G[0] * G[5]) * id);
-        o[6] = (float)(c2 * id); o[7] = (float)((G[1] * G[6] - G[0] * G[7]) * id); o[8] = (float)((G[0] * G[4] - G[1] * G[3]) * id);
-        o[9] = usable ? 1.0f : 0.0f;
+        float* o = ginv + threadIdx.x * 12;
+        o[9] = plane_inverse(m, plane_depth((int)threadIdx.x, N, inv_min, inv_max), g, L.W1, L.H1, o) ? 1.0f : 0.0f;
     }
     __syncthreads();
 
@@ -307,10 +355,10 @@ __device__ __forceinline__ void init_gather_level(const BwdArgs& a, const BwdLev
 #pragma unroll 1
     for (int n = 0; n < N; ++n) {
         const float* gi = ginv + n * 12;
-        const float frac = (float)n / (float)(N - 1);       // itermvs.py:13-17, the forward kernel's expression
-        const float d = 1.0f / (inv_max + frac * (inv_min - inv_max));
+        if (gi[9] == 0.0f) continue;                        // routed to the scatter of corr_bwd_kernel (plane_inverse)
+        const float d = plane_depth(n, N, inv_min, inv_max);
         // the square's pre-image on the reference grid
-        bool reg = gi[9] != 0.0f;
+        bool reg = true;
         float minx = 3.0e38f, maxx = -3.0e38f, miny = 3.0e38f, maxy = -3.0e38f, w2_first = 0.0f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -484,11 +532,13 @@ extern "C" int itermvs_corr_init_backward(const itermvs_corr_init_params* p, con
     a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max;
     a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.init = 1;
     a.vch = 1; a.hyp_chunks = (p->N + 7) / 8;
-    a.scatter = p->depth ? 1 : 0;      // generated hypotheses are planes: dL/dsrc by the atomic-free gather
+    // generated hypotheses are planes: dL/dsrc by the atomic-free gather, except the (view, plane) pairs whose vanishing
+    // line comes near the source image or whose homography is singular: those are scattered here (mode 2, plane_inverse)
+    a.scatter = p->depth ? 1 : 2;
     const int P = p->H * p->W;
     ITERMVS_RETURN_IF(p->ref.dtype != p->src.dtype, ITERMVS_ERR_DTYPE);
     const int rc2 = launch_bwd(a, p->src.dtype, dim3((((P + kBwdTile - 1) / kBwdTile + 7) / 8) * 8, p->S * a.hyp_chunks, p->B), (hipStream_t)stream);
-    if (rc2 || a.scatter) return rc2;
+    if (rc2 || a.scatter == 1) return rc2;
     const int P1 = p->src.H * p->src.W;
     return launch_gather(a, p->src.dtype, dim3((((P1 + 15) / 16 + 7) / 8) * 8, p->S, p->B), (hipStream_t)stream);
 }

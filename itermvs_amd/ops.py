@@ -274,6 +274,51 @@ def _need_cl(t: Tensor, name: str) -> Tensor:
     return t
 
 
+class FeatureGradPool:
+    """Shared accumulators for the feature gradients of ONE training forward.
+
+    Every ``Evaluation`` call of a step (one initialisation + ``iteration`` iteration calls, models/itermvs.py:271-298) sends a
+    gradient to the same three pyramid tensors.  As separate autograd outputs that is one zero-filled dense tensor per call
+    and level plus autograd's sums (at train_dtu.sh's batch of 4: 177 MB per call, ~3 ms of element-wise kernels per step).
+    With a pool the backward kernels of all calls scatter into ONE zero-filled fp32 tensor per level; ``feature_grad_sink``
+    hands those to autograd once, after the last call's backward has been enqueued."""
+
+    def __init__(self):
+        self.acc = {}
+
+    def get(self, level: int, like: Tensor) -> Tensor:
+        a = self.acc.get(level)
+        if a is None:
+            a = self.acc[level] = torch.zeros_like(like, dtype=torch.float32)     # dense channels-last like the features
+        return a
+
+
+class _FeatGradSink(torch.autograd.Function):
+    """identity on the three pyramid levels; its backward adds the pool's accumulators to whatever other consumers of the
+    features (reference-view resampling, up-sampling head) sent.  The fused correlation Functions take THESE outputs as their
+    feature inputs, so autograd runs this backward only after every one of theirs."""
+
+    @staticmethod
+    def forward(ctx, pool, f1, f2, f3):
+        ctx.pool = pool
+        ctx.set_materialize_grads(False)
+        return f1.view_as(f1), f2.view_as(f2), f3.view_as(f3)
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        out = []
+        for level, g in zip((1, 2, 3), (g1, g2, g3)):
+            a = ctx.pool.acc.pop(level, None)
+            out.append(g if a is None else (a if g is None else a.add_(g)))
+        return (None,) + tuple(out)
+
+
+def feature_grad_sink(pool: FeatureGradPool, feats: Dict[int, Tensor]) -> Dict[int, Tensor]:
+    """route the feature gradients of every fused correlation call given ``pool=`` through ``pool`` (see FeatureGradPool)"""
+    f1, f2, f3 = _FeatGradSink.apply(pool, feats[1], feats[2], feats[3])
+    return {1: f1, 2: f2, 3: f3}
+
+
 class _CorrIterFn(torch.autograd.Function):
     """itermvs.py:84-120 as one differentiable op: forward = itermvs_corr_iter, backward = itermvs_corr_iter_backward.
     Inputs: ref_q [B,H,W,96], proj, view_w (detached by the caller, itermvs.py:295), inverse depth range, normalised
@@ -284,7 +329,8 @@ class _CorrIterFn(torch.autograd.Function):
     taken at the stored values and handed to the fp32 tensors in fp32 (straight-through rounding, no 16-bit gradient)."""
 
     @staticmethod
-    def forward(ctx, ref_q, proj, view_w, inv_min, inv_max, norm_depth, offsets, b, v, f1, f2, f3, s1, s2, s3):
+    def forward(ctx, ref_q, proj, view_w, inv_min, inv_max, norm_depth, offsets, b, v, f1, f2, f3, s1, s2, s3, pool=None):
+        ctx.pool = pool
         f1, f2, f3 = s1, s2, s3
         src = {l: _views(f, b, v)[1] for l, f in ((1, f1), (2, f2), (3, f3))}
         _, h, w, _ = ref_q.shape
@@ -303,29 +349,32 @@ class _CorrIterFn(torch.autograd.Function):
         src = {l: _views(f, b, v)[1] for l, f in zip((1, 2, 3), feats)}
         p, nd = _corr_iter_params(src, ref_q, proj, view_w, inv_min, inv_max, nd, offsets, None)
         gouts = [g.contiguous() for g in gouts]
-        # dense channels-last like the features, fp32 whatever their storage type (fp32 atomics)
-        gfeat = [torch.zeros_like(f, dtype=torch.float32) for f in feats]
+        # dense channels-last like the features, fp32 whatever their storage type (fp32 atomics); with a pool: the step's
+        # shared accumulators (FeatureGradPool), handed to autograd once by the sink
+        pool = ctx.pool
+        gfeat = [torch.zeros_like(f, dtype=torch.float32) if pool is None else pool.get(l, f) for l, f in zip((1, 2, 3), feats)]
         gref = torch.empty_like(ref_q)
         go = (C.c_void_p * 3)(*[g.data_ptr() for g in gouts])
         lv = [(C.c_void_p * (v - 1))(*[t.data_ptr() for t in _views(gf, b, v)[1]]) for gf in gfeat]
         gs = (C.POINTER(C.c_void_p) * 3)(*[C.cast(a, C.POINTER(C.c_void_p)) for a in lv])
         check(_lib.load().itermvs_corr_iter_backward(C.byref(p), C.byref(go), C.byref(gs), gref.data_ptr(), _stream()),
               "itermvs_corr_iter_backward")
-        return (gref, None, None, None, None, None, None, None, None) + tuple(gfeat) + (None, None, None)
+        return (gref, None, None, None, None, None, None, None, None) + (tuple(gfeat) if pool is None else (None, None, None)) + (None, None, None, None)
 
 
 def corr_iter_train(feats: Dict[int, Tensor], b: int, v: int, ref_q: Tensor, proj: Tensor, view_w: Tensor, inv_min: Tensor,
                     inv_max: Tensor, norm_depth: Tensor, offsets: Dict[int, Sequence[float]],
-                    stored: Optional[Dict[int, Tensor]] = None) -> Tuple[Tensor, ...]:
+                    stored: Optional[Dict[int, Tensor]] = None, pool: Optional[FeatureGradPool] = None) -> Tuple[Tensor, ...]:
     """differentiable itermvs_corr_iter: ``feats[l]`` = dense channels-last fp32 [B*V,C_l,H_l,W_l] (gradient to the source
     views) and ``ref_q`` [B,H,W,96] (gradient) -> three [B,N_l,8,H,W] tensors.  ``stored[l]``: the 16-bit copies the kernels
-    gather from (feature storage bf16 / fp16); default: ``feats`` themselves."""
+    gather from (feature storage bf16 / fp16); default: ``feats`` themselves.  ``pool``: ``feats`` are the outputs of
+    ``feature_grad_sink(pool, ...)`` and their gradient is accumulated there instead of being returned to autograd per call."""
     f = [_need_cl(_dev(feats[l], f"feature level {l}"), f"feature level {l}") for l in (1, 2, 3)]
     st = f if stored is None else [_need_cl(stored[l].detach(), f"stored feature level {l}") for l in (1, 2, 3)]
     if any(a.shape != c.shape for a, c in zip(f, st)):
         raise RuntimeError("corr_iter_train: stored features must have the shapes of the fp32 features")
     return _CorrIterFn.apply(_dev(ref_q, "ref_q").contiguous(), _dev(proj, "proj").contiguous(), _dev(view_w, "view_w").contiguous(),
-                             inv_min, inv_max, norm_depth.detach(), {l: tuple(offsets[l]) for l in (1, 2, 3)}, b, v, *f, *st)
+                             inv_min, inv_max, norm_depth.detach(), {l: tuple(offsets[l]) for l in (1, 2, 3)}, b, v, *f, *st, pool)
 
 
 def _corr_init_params(src3, ref3, proj, inv_min, inv_max, n, out):
@@ -346,7 +395,8 @@ class _CorrInitFn(torch.autograd.Function):
     per-view group correlation [B,S,N,8,H,W]; gradient = one dense tensor (reference view gathered, sources scattered)"""
 
     @staticmethod
-    def forward(ctx, f3, proj, inv_min, inv_max, n, b, v, s3):
+    def forward(ctx, f3, proj, inv_min, inv_max, n, b, v, s3, pool=None):
+        ctx.pool = pool
         f3 = s3                 # the tensor the kernel reads (f3 itself, or its 16-bit rounding); gradient goes to f3 in fp32
         ref3, src3 = _views(f3, b, v)
         out = torch.empty((b, v - 1, n, 8) + tuple(f3.shape[2:]), device=f3.device, dtype=torch.float32)
@@ -363,21 +413,21 @@ class _CorrInitFn(torch.autograd.Function):
         ref3, src3 = _views(f3, b, v)
         p = _corr_init_params(src3, ref3, proj, inv_min, inv_max, n, None)
         gout = gout.contiguous()
-        gf = torch.zeros_like(f3, dtype=torch.float32)
+        gf = torch.zeros_like(f3, dtype=torch.float32) if ctx.pool is None else ctx.pool.get(3, f3)
         gref, gsrc = _views(gf, b, v)
         ptrs = (C.c_void_p * (v - 1))(*[t.data_ptr() for t in gsrc])
         check(_lib.load().itermvs_corr_init_backward(C.byref(p), gout.data_ptr(), ptrs, gref.data_ptr(), _stream()),
               "itermvs_corr_init_backward")
-        return gf, None, None, None, None, None, None, None
+        return (gf if ctx.pool is None else None), None, None, None, None, None, None, None, None
 
 
 def corr_init_train(f3: Tensor, b: int, v: int, proj: Tensor, inv_min: Tensor, inv_max: Tensor, num_samples: int = 32,
-                    stored: Optional[Tensor] = None) -> Tensor:
+                    stored: Optional[Tensor] = None, pool: Optional[FeatureGradPool] = None) -> Tensor:
     """differentiable itermvs_corr_init on the dense channels-last fp32 level-3 features [B*V,48,H,W]: -> [B,S,N,8,H,W];
     ``stored``: the bf16 / fp16 copy the kernel reads (16-bit feature storage), default ``f3`` itself"""
     f3 = _need_cl(_dev(f3, "feature level 3"), "feature level 3")
     s3 = f3 if stored is None else _need_cl(stored.detach(), "stored feature level 3")
-    return _CorrInitFn.apply(f3, _dev(proj, "proj").contiguous(), inv_min, inv_max, num_samples, b, v, s3)
+    return _CorrInitFn.apply(f3, _dev(proj, "proj").contiguous(), inv_min, inv_max, num_samples, b, v, s3, pool)
 
 
 class _BnReluTrainFn(torch.autograd.Function):

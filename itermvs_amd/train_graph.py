@@ -166,6 +166,10 @@ def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor
     if store_dt != torch.float32:
         stored = {l: cl[l].detach().to(store_dt) for l in cl}                          # what the kernels read
         cl = {l: cl[l] + (stored[l].float() - cl[l]).detach() for l in cl}             # same values for the torch side
+    # every Evaluation call below sends a gradient to these three tensors: ONE shared zero-filled accumulator per level
+    # (ops.FeatureGradPool) instead of one dense tensor per call summed by autograd
+    pool = ops.FeatureGradPool()
+    cl = ops.feature_grad_sink(pool, cl)
     ref = {l: cl[l].view(b, v, *cl[l].shape[1:])[:, 0] for l in (1, 2, 3)}
     nan_flag = torch.zeros((1,), device=imgs.device, dtype=torch.int32)
     with torch.no_grad():
@@ -183,7 +187,7 @@ def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor
     # ---- initialisation: itermvs.py:36-82 ------------------------------------------------------
     k = torch.arange(INIT_SAMPLES, device=imgs.device, dtype=torch.float32).view(1, -1, 1, 1)
     corr_views = ops.corr_init_train(cl[3], b, v, proj[2], inv_min_b, inv_max_b, INIT_SAMPLES,
-                                     stored=None if stored is None else stored[3])                 # [B,S,N,8,h3,w3]
+                                     stored=None if stored is None else stored[3], pool=pool)      # [B,S,N,8,h3,w3]
     acc, wsum, vws = 0, 1e-5, []
     for i in range(s):
         corr = corr_views[:, i]                                                                 # [B,N,8,h3,w3]
@@ -214,7 +218,7 @@ def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor
     # ---- iterations: itermvs.py:288-314 ----------------------------------------------------------
     for it in range(iteration):
         # hypotheses clamp(nd + offsets) -> depth (itermvs.py:290-293) are built inside the kernel, as at inference
-        aggs = ops.corr_iter_train(cl, b, v, ref_q, proj, view_w_const, inv_min_b, inv_max_b, nd, offsets, stored=stored)
+        aggs = ops.corr_iter_train(cl, b, v, ref_q, proj, view_w_const, inv_min_b, inv_max_b, nd, offsets, stored=stored, pool=pool)
         scores = [net.corr_net(aggs[i], l) for i, l in enumerate((1, 2, 3))]
         hidden = net.gru(hidden, torch.cat([nd] + scores, 1))
         conf0 = net.conf_logit(hidden)

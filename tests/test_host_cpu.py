@@ -244,3 +244,51 @@ def test_timed_regions_and_median():
     assert len(regions) == 5 and all(r >= 0 for r in regions)
     assert calls == list(range(3 + 4 * 5))                       # a running step index: warm-up, then 5 regions of 4
     assert shard.median([3.0, 1.0, 2.0]) == 2.0 and shard.median([4.0, 1.0, 2.0, 3.0]) == 2.5
+
+
+def test_feature_grad_pool_matches_per_call_gradients():
+    """ops.FeatureGradPool / feature_grad_sink (training: one shared accumulator per pyramid level for all Evaluation calls
+    of a step): with stand-in Functions on the CPU the pooled form must give the gradients of the per-call form, the sink's
+    backward must run after every pooled call's, and other consumers' gradients must be added"""
+    from itermvs_amd.ops import FeatureGradPool, feature_grad_sink
+    order = []
+
+    class Call(torch.autograd.Function):              # stand-in for _CorrIterFn: y = k * sum(f_l); pooled backward scatters
+        @staticmethod
+        def forward(ctx, k, f1, f2, f3, pool):
+            ctx.k, ctx.pool = k, pool
+            ctx.save_for_backward(f1, f2, f3)
+            return k * (f1.sum() + 2 * f2.sum() + 3 * f3.sum())
+
+        @staticmethod
+        def backward(ctx, g):
+            order.append(("call", ctx.k))
+            grads = []
+            for l, f in zip((1, 2, 3), ctx.saved_tensors):
+                contrib = torch.full_like(f, float(g) * ctx.k * l)
+                if ctx.pool is None:
+                    grads.append(contrib)
+                else:
+                    ctx.pool.get(l, f).add_(contrib)
+                    grads.append(None)
+            return (None,) + tuple(grads) + (None,)
+
+    def run(pooled):
+        torch.manual_seed(0)
+        leaves = {l: torch.randn(2, 3, 4, 5).requires_grad_(True) for l in (1, 2, 3)}
+        feats = {l: leaves[l] * 1.5 for l in leaves}
+        pool = FeatureGradPool() if pooled else None
+        if pooled:
+            feats = feature_grad_sink(pool, feats)
+        loss = sum(Call.apply(float(k), feats[1], feats[2], feats[3], pool) for k in (1, 2, 3))
+        loss = loss + (feats[2] ** 2).sum()                        # another consumer of a level (like the up-sampling head)
+        loss.backward()
+        assert pool is None or not pool.acc                         # handed over and released
+        return {l: leaves[l].grad.clone() for l in leaves}
+
+    plain = run(False)
+    order.clear()
+    pooled = run(True)
+    assert len(order) == 3
+    for l in (1, 2, 3):
+        assert torch.allclose(plain[l], pooled[l], rtol=1e-6, atol=1e-6), l

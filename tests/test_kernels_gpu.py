@@ -382,6 +382,40 @@ def test_corr_init_backward_matches_autograd(b, v, cams):
     assert maxdiff(fg.grad, f3.grad) <= 1e-4 * max(1.0, float(f3.grad.abs().max()))
 
 
+def test_corr_init_backward_degenerate_camera_at_full_size_is_bounded():
+    """a singular camera in the batch at the largest configuration's level-3 size (1/8 of 1920x1280 = 160x240): round 3's
+    gather scanned the whole reference grid per source pixel for such a view (O(P1 * N * P) = 4.7e10 projections, seconds);
+    the (view, plane) pairs are now routed to the atomic scatter: the gradient still equals autograd through the oracle
+    and the launch pair takes milliseconds"""
+    import time
+    b, v, h3, w3 = 1, 3, 160, 240
+    gen = torch.Generator().manual_seed(3)
+    from itermvs_amd import synthetic
+    sm = synthetic.make_sample(b, v, 8 * h3, 8 * w3, seed=1)
+    pr = sm["proj_matrices"]["level_3"]
+    p12 = torch.stack([proj12_cpu(pr[:, s], pr[:, 0]) for s in range(1, v)], 1)            # [B,S,12]
+    p12[:, 0, 0:4] = p12[:, 0, 8:12]                                                        # first view: three identical rows
+    p12[:, 0, 4:8] = p12[:, 0, 8:12]
+    inv_min, inv_max = torch.full((b,), 1 / 425.0), torch.full((b,), 1 / 935.0)
+    f3 = torch.randn((b * v, 48, h3, w3), generator=gen).requires_grad_(True)
+    depth = O.initial_depth_samples(inv_min.view(b, 1, 1, 1), inv_max.view(b, 1, 1, 1), h3, w3)
+    gw = torch.randn((b, v - 1, 32, 8, h3, w3), generator=gen)
+    ref = f3.view(b, v, *f3.shape[1:])[:, 0]
+    corrs = _oracle_corr(f3, ref, p12, depth, b, v, (h3, w3))
+    sum((c.permute(0, 2, 1, 3, 4) * gw[:, s]).sum() for s, c in enumerate(corrs)).backward()
+    fg = cu(f3.detach()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = ops().corr_init_train(fg, b, v, cu(p12), cu(inv_min), cu(inv_max), 32)
+    gwd = cu(gw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    (out * gwd).sum().backward()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    assert maxdiff(fg.grad, f3.grad) <= 1e-4 * max(1.0, float(f3.grad.abs().max()))
+    assert ms < 200.0, ms            # (incl. the element-wise part of the toy loss; the scan form took seconds)
+    print(f"degenerate camera, 160x240 level-3 map: backward {ms:.1f} ms")
+
+
 @pytest.mark.parametrize("tag", ["seed0", "dtu"])
 def test_prob_regress_bit_exact_indices(tag):
     g = golden(f"e2e_small_{tag}.npz")

@@ -10,7 +10,7 @@ print(f"value {d['value']:.1f} {d['unit']}  ms/step {d['ms_per_step']:.4f} (min 
 if r:
     ci = r.get("corr_init") or {}
     print(f"corr_iter {r['avg_launch_ms'] * 1e3:.1f} us frac {r['frac']:.3f} traffic {r.get('traffic')}  corr_init {ci.get('avg_launch_ms', 0) * 1e3:.1f} us frac {ci.get('frac', 0):.3f}")
-for k in ("pipelined", "with_transfers", "roofline_conv", "cpu_baseline"):
+for k in ("staged_inputs", "pipelined", "with_transfers", "roofline_conv", "cpu_baseline"):
     v = d.get(k)
     if v:
         extra = ""
