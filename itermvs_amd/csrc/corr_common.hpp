@@ -18,7 +18,7 @@ struct Chunk {
     //   C=16: channels 4j..4j+3           = correlation groups 2j, 2j+1 (2 channels each)
     //   C=32: channels 4j.. and 16+4j..   = groups j and 4+j (4 channels each)
     //   C=48: the lane's 12 channels straddle the 6-channel groups; partial sums are re-grouped with four quad-local
-    //         DPP moves (see blend_corr) and lane j finalises groups 2j, 2j+1
+    //         DPP moves (see chunk_corr) and lane j finalises groups 2j, 2j+1
     static constexpr int VEC = 2 * CPG;   // floats per lane: 4 / 8 / 12
     static constexpr int LPT = 4;         // lanes per (pixel, hypothesis)
     static constexpr int NG = 2;          // correlation groups finalised per lane
@@ -136,30 +136,6 @@ __device__ __forceinline__ Footprint make_footprint(float ix, float iy, int W1, 
     return f;
 }
 
-__device__ __forceinline__ Footprint shfl_footprint(const Footprint& f, int src_lane) {
-    Footprint o;
-    o.r0 = (uint32_t)__shfl((int)f.r0, src_lane, 64); o.r1 = (uint32_t)__shfl((int)f.r1, src_lane, 64);
-    o.c0 = (uint32_t)__shfl((int)f.c0, src_lane, 64); o.c1 = (uint32_t)__shfl((int)f.c1, src_lane, 64);
-    o.nw = __shfl(f.nw, src_lane, 64); o.ne = __shfl(f.ne, src_lane, 64);
-    o.sw = __shfl(f.sw, src_lane, 64); o.se = __shfl(f.se, src_lane, 64);
-    return o;
-}
-
-template <int VEC>
-struct TapData {
-    float v00[VEC], v01[VEC], v10[VEC], v11[VEC];
-};
-
-// `fb` is wave-uniform (SGPR base), tap offsets are 32-bit element offsets (saddr + voffset loads).
-template <int VEC, int FT>
-__device__ __forceinline__ void load_taps(const float* __restrict__ fb, uint32_t joff, const Footprint& tp, TapData<VEC>& t) {
-    const uint32_t r0 = tp.r0 + joff, r1 = tp.r1 + joff;
-    load_feat<VEC, FT>(fb, r0 + tp.c0, t.v00);
-    load_feat<VEC, FT>(fb, r0 + tp.c1, t.v01);
-    load_feat<VEC, FT>(fb, r1 + tp.c0, t.v10);
-    load_feat<VEC, FT>(fb, r1 + tp.c1, t.v11);
-}
-
 // footprint held by quad lane u, in every lane of the quad: 8 DPP moves (u constant after unrolling)
 __device__ __forceinline__ Footprint quad_footprint(const Footprint& f, int u) {
     Footprint o;
@@ -168,55 +144,11 @@ __device__ __forceinline__ Footprint quad_footprint(const Footprint& f, int u) {
     return o;
 }
 
-// group correlation of one lane's chunk for one view: bilinear blend of the four taps, product
-// with the reference chunk, mean over the channels of each group (itermvs.py:50-51).
-template <int CPG>
-__device__ __forceinline__ void blend_corr(const TapData<Chunk<CPG>::VEC>& t, const Footprint& tp,
-                                           const float (&refv)[Chunk<CPG>::VEC], float (&corr)[Chunk<CPG>::NG]) {
-    constexpr int VEC = Chunk<CPG>::VEC;
-    float w[VEC];
-#pragma unroll
-    for (int c = 0; c < VEC; ++c)
-        w[c] = fmaf(tp.se, t.v11[c], fmaf(tp.sw, t.v10[c], fmaf(tp.ne, t.v01[c], tp.nw * t.v00[c])));
-    if constexpr (CPG == 2) {
-        corr[0] = fmaf(w[1], refv[1], w[0] * refv[0]) * 0.5f;
-        corr[1] = fmaf(w[3], refv[3], w[2] * refv[2]) * 0.5f;
-    } else if constexpr (CPG == 4) {   // channels 4j..4j+3 = group j, 16+4j.. = group 4+j
-        corr[0] = fmaf(w[3], refv[3], fmaf(w[2], refv[2], fmaf(w[1], refv[1], w[0] * refv[0]))) * 0.25f;
-        corr[1] = fmaf(w[7], refv[7], fmaf(w[6], refv[6], fmaf(w[5], refv[5], w[4] * refv[4]))) * 0.25f;
-    } else {
-        // lane j (= lane & 3) holds channels 16i + 4j + k (i = 0..2, k = 0..3); group g = channels
-        // 6g .. 6g+5.  lo_i / hi_i = products of the lower / upper channel pair of block i:
-        //   g0 = s0[j0] + lo0[j1]   g1 = hi0[j1] + s0[j2]      (s_i = lo_i + hi_i)
-        //   g2 = s0[j3] + lo1[j0]   g3 = hi1[j0] + s1[j1]
-        //   g4 = s1[j2] + lo1[j3]   g5 = hi1[j3] + s2[j0]
-        //   g6 = s2[j1] + lo2[j2]   g7 = hi2[j2] + s2[j3]
-        // lane d finalises groups 2d and 2d+1; each source lane selects what it owes and one
-        // quad_perm per term delivers it.
-        float lo[3], hi[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            lo[i] = fmaf(w[4 * i + 1], refv[4 * i + 1], w[4 * i] * refv[4 * i]);
-            hi[i] = fmaf(w[4 * i + 3], refv[4 * i + 3], w[4 * i + 2] * refv[4 * i + 2]);
-        }
-        const float s0 = lo[0] + hi[0], s1 = lo[1] + hi[1], s2 = lo[2] + hi[2];
-        const int j = threadIdx.x & 3;
-        const float ta = (j == 0 || j == 3) ? s0 : (j == 2 ? s1 : s2);
-        const float tb = (j == 1) ? lo[0] : (j == 2 ? lo[2] : lo[1]);
-        const float tc = (j == 1) ? hi[0] : (j == 2 ? hi[2] : hi[1]);
-        const float tdd = (j == 2) ? s0 : (j == 1 ? s1 : s2);
-        const float g_first = quad_perm<ITERMVS_QP(0, 3, 2, 1)>(ta) + quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tb);
-        const float g_second = quad_perm<ITERMVS_QP(1, 0, 3, 2)>(tc) + quad_perm<ITERMVS_QP(2, 1, 0, 3)>(tdd);
-        // mean over the 6 channels of the group (itermvs.py:103-104): three instructions instead of the ~10 of an IEEE division
-        corr[0] = div_rcp(g_first, 6.0f, 1.0f / 6.0f);
-        corr[1] = div_rcp(g_second, 6.0f, 1.0f / 6.0f);
-    }
-}
-
-// One view's contribution for one lane: the chunk is walked one 16-channel block at a time (4 tap loads of one float4 each,
-// blend, products with the reference block) so that only 16 tap registers are live at once -- with all 12 loads of a C=48
-// chunk in flight the kernel needed 114 VGPRs (4 waves per SIMD); block by block it fits 64 (8 waves), and the memory-level
-// parallelism comes from the doubled occupancy instead.  Arithmetic and summation order are those of blend_corr.
+// One view's contribution for one lane: group correlation of the lane's chunk -- bilinear blend of the four taps, product
+// with the reference chunk, mean over the channels of each group (itermvs.py:50-51).  The chunk is walked one 16-channel block
+// at a time (4 tap loads of one float4 each, blend, products with the reference block) so that only 16 tap registers are live
+// at once (the fp32 iteration kernel allocates 116 VGPRs = 4 waves per SIMD; forcing more waves spills and is slower, fewer
+// registers in flight per wave is what the block-wise walk buys -- profiles/r03).
 // `fb`: wave-uniform base of the view's map; the footprint's row / column offsets and `joff` are in BYTES (make_footprint
 // was given byte strides), so a tap address is a 32-bit add and the 16-channel blocks ride in the instruction's immediate.
 template <int CPG, int FT>
