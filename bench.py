@@ -219,6 +219,10 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=1, help="reference views per step and GPU")
     ap.add_argument("--feature-dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
                     help="storage type of the feature pyramids (BASELINE cfg 4 bf16 / cfg 5 fp16); arithmetic stays fp32")
+    ap.add_argument("--projection", default="device_fp64", choices=["device_fp64", "host_fp32"],
+                    help="host_fp32: the cameras stay on the host and src @ inverse(ref) is composed there in fp32 like module.py:77-90 "
+                         "(the reference's tap indices on this host), per step, inside the timed region; the graphs read the composed "
+                         "matrices from a static buffer refreshed through pinned memory")
     ap.add_argument("--repeats", type=int, default=9,
                     help="the --steps long timed region (barrier + device synchronise on both sides) is run this many times back "
                          "to back; `value` / `ms_per_step` are the MEDIAN region, min / max are reported beside them")
@@ -234,6 +238,9 @@ def main() -> None:
     args = ap.parse_args()
     if args.minimal:
         args.no_cpu_baseline = args.no_transfers = True
+        args.pipeline_streams = 0
+    if args.projection == "host_fp32":          # an A/B of the headline region only: the side legs keep the default composition
+        args.no_transfers = True
         args.pipeline_streams = 0
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -262,9 +269,11 @@ def main() -> None:
         m.load_state_dict(synthetic.random_state_dict(0))
         m.use_graphs = not args.eager
         m.feature_dtype = args.feature_dtype
+        m.projection = args.projection
         models.append(m.to(dev).eval())
         streams.append(torch.cuda.Stream(device=dev) if args.streams > 1 else torch.cuda.current_stream(dev))
     model = models[0]
+    cam_dev = "cpu" if args.projection == "host_fp32" else dev
 
     # this rank's shard of the synthetic reference views, resident in HBM before timing starts
     n_resident = 4
@@ -273,7 +282,7 @@ def main() -> None:
         s = synthetic.make_sample(batch=args.batch, num_views=args.views, height=args.height, width=args.width,
                                   seed=rank * n_resident + i)
         samples.append(({k: v.to(dev) for k, v in s["imgs"].items()},
-                        {k: v.to(dev) for k, v in s["proj_matrices"].items()},
+                        {k: v.to(cam_dev) for k, v in s["proj_matrices"].items()},
                         s["depth_min"].to(dev), s["depth_max"].to(dev)))
 
     sink = []
@@ -317,14 +326,15 @@ def main() -> None:
                 from itermvs_amd.engine import InferenceEngine
                 # runner 0 brackets the corr_iter launch of GRU iteration 0, runner 1 that of iteration 2 and the corr_init launch,
                 # runners 2 and 3 carry no timing nodes at all (a bracket costs ~5 us of graph time)
-                models[k]._engine = InferenceEngine(models[k].weights(), models[k].iteration, args.feature_dtype)
+                models[k]._engine = InferenceEngine(models[k].weights(), models[k].iteration, args.feature_dtype, args.projection)
                 models[k]._engine_version = models[k]._weights_version()      # (the engine belongs to the current weights)
                 models[k]._engine.profile_iterations = {0} if k == 0 else ({min(2, args.iters - 1)} if k == 1 else set())
                 models[k]._engine.profile_init = (k == 1)
             models[k](*samples[k % n_resident])
             if ab == 4:
                 r = next(iter(models[k]._runners.values()))
-                resident[k] = ({"level_0": r.imgs}, {f"level_{l}": r.projs[l] for l in (1, 2, 3)}, r.depth_min, r.depth_max)
+                cams = samples[k % n_resident][1] if args.projection == "host_fp32" else {f"level_{l}": r.projs[l] for l in (1, 2, 3)}
+                resident[k] = ({"level_0": r.imgs}, cams, r.depth_min, r.depth_max)
     torch.cuda.synchronize()
     ops.profile_collect(max_samples=4096)              # drop the set-up launches' samples
 
@@ -486,6 +496,7 @@ def main() -> None:
                        "batch_per_gpu": args.batch, "streams_per_gpu": args.streams, "feature_dtype": args.feature_dtype,
                        "launch": "eager" if args.eager else "one hipGraph per depth map",
                        "parallelism": f"ref-view sharding x{world}, no collective",
+                       "projection": args.projection,
                        "process_group": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                        "algorithmic_MB_per_depth_map": b_map / 1e6},
             "roofline": roofline,

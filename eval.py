@@ -51,6 +51,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--outdir", default="./outputs")
     p.add_argument("--display", action="store_true")
     p.add_argument("--iteration", type=int, default=4)
+    p.add_argument("--projection", default="device_fp64", choices=["device_fp64", "host_fp32"],
+                   help="how src_proj @ inverse(ref_proj) (module.py:77-90) is composed: on the GPU in fp64 rounded once (default), or "
+                        "on the host in fp32 operation for operation like the reference (tap indices of a reference run on this "
+                        "host); the cameras then stay on the host, no synchronisation")
     p.add_argument("--feature_dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
                    help="storage type of the feature pyramids (BASELINE cfg 5: fp16); arithmetic stays fp32")
     p.add_argument("--geo_pixel_thres", type=float, default=1)
@@ -119,6 +123,7 @@ def tocuda(x, dev):
 def load_model(args, dev) -> Pipeline:
     model = Pipeline(iteration=args.iteration, test=True)
     model.feature_dtype = getattr(args, "feature_dtype", "fp32")
+    model.projection = getattr(args, "projection", "device_fp64")
     if args.loadckpt:
         print("loading model {}".format(args.loadckpt))
         state = torch.load(args.loadckpt, map_location="cpu", weights_only=False)
@@ -143,6 +148,8 @@ def save_depth(args) -> int:
             t0 = time.time()
             sample = collate([dataset[j] for j in mine[i:i + args.batch_size]])
             cu = tocuda(sample, dev)
+            if model.projection == "host_fp32":
+                cu["proj_matrices"] = sample["proj_matrices"]      # composed on the host: the cameras never need the device
             out = model(cu["imgs"], cu["proj_matrices"], cu["depth_min"], cu["depth_max"])
             depth = out["depths_upsampled"].cpu().numpy()      # D2H + sync, like tensor2numpy (eval.py:135)
             conf = out["confidence_upsampled"].cpu().numpy()
@@ -184,6 +191,8 @@ def save_depth_folder(args, dataset, mine, model, dev) -> int:
         prev = None
         for n, (sample, (imgs, projs, dmin, dmax)) in enumerate(Prefetcher(dataset, mine, dev)):
             t0 = time.time()
+            if model.projection == "host_fp32":
+                projs = {key: v.unsqueeze(0) for key, v in sample["proj_matrices"].items()}      # CPU cameras
             out = model(imgs, projs, dmin, dmax)
             k = n % 2
             d, c = out["depths_upsampled"], out["confidence_upsampled"]

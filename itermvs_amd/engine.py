@@ -65,8 +65,11 @@ class InferenceEngine:
         GPU in fp64, rounded once, inside the launch that packs the reference features -- no host round trip, within 5e-5
         px of any fp32 evaluation.  "host_fp32": on the host with torch in fp32, operation for operation like the reference
         (``torch.inverse`` per batch item, then ``torch.matmul``) -- for users who need tap indices identical to a
-        reference run on the same host; costs a device-to-host copy of the cameras and a synchronisation per forward, and
-        cannot be captured into a hipGraph.  (The reference itself has no single bit pattern here: its fp32 LAPACK inverse
+        reference run on the same host.  With the cameras handed over as CPU tensors (where a data loader has them anyway)
+        the composition costs no synchronisation and the mode IS capturable: the graph reads the composed [3,B,S,12] matrices
+        from a static buffer that each replay refreshes through pinned memory (``run(..., composed=)``,
+        ``GraphedRunner(..., composed=)``).  With device-resident cameras it costs a device-to-host copy and a synchronisation per
+        forward and cannot be captured.  (The reference itself has no single bit pattern here: its fp32 LAPACK inverse
         differs between CPU BLAS builds and from its own CUDA path.)
         ``feature_dtype``: storage type of the three feature pyramids the correlation kernels gather from -- "fp32"
         (default, the reference's numerics), "bf16" or "fp16" (BASELINE cfg 4 / cfg 5: half the gathered bytes, fp32
@@ -313,10 +316,12 @@ class InferenceEngine:
                    aux2=zbuf, out=hx[:, :HIDDEN], out2=ws["hidden"])
 
     # -- one batch of reference views -----------------------------------------------------------
-    def run(self, imgs: Tensor, projs, depth_min: Tensor, depth_max: Tensor, trace: dict = None) -> Tuple[Tensor, Tensor]:
+    def run(self, imgs: Tensor, projs, depth_min: Tensor, depth_max: Tensor, trace: dict = None,
+            composed: Tensor = None) -> Tuple[Tensor, Tensor]:
         """imgs [B,V,3,H,W]; projs {1,2,3: [B,V,4,4]} like the reference's sample dict, or the same stacked [3,B,V,4,4];
         depth_min/max [B] -> (depth [B,1,H,W], confidence [B,1,H,W]) like itermvs.py:326-327 / net.py:125-128.
-        ``trace`` (dict) collects the intermediate tensors and evaluates the depth head layer by layer (logits kept)."""
+        ``trace`` (dict) collects the intermediate tensors and evaluates the depth head layer by layer (logits kept).
+        ``composed``: the projections already composed ([3,B,S,12] on the device, ``compose_host``); ``projs`` is then unused."""
         b, v, _, hh, ww = imgs.shape
         s = v - 1
         feats = self.feature_net(imgs.reshape(b * v, 3, hh, ww).contiguous())
@@ -331,8 +336,12 @@ class InferenceEngine:
         ref2_nchw = f2p[:1] if b == 1 else f2p.view(b, v, *f2p.shape[1:])[:, 0].contiguous()
         up_logits = self.upsample_logits(ref2_nchw, ws)                 # only needed by the final convex up-sampling
         # camera composition (+ inverse depth range) rides in the launch that packs the reference features
-        pstack = projs if torch.is_tensor(projs) else torch.stack([projs[1], projs[2], projs[3]])
-        if self.projection == "host_fp32":
+        pstack = None if composed is not None else (projs if torch.is_tensor(projs) else torch.stack([projs[1], projs[2], projs[3]]))
+        if composed is not None:
+            proj = composed
+            inv_min, inv_max = 1.0 / depth_min, 1.0 / depth_max                    # itermvs.py:267-268 (IEEE division, as on the host)
+            ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
+        elif self.projection == "host_fp32":
             proj, inv_min, inv_max = self.compose_on_host(pstack.reshape(3, b, v, 4, 4), depth_min, depth_max)
             ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
         else:
@@ -369,19 +378,26 @@ class InferenceEngine:
     def compose_on_host(self, pstack: Tensor, depth_min: Tensor, depth_max: Tensor):
         """module.py:77-90 on the host in fp32, operation for operation (``projection="host_fp32"``): pstack [3,B,V,4,4] ->
         (proj [3,B,S,12], 1/depth_min, 1/depth_max) on the device.  Synchronises (the cameras come back from the GPU)."""
-        pm = pstack.detach().float().cpu()
+        proj = self.compose_host(pstack.detach().float().cpu())
+        if bool(torch.isnan(proj).any()):
+            self.nan_flag.fill_(1)                                                  # surfaces through check_projection_finite
+        dev = pstack.device
+        inv_min, inv_max = 1.0 / depth_min.detach().float().cpu(), 1.0 / depth_max.detach().float().cpu()      # itermvs.py:267-268
+        return proj.to(dev), inv_min.to(dev), inv_max.to(dev)
+
+    @staticmethod
+    def compose_host(pm: Tensor) -> Tensor:
+        """module.py:77-90 on the host in fp32, operation for operation: CPU cameras [3,B,V,4,4] -> CPU [3,B,S,12] rows of
+        ``(src_proj @ inverse(ref_proj))[:3, :4]`` (``torch.inverse`` per batch item like module.py:81,86, then ``torch.matmul``).
+        No device work, no synchronisation."""
+        pm = pm.detach().float()
         levels = []
         for l in range(3):
             ref_p = pm[l, :, 0]                                                     # [B,4,4]
             inv = torch.stack([torch.inverse(ref_p[i]) for i in range(ref_p.shape[0])])
             views = [torch.matmul(pm[l, :, k], inv)[:, :3, :4].reshape(-1, 12) for k in range(1, pm.shape[2])]
             levels.append(torch.stack(views, 1))
-        proj = torch.stack(levels)                                                  # [3,B,S,12]
-        if bool(torch.isnan(proj).any()):
-            self.nan_flag.fill_(1)                                                  # surfaces through check_projection_finite
-        dev = pstack.device
-        inv_min, inv_max = 1.0 / depth_min.detach().float().cpu(), 1.0 / depth_max.detach().float().cpu()      # itermvs.py:267-268
-        return proj.to(dev), inv_min.to(dev), inv_max.to(dev)
+        return torch.stack(levels).contiguous()                                     # [3,B,S,12]
 
     def check_projection_finite(self) -> None:
         """Deferred form of the reference's NaN asserts (module.py:83,87) for every ``run`` / graph replay enqueued since
@@ -410,12 +426,23 @@ class GraphedRunner:
     Outputs are static buffers, overwritten by the next replay on the same runner."""
 
     def __init__(self, engine: InferenceEngine, imgs: Tensor, projs: Dict[int, Tensor], depth_min: Tensor,
-                 depth_max: Tensor, stream: "torch.cuda.Stream" = None):
+                 depth_max: Tensor, stream: "torch.cuda.Stream" = None, composed: Tensor = None):
+        """``composed`` (CPU [3,B,S,12], ``InferenceEngine.compose_host``): capture the form that READS composed projections
+        from a static device buffer instead of composing the cameras on the device (``projs`` is then ignored): the
+        capturable ``projection="host_fp32"``.  Replays refresh the buffer through a small ring of pinned staging buffers."""
         self.engine = engine
         self.stream = stream or torch.cuda.Stream(device=imgs.device)
         self.imgs = imgs.clone()
-        self.proj_stack = torch.stack([projs[1], projs[2], projs[3]]).contiguous()      # static [3,B,V,4,4]
-        self.projs = {l: self.proj_stack[l - 1] for l in (1, 2, 3)}
+        self.composed = None
+        if composed is not None:
+            self.composed = composed.to(imgs.device).contiguous()                       # static [3,B,S,12]
+            self._pin = [torch.empty(tuple(composed.shape), dtype=torch.float32).pin_memory() for _ in range(4)]
+            self._pin_ev = [None] * len(self._pin)
+            self._pin_i = 0
+            self.proj_stack, self.projs = None, {}
+        else:
+            self.proj_stack = torch.stack([projs[1], projs[2], projs[3]]).contiguous()  # static [3,B,V,4,4]
+            self.projs = {l: self.proj_stack[l - 1] for l in (1, 2, 3)}
         self.depth_min, self.depth_max = depth_min.clone(), depth_max.clone()
         self.key = (tuple(imgs.shape), tuple(depth_min.shape))
         self.stream.wait_stream(torch.cuda.current_stream(imgs.device))
@@ -428,12 +455,12 @@ class GraphedRunner:
         try:
             with torch.cuda.stream(self.stream):
                 for _ in range(2):                              # warm-up: allocates the workspaces, primes caches
-                    engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max)
+                    engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max, composed=self.composed)
                 torch.cuda.synchronize(imgs.device)
                 first = ops.profile_graph_count()
                 self.graph = torch.cuda.CUDAGraph()
                 self.graph.capture_begin()
-                self.out = engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max)
+                self.out = engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max, composed=self.composed)
                 self.graph.capture_end()
                 self.profile_pairs = (first, ops.profile_graph_count() - first)
         finally:
@@ -446,9 +473,26 @@ class GraphedRunner:
         may fill them in place and pass them back to ``__call__``, which then skips its staging copies."""
         return self.imgs, self.projs, self.depth_min, self.depth_max
 
-    def __call__(self, imgs: Tensor, projs: Dict[int, Tensor], depth_min: Tensor, depth_max: Tensor):
+    def _stage_composed(self, host: Tensor) -> None:
+        """CPU [3,B,S,12] -> the static device buffer, in stream order, without synchronising the stream: a ring of pinned
+        buffers, each reused only after the copy that last read it has completed (a host wait on a long-finished event)"""
+        i = self._pin_i
+        self._pin_i = (i + 1) % len(self._pin)
+        if self._pin_ev[i] is not None:
+            self._pin_ev[i].synchronize()
+        self._pin[i].copy_(host)
+        self.composed.copy_(self._pin[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pin_ev[i] = ev
+
+    def __call__(self, imgs: Tensor, projs, depth_min: Tensor, depth_max: Tensor):
         """copy the sample into the static inputs (unless it already IS them) and replay ON THE CURRENT
-        STREAM; returns the static (depth, confidence) buffers, valid in stream order like any other torch op"""
+        STREAM; returns the static (depth, confidence) buffers, valid in stream order like any other torch op.
+        A runner captured with ``composed=`` takes the composed projections (CPU [3,B,S,12]) as ``projs``."""
+        if self.composed is not None:
+            self._stage_composed(projs)
+            projs = {}
         dst, src = [], []
         for d, t in [(self.imgs, imgs), (self.depth_min, depth_min), (self.depth_max, depth_max)] + \
                     [(self.projs[l], projs[l]) for l in self.projs]:

@@ -158,9 +158,15 @@ class Pipeline(nn.Module):
         h, w = x.shape[-2:]
         if h % 32 or w % 32:
             raise RuntimeError(f"image height and width must be multiples of 32, got {h}x{w}")
+        # cameras may stay on the host (tiny; a data loader has them there): projection="host_fp32" then composes them without
+        # any synchronisation, also under use_graphs; the default mode simply uploads them
+        cams_on_host = not proj_matrices["level_1"].is_cuda
+        host_composed = self.test and self.projection == "host_fp32" and cams_on_host
         projs = {l: proj_matrices[f"level_{l}"].float() for l in (1, 2, 3)}
-        depth_min = depth_min.float()
-        depth_max = depth_max.float()
+        if cams_on_host and not host_composed:
+            projs = {l: t.to(x.device, non_blocking=True) for l, t in projs.items()}
+        depth_min = depth_min.float().to(x.device)
+        depth_max = depth_max.float().to(x.device)
         if self.test:
             from .engine import InferenceEngine
             if self._engine is not None and self._engine_version != self._weights_version():
@@ -169,15 +175,24 @@ class Pipeline(nn.Module):
                 self._engine = InferenceEngine(self.weights(), self.iteration, self.feature_dtype, self.projection)
                 self._engine_version = self._weights_version()
             with torch.no_grad():
+                composed = None
+                if host_composed:
+                    composed = self._engine.compose_host(torch.stack([projs[1], projs[2], projs[3]]))      # CPU [3,B,S,12]
+                    # module.py:83,87 assert right here; the cameras are on the host, so this check is free
+                    assert not bool(torch.isnan(composed).any()), "nan in proj (singular or non-finite camera matrix, module.py:83,87)"
                 if self.use_graphs:
-                    if self.projection != "device_fp64":
-                        raise RuntimeError("projection='host_fp32' reads the cameras back on the host: not capturable, use eager mode")
+                    if self.projection != "device_fp64" and not host_composed:
+                        raise RuntimeError("projection='host_fp32' with device-resident cameras reads them back on the host: not "
+                                           "capturable -- pass proj_matrices as CPU tensors, or use eager mode")
                     from .engine import GraphedRunner
-                    key = (tuple(x.shape), x.device.index)
+                    key = (tuple(x.shape), x.device.index, host_composed)
                     runner = self._runners.get(key)
                     if runner is None:
-                        runner = self._runners[key] = GraphedRunner(self._engine, x.float(), projs, depth_min, depth_max)
-                    depth_up, conf_up = runner(x.float(), projs, depth_min, depth_max)
+                        runner = self._runners[key] = GraphedRunner(self._engine, x.float(), projs, depth_min, depth_max, composed=composed)
+                    depth_up, conf_up = runner(x.float(), composed if host_composed else projs, depth_min, depth_max)
+                elif host_composed:
+                    depth_up, conf_up = self._engine.run(x.float(), None, depth_min, depth_max,
+                                                         composed=composed.to(x.device, non_blocking=True))
                 else:
                     depth_up, conf_up = self._engine.run(x.float(), projs, depth_min, depth_max)
             if self.check_nan if self.check_nan is not None else not self.use_graphs:

@@ -397,3 +397,48 @@ def test_host_fp32_projection_mode_reproduces_the_reference_composition():
     m_host.use_graphs = True
     with pytest.raises(RuntimeError, match="host_fp32"):
         m_host(imgs, pm, dmin, dmax)
+
+
+def test_host_fp32_projection_is_capturable_with_host_resident_cameras():
+    """``projection="host_fp32"`` with the cameras handed over as CPU tensors (where a data loader has them): composed on the
+    host in fp32 like module.py:77-90 WITHOUT any device synchronisation, and capturable -- the hipGraph reads the composed
+    matrices from a static buffer every replay refreshes through pinned memory.  Eager == graph replay bit for bit, both ==
+    the synchronising device-camera form, and replays follow changing cameras."""
+    from itermvs_amd import synthetic
+    from itermvs_amd.engine import InferenceEngine
+    from oracle import itermvs_oracle as O
+    s = [synthetic.make_sample(batch=1, num_views=4, height=64, width=96, seed=k) for k in (3, 4, 5)]
+    want = []
+    m_ref = make_model("seed0", 2)
+    m_ref.projection = "host_fp32"
+    for smp in s:                                           # the eager, synchronising form with device cameras (round 3)
+        imgs, pm, dmin, dmax = to_dev(smp)
+        want.append(m_ref(imgs, pm, dmin, dmax)["depths_upsampled"].clone())
+    pm0 = torch.stack([s[0]["proj_matrices"][f"level_{l}"].float() for l in (1, 2, 3)])
+    comp = InferenceEngine.compose_host(pm0)
+    for i in range(3):
+        for k in range(1, 4):
+            assert torch.equal(comp[i][:, k - 1], O.compose_projection(pm0[i][:, k], pm0[i][:, 0])[:, :3, :4].reshape(-1, 12))
+    for graphs in (False, True):
+        m = make_model("seed0", 2)
+        m.projection = "host_fp32"
+        m.use_graphs = graphs
+        for rep in range(2):                                # second pass: replays of the captured graph with other cameras
+            for smp, w in zip(s, want):
+                imgs, _, dmin, dmax = to_dev(smp)
+                got = m(imgs, smp["proj_matrices"], dmin, dmax)["depths_upsampled"]         # CPU cameras
+                assert torch.equal(got, w), (graphs, rep)
+        if graphs:
+            assert len(m._runners) == 1
+    bad = {k: v.clone() for k, v in s[0]["proj_matrices"].items()}
+    bad["level_2"][0, 1, 0, 0] = float("nan")               # non-finite source camera: module.py:83,87 assert, raised on the spot
+    imgs, _, dmin, dmax = to_dev(s[0])
+    with pytest.raises(AssertionError, match="nan in proj"):
+        m(imgs, bad, dmin, dmax)
+    bad["level_2"][0, 1, 0, 0] = s[0]["proj_matrices"]["level_2"][0, 1, 0, 0]
+    bad["level_2"][0, 0] = 0.0                              # singular reference camera: torch.inverse raises on the host, as in the
+    with pytest.raises(RuntimeError):                       # reference run on a CPU (module.py:81)
+        m(imgs, bad, dmin, dmax)
+    m_dev = make_model("seed0", 2)                          # default composition: CPU cameras are simply uploaded
+    imgs, pm, dmin, dmax = to_dev(s[1])
+    assert torch.equal(m_dev(imgs, s[1]["proj_matrices"], dmin, dmax)["depths_upsampled"], m_dev(imgs, pm, dmin, dmax)["depths_upsampled"])
