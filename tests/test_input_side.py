@@ -174,7 +174,8 @@ def test_prefetcher_stages_one_sample_ahead(tmp_path):
     t0, stamps = time.perf_counter(), []
     for _ in Prefetcher(Slow(ds), [0, 1, 2], dev, depth=1):
         stamps.append(time.perf_counter() - t0)
-    assert len(stamps) == 3 and stamps[0] < 0.5 and stamps[1] < 0.85, stamps     # 0.3 s per decode, none waited for twice
+    assert len(stamps) == 3 and stamps[0] < 0.55 and stamps[1] < 0.9, stamps     # 0.3 s per decode, none waited for twice
+                                                                               # (the blocking form hands item 0 out at >= 0.6 s)
     # leaving early: close() drains the queue and the worker exits instead of blocking on a full queue
     pf2 = Prefetcher(ds, [0, 1, 2, 3], dev, depth=1)
     for _ in pf2:
