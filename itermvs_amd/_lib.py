@@ -156,6 +156,11 @@ def load() -> C.CDLL:
         raise HipLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C itermvs_amd/csrc`).  The IterMVS engine has no CPU fallback.")
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so); the library links /opt/rocm's.  Both answer to the
+    # same soname, so whichever is loaded FIRST serves the whole process.  Streams and device memory come from torch: its
+    # runtime must be the resident one, or the first launch on a torch stream fails (seen as ITERMVS_ERR_LAUNCH when this
+    # library was dlopen-ed before `import torch`, e.g. build() followed by smoke() in one process).
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the box

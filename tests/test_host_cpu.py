@@ -292,3 +292,18 @@ def test_feature_grad_pool_matches_per_call_gradients():
     assert len(order) == 3
     for l in (1, 2, 3):
         assert torch.allclose(plain[l], pooled[l], rtol=1e-6, atol=1e-6), l
+
+
+def test_library_load_brings_torch_in_first():
+    """_lib.load() in a fresh interpreter: torch (and with it PyTorch-ROCm's bundled HIP runtime) is imported before the
+    dlopen of libitermvs_hip.so -- see tests/test_drivers_gpu.py::test_build_then_smoke_in_one_process for why"""
+    import subprocess
+    import sys
+    code = ("import sys, ctypes; real = ctypes.CDLL\n"
+            "def spy(path, *a, **k):\n"
+            "    if 'libitermvs_hip' in str(path): print('TORCH_FIRST', 'torch' in sys.modules)\n"
+            "    return real(path, *a, **k)\n"
+            "ctypes.CDLL = spy\n"
+            "from itermvs_amd import _lib; _lib.load()")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "TORCH_FIRST True" in p.stdout, (p.stdout, p.stderr[-800:])
