@@ -35,6 +35,12 @@ for spec in ${CORR_VARIANTS:-}; do
   /opt/rocm/bin/hipcc $FLAGS $defs -I$C -c $C/corr.hip -o $T/corr_$name.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $T/corr_$name.o -o $V/libitermvs_corr_$name.so
 done
+# tile: conv_tile.hip with other -D switches, e.g. TILE_VARIANTS="dma:-DITERMVS_TILE_DMA"
+for spec in ${TILE_VARIANTS:-}; do
+  name=${spec%%:*}; defs=$(echo "${spec#*:}" | tr ',' ' ')
+  /opt/rocm/bin/hipcc $FLAGS $defs -I$C -c $C/conv_tile.hip -o $T/conv_tile_$name.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/*.o | grep -v "/conv_tile.o") $T/conv_tile_$name.o -o $V/libitermvs_tile_$name.so
+done
 # bwd: corr_bwd.hip with other -D switches, e.g. BWD_VARIANTS="qt:-DITERMVS_BWD_QT=1"
 for spec in ${BWD_VARIANTS:-}; do
   name=${spec%%:*}; defs=$(echo "${spec#*:}" | tr ',' ' ')
