@@ -57,6 +57,9 @@ def build_parser() -> argparse.ArgumentParser:
                         "host); the cameras then stay on the host, no synchronisation")
     p.add_argument("--feature_dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
                    help="storage type of the feature pyramids (BASELINE cfg 5: fp16); arithmetic stays fp32")
+    p.add_argument("--no_graphs", action="store_true",
+                   help="launch every kernel from Python (~85 launches per depth map) instead of replaying one hipGraph per depth map "
+                        "(captured once per image shape; results are bit-identical)")
     p.add_argument("--geo_pixel_thres", type=float, default=1)
     p.add_argument("--geo_depth_thres", type=float, default=0.01)
     p.add_argument("--photo_thres", type=float, default=0.3)
@@ -124,6 +127,9 @@ def load_model(args, dev) -> Pipeline:
     model = Pipeline(iteration=args.iteration, test=True)
     model.feature_dtype = getattr(args, "feature_dtype", "fp32")
     model.projection = getattr(args, "projection", "device_fp64")
+    # one hipGraph replay per depth map (bit-identical to the eager launches); host_fp32 with device-resident cameras cannot be
+    # captured -- save_depth keeps the cameras on the host for that mode
+    model.use_graphs = not getattr(args, "no_graphs", False)
     if args.loadckpt:
         print("loading model {}".format(args.loadckpt))
         state = torch.load(args.loadckpt, map_location="cpu", weights_only=False)

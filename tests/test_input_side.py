@@ -152,6 +152,7 @@ def test_prefetcher_stages_one_sample_ahead(tmp_path):
     ds = ScanFolderDataset(str(tmp_path / "data"), [scan], 4, (160, 96))
     dev = torch.device(DEV)
     pf = Prefetcher(ds, [0, 1, 2, 3], dev, depth=1)
+    time.sleep(0.5)                              # the decoder gets ahead of the consumer (item 0 queued, item 1 decoded and waiting)
     seen, ahead = [], []
     for sample, (imgs, projs, dmin, dmax) in pf:
         ahead.append(pf.staged_ahead)
