@@ -82,14 +82,19 @@ def test_validation_mode_scalars_and_no_weight_change():
     assert not model.training
 
 
-def test_build_then_smoke_in_one_process():
+def test_library_loaded_before_torch_then_smoke():
     """the driver's two entry points in ONE interpreter: build() dlopen-s the library before anything imported torch.  The
     library links /opt/rocm's HIP runtime, PyTorch bundles its own under the same soname, the first one loaded serves the
     process -- _lib.load() therefore imports torch first (with the library's runtime resident instead, the first launch on a
-    torch stream failed with ITERMVS_ERR_LAUNCH)"""
+    torch stream failed with ITERMVS_ERR_LAUNCH).  Same order as build() + smoke(), without running make inside the suite."""
     import subprocess
     import sys
     from conftest import ROOT
-    p = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=ROOT, capture_output=True,
-                       text=True, timeout=900)
+    code = ("import sys\n"
+            "from itermvs_amd import _lib\n"
+            "assert 'torch' not in sys.modules\n"
+            "_lib.load()\n"
+            "import __graft_entry__ as g\n"
+            "g.smoke()")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "smoke ok" in p.stdout, (p.stdout[-500:], p.stderr[-1500:])

@@ -296,7 +296,7 @@ def test_feature_grad_pool_matches_per_call_gradients():
 
 def test_library_load_brings_torch_in_first():
     """_lib.load() in a fresh interpreter: torch (and with it PyTorch-ROCm's bundled HIP runtime) is imported before the
-    dlopen of libitermvs_hip.so -- see tests/test_drivers_gpu.py::test_build_then_smoke_in_one_process for why"""
+    dlopen of libitermvs_hip.so -- see tests/test_drivers_gpu.py::test_library_loaded_before_torch_then_smoke for why"""
     import subprocess
     import sys
     code = ("import sys, ctypes; real = ctypes.CDLL\n"
