@@ -32,6 +32,21 @@ def test_eval_driver_writes_pfm(tmp_path):
     d1, _ = read_pfm(str(tmp_path / "scan_synthetic" / "depth_est" / "00000001.pfm"))
     rel = np.abs(d1[..., 0] - out["depths_upsampled"][0, 0].cpu().numpy()) / d1[..., 0]
     assert float((rel > 1e-4).mean()) <= 0.02          # batch of 2 vs batch of 1: same maps up to arg-max chaos
+    # --projection host_fp32: the cameras stay on the host, composed there like module.py:77-90, the hipGraph replays read the
+    # composed matrices; the files hold exactly what the model returns in that mode, and the two modes agree to the chaos floor
+    out_h = tmp_path / "host"
+    args_h = E.build_parser().parse_args(["--n_views", "3", "--img_wh", "96", "64", "--iteration", "2", "--num_samples", "3",
+                                          "--outdir", str(out_h), "--projection", "host_fp32"])
+    assert E.save_depth(args_h) == 3
+    model_h = E.load_model(args_h, torch.device("cuda"))
+    assert model_h.use_graphs and model_h.projection == "host_fp32"
+    cpu_s = E.collate([ds[1]])
+    with torch.no_grad():
+        want = model_h(s["imgs"], cpu_s["proj_matrices"], s["depth_min"], s["depth_max"])["depths_upsampled"][0, 0].cpu().numpy()
+    dh, _ = read_pfm(str(out_h / "scan_synthetic" / "depth_est" / "00000001.pfm"))
+    assert np.array_equal(dh[..., 0], want)
+    rel = np.abs(dh[..., 0] - d1[..., 0]) / d1[..., 0]
+    assert float(np.median(rel)) <= 1e-5 and float((rel > 1e-4).mean()) <= 0.05
 
 
 def test_train_driver_steps_and_checkpoint(tmp_path):
