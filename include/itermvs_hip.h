@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define ITERMVS_ABI_VERSION 7
+#define ITERMVS_ABI_VERSION 8
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -188,6 +188,37 @@ typedef struct itermvs_corr_init_params {
 } itermvs_corr_init_params;
 
 int itermvs_corr_init(const itermvs_corr_init_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * itermvs_tap_indices -- diagnostic: the bilinear tap indices the FUSED kernels use (models/module.py:99-115 followed by
+ * grid_sample's un-normalisation and floor, ATen GridSampler.h:31,205-207).  itermvs_corr_iter / itermvs_corr_init and
+ * their gradients never store the sampling position; this entry evaluates it with the same device functions in the same
+ * order (hypothesis construction, ray, projection with the library's division form, floor, bounds) and writes, for every
+ * (b, view s, hypothesis n, pixel p = y*W + x) of the sample grid:
+ *   out[b,s,n,0,p] = floor(ix)   out[b,s,n,1,p] = floor(iy)     as int32 (NaN -> INT32_MIN, saturated at +-2^30)
+ *   out[b,s,n,2,p] = bit 0: column x0 inside the source map, bit 1: x0+1, bit 2: row y0, bit 3: y0+1
+ *   coords[b,s,n,0,p] = ix, coords[b,s,n,1,p] = iy  (optional, may be NULL)
+ * Hypotheses: `depth` [B,N,H,W] when given; else, with init != 0, the N initial planes (models/itermvs.py:13-17); else
+ * norm_depth + offsets[n] clamped and un-normalised (models/itermvs.py:291-293, N <= ITERMVS_MAX_HYP).
+ * tests/test_tap_indices_gpu.py holds it bit for bit to the reference's own sampling grids (tests/golden/tap_cases.npz).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct itermvs_tap_params {
+    int32_t B, S, H, W;                        /* sample grid                              */
+    int32_t N;                                 /* hypotheses                               */
+    int32_t H1, W1;                            /* source map size                          */
+    int32_t init;                              /* != 0: generate the initial planes        */
+    const float* proj;                         /* [B,S,12]                                 */
+    const float* depth;                        /* [B,N,H,W] or NULL                        */
+    const float* norm_depth;                   /* element (b,y,x) at norm_depth[b*norm_depth_sb + y*W + x] */
+    int64_t norm_depth_sb;
+    float offsets[ITERMVS_MAX_HYP];
+    const float* inv_depth_min;                /* device [B] */
+    const float* inv_depth_max;                /* device [B] */
+    int32_t* out;                              /* [B,S,N,3,H,W] */
+    float* coords;                             /* [B,S,N,2,H,W] or NULL */
+} itermvs_tap_params;
+
+int itermvs_tap_indices(const itermvs_tap_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gradients of the two fused correlation entry points for training (train.py:194-243; the training branches of

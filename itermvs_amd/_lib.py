@@ -14,7 +14,7 @@ MAX_SRC = 16
 MAX_HYP = 8
 GROUPS = 8
 F32, F16, BF16 = 0, 1, 2      # itermvs_dtype: storage type of feature maps
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitermvs_hip.so")
@@ -56,6 +56,15 @@ class CorrInitParams(C.Structure):
                 ("inv_depth_min", C.c_void_p), ("inv_depth_max", C.c_void_p), ("out", C.c_void_p)]
 
 
+class TapParams(C.Structure):
+    """itermvs_tap_params"""
+    _fields_ = [("B", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("N", C.c_int32),
+                ("H1", C.c_int32), ("W1", C.c_int32), ("init", C.c_int32),
+                ("proj", C.c_void_p), ("depth", C.c_void_p), ("norm_depth", C.c_void_p), ("norm_depth_sb", C.c_int64),
+                ("offsets", C.c_float * MAX_HYP),
+                ("inv_depth_min", C.c_void_p), ("inv_depth_max", C.c_void_p), ("out", C.c_void_p), ("coords", C.c_void_p)]
+
+
 class ConvParams(C.Structure):
     """itermvs_conv_params"""
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p), ("add", C.c_void_p),
@@ -89,6 +98,7 @@ PROTOTYPES = {
     "itermvs_copy_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p]),
     "itermvs_corr_iter": (C.c_int, [C.POINTER(CorrIterParams), C.c_void_p]),
     "itermvs_corr_init": (C.c_int, [C.POINTER(CorrInitParams), C.c_void_p]),
+    "itermvs_tap_indices": (C.c_int, [C.POINTER(TapParams), C.c_void_p]),
     "itermvs_corr_iter_backward": (C.c_int, [C.POINTER(CorrIterParams), C.POINTER(C.c_void_p * 3),
                                              C.POINTER(C.POINTER(C.c_void_p) * 3), C.c_void_p, C.c_void_p]),
     "itermvs_corr_init_backward": (C.c_int, [C.POINTER(CorrInitParams), C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),

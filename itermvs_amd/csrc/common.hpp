@@ -147,8 +147,14 @@ struct Taps {
     int x0, x1, y0, y1;
     float nw, ne, sw, se;
 };
+// what make_taps decided, for itermvs_tap_indices (the diagnostic entry that exposes the fused kernels' tap indices):
+// floor(ix), floor(iy) as floats and the validity of the two columns / two rows (bit 0: x0, 1: x1, 2: y0, 3: y1)
+struct TapDiag {
+    float fx0, fy0;
+    int bits;
+};
 
-__device__ __forceinline__ Taps make_taps(float ix, float iy, int W1, int H1) {
+__device__ __forceinline__ Taps make_taps(float ix, float iy, int W1, int H1, TapDiag* diag = nullptr) {
     Taps t;
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     const float fx1 = fx0 + 1.0f, fy1 = fy0 + 1.0f;
@@ -167,12 +173,29 @@ __device__ __forceinline__ Taps make_taps(float ix, float iy, int W1, int H1) {
     t.x1 = vx1 ? (int)fx1 : 0;
     t.y0 = vy0 ? (int)fy0 : 0;
     t.y1 = vy1 ? (int)fy1 : 0;
+    if (diag) {
+        diag->fx0 = fx0;
+        diag->fy0 = fy0;
+        diag->bits = (vx0 ? 1 : 0) | (vx1 ? 2 : 0) | (vy0 ? 4 : 0) | (vy1 ? 8 : 0);
+    }
     return t;
 }
 
 // models/module.py:148-152
 __device__ __forceinline__ float unnormalize_depth(float nd, float inv_min, float inv_max) {
     return 1.0f / (inv_max + nd * (inv_min - inv_max));
+}
+
+// hypothesis n of the iteration branch around the normalised depth `nd` (itermvs.py:291-293) and plane n of the N initial
+// hypotheses (itermvs.py:13-17): ONE definition for the fused forward kernels, their gradients and itermvs_tap_indices
+__device__ __forceinline__ float iter_hypothesis(float nd, float off, float inv_min, float inv_max) {
+    float ns = nd + off;
+    ns = fminf(fmaxf(ns, 0.0f), 1.0f);
+    return unnormalize_depth(ns, inv_min, inv_max);
+}
+__device__ __forceinline__ float init_hypothesis(int n, int N, float inv_min, float inv_max) {
+    const float frac = (float)n / (float)(N - 1);
+    return 1.0f / (inv_max + frac * (inv_min - inv_max));
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -73,9 +73,7 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
         if (L.depth) {
             d = L.depth[((size_t)b * N + n) * P + p];
         } else {  // itermvs.py:291-293
-            float ns = a.nd[b * a.nd_sb + p] + L.offs[n];
-            ns = fminf(fmaxf(ns, 0.0f), 1.0f);
-            d = unnormalize_depth(ns, inv_min, inv_max);
+            d = iter_hypothesis(a.nd[b * a.nd_sb + p], L.offs[n], inv_min, inv_max);
         }
         float refv[K::VEC];
         if constexpr (FT == ITERMVS_F32) load_vec<K::VEC>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff + j * 4, refv);
@@ -241,8 +239,7 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
             if (a.depth) {
                 d = a.depth[((size_t)b * a.N + n) * P + p];
             } else {  // itermvs.py:13-17
-                const float frac = (float)n / (float)(a.N - 1);
-                d = 1.0f / (inv_max + frac * (inv_min - inv_max));
+                d = init_hypothesis(n, a.N, inv_min, inv_max);
             }
             float rx, ry, rz, ix, iy;
             ray_dir(m, (float)x * g.xr, (float)y * g.yr, rx, ry, rz);
@@ -425,9 +422,88 @@ __global__ void __launch_bounds__(512) pvw_tail_kernel(const float* __restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// itermvs_tap_indices: the sampling decisions of the fused kernels, observable.  One thread per (b, view, hypothesis,
+// pixel) evaluates the hypothesis, ray, projection and footprint with the SAME inline functions, in the same order, as
+// corr_iter_level / corr_init_body / the gradient kernels (iter_hypothesis / init_hypothesis, ray_dir, project_fast,
+// make_taps) and stores floor(ix), floor(iy) and the validity bits instead of gathering.
+// ---------------------------------------------------------------------------------------------
+struct TapArgs {
+    const float* proj;
+    const float* depth;
+    const float* nd;
+    int64_t nd_sb;
+    float offs[ITERMVS_MAX_HYP];
+    const float* inv_min;
+    const float* inv_max;
+    int32_t* out;
+    float* coords;
+    int B, S, H, W, N, H1, W1, init;
+};
+
+__device__ __forceinline__ int32_t tap_floor_to_int(float f) {
+    if (!(f == f)) return INT32_MIN;                       // NaN
+    if (f >= 1073741824.0f) return 1073741824;             // +-2^30 saturation (inf included)
+    if (f <= -1073741824.0f) return -1073741824;
+    return (int32_t)f;
+}
+
+__global__ void __launch_bounds__(256) tap_indices_kernel(const TapArgs a) {
+    const int P = a.H * a.W;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)a.B * a.S * a.N * P) return;
+    const int p = (int)(t % P);
+    const int n = (int)((t / P) % a.N);
+    const int s = (int)((t / ((int64_t)P * a.N)) % a.S);
+    const int b = (int)(t / ((int64_t)P * a.N * a.S));
+    const int y = p / a.W, x = p - y * a.W;
+    const WarpGeom g = make_geom(a.W, a.H, a.W1, a.H1);
+    const WarpRcp rc = make_rcp(g);
+    const float inv_min = a.inv_min[b], inv_max = a.inv_max[b];
+    float d;
+    if (a.depth) d = a.depth[((size_t)b * a.N + n) * P + p];
+    else if (a.init) d = init_hypothesis(n, a.N, inv_min, inv_max);
+    else d = iter_hypothesis(a.nd[b * a.nd_sb + p], a.offs[n], inv_min, inv_max);
+    const float* m = a.proj + ((size_t)b * a.S + s) * 12;
+    const float xs = (float)x * g.xr, ys = (float)y * g.yr;
+    float rx, ry, rz, ix, iy;
+    ray_dir(m, xs, ys, rx, ry, rz);
+    project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
+    TapDiag dg;
+    (void)make_taps(ix, iy, a.W1, a.H1, &dg);
+    int32_t* o = a.out + (((size_t)b * a.S + s) * a.N + n) * 3 * P + p;
+    o[0] = tap_floor_to_int(dg.fx0);
+    o[P] = tap_floor_to_int(dg.fy0);
+    o[2 * (size_t)P] = dg.bits;
+    if (a.coords) {
+        float* c = a.coords + (((size_t)b * a.S + s) * a.N + n) * 2 * P + p;
+        c[0] = ix;
+        c[P] = iy;
+    }
+}
+
 }  // namespace itermvs
 
 using namespace itermvs;
+
+extern "C" int itermvs_tap_indices(const itermvs_tap_params* p, void* stream) {
+    ITERMVS_RETURN_IF(!p, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(p->B < 1 || p->H < 1 || p->W < 1 || p->H1 < 1 || p->W1 < 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(p->S < 1 || p->S > ITERMVS_MAX_SRC, ITERMVS_ERR_VIEWS);
+    ITERMVS_RETURN_IF(!p->proj || !p->inv_depth_min || !p->inv_depth_max || !p->out, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(p->N < 1 || (p->init && p->N < 2), ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(!p->depth && !p->init && (!p->norm_depth || p->N > ITERMVS_MAX_HYP), p->norm_depth ? ITERMVS_ERR_DIMS : ITERMVS_ERR_NULL);
+    TapArgs a;
+    a.proj = p->proj; a.depth = p->depth; a.nd = p->norm_depth; a.nd_sb = p->norm_depth_sb;
+    for (int n = 0; n < ITERMVS_MAX_HYP; ++n) a.offs[n] = p->offsets[n];
+    a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max; a.out = p->out; a.coords = p->coords;
+    a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.N = p->N; a.H1 = p->H1; a.W1 = p->W1; a.init = p->init;
+    const int64_t total = (int64_t)p->B * p->S * p->N * p->H * p->W;
+    ITERMVS_RETURN_IF(total >= ((int64_t)1 << 31) * 256, ITERMVS_ERR_DIMS);
+    hipLaunchKernelGGL(tap_indices_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return itermvs_launch_status();
+}
 
 extern "C" int itermvs_pvw_tail(const float* x, const float* w, const float* bias, int32_t M, int32_t N, int32_t C,
                                 int32_t P, float* out, void* stream) {

@@ -107,8 +107,7 @@ __device__ __forceinline__ bool plane_inverse(const float* __restrict__ m, float
 }
 // depth of plane n of the initialisation branch (itermvs.py:13-17, the forward kernel's expression)
 __device__ __forceinline__ float plane_depth(int n, int N, float inv_min, float inv_max) {
-    const float frac = (float)n / (float)(N - 1);
-    return 1.0f / (inv_max + frac * (inv_min - inv_max));
+    return init_hypothesis(n, N, inv_min, inv_max);
 }
 
 constexpr int kBwdTile = 16;                                           // pixels per block = rows of 16 lanes
@@ -219,12 +218,9 @@ __device__ __forceinline__ void corr_bwd_level(const BwdArgs& a, const BwdLevel&
             if constexpr (decltype(explicit_depth)::value) {
                 d = L.depth[((size_t)b * N + n) * P + pc];
             } else if (a.init) {   // itermvs.py:13-17
-                const float frac = (float)n / (float)(N - 1);
-                d = 1.0f / (inv_max + frac * (inv_min - inv_max));
+                d = init_hypothesis(n, N, inv_min, inv_max);
             } else {               // itermvs.py:291-293
-                float ns = ndv + L.offs[n];
-                ns = fminf(fmaxf(ns, 0.0f), 1.0f);
-                d = unnormalize_depth(ns, inv_min, inv_max);
+                d = iter_hypothesis(ndv, L.offs[n], inv_min, inv_max);
             }
             float ix, iy;
             project_fast(g, rc, m, rx, ry, rz, d, ix, iy);

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import MAX_HYP, MAX_SRC, ConvParams, CorrInitParams, CorrIterParams, FMap, LevelSrc, check
+from ._lib import MAX_HYP, MAX_SRC, ConvParams, CorrInitParams, CorrIterParams, FMap, LevelSrc, TapParams, check
 
 Tensor = torch.Tensor
 
@@ -527,6 +527,41 @@ def corr_init(src3: Sequence[Tensor], ref3: Tensor, proj: Tensor, inv_min: Tenso
     if not timed:
         lib.itermvs_profile_set_mask(_PROFILE_MASK[0])
     return out
+
+
+def tap_indices(proj: Tensor, inv_min: Tensor, inv_max: Tensor, grid_hw: Tuple[int, int], src_hw: Tuple[int, int], *,
+                depth: Optional[Tensor] = None, norm_depth: Optional[Tensor] = None, offsets: Sequence[float] = (),
+                init_samples: int = 0, want_coords: bool = False):
+    """Diagnostic (itermvs_tap_indices): floor(ix), floor(iy) and the validity bits of the bilinear footprints exactly as
+    the fused correlation kernels compute them (module.py:99-115 + grid_sample's floor).  proj [B,S,12]; hypotheses from
+    ``depth`` [B,N,h,w], or ``init_samples`` initial planes, or ``norm_depth`` [B,1,h,w] + ``offsets``.
+    -> int32 [B,S,N,3,h,w] (x0, y0, bits)  (+ float [B,S,N,2,h,w] coordinates with ``want_coords``)."""
+    proj = _dev(proj, "proj").contiguous()
+    b, s = proj.shape[0], proj.shape[1]
+    h, w = grid_hw
+    p = TapParams()
+    p.B, p.S, p.H, p.W, p.H1, p.W1 = b, s, h, w, src_hw[0], src_hw[1]
+    p.proj = proj.data_ptr()
+    if depth is not None:
+        depth = _dev(depth, "depth").contiguous()
+        p.N = depth.shape[1]
+        p.depth = depth.data_ptr()
+    elif init_samples:
+        p.N, p.init = init_samples, 1
+    else:
+        nd = _dev(norm_depth, "norm_depth")
+        if nd.stride(-1) != 1 or nd.stride(-2) != w:
+            nd = nd.contiguous()
+        p.N = len(offsets)
+        p.norm_depth, p.norm_depth_sb = nd.data_ptr(), nd.stride(0)
+        for i, o in enumerate(offsets):
+            p.offsets[i] = o
+    p.inv_depth_min, p.inv_depth_max = _dev(inv_min, "inv_min").data_ptr(), _dev(inv_max, "inv_max").data_ptr()
+    out = torch.empty((b, s, p.N, 3, h, w), device=proj.device, dtype=torch.int32)
+    coords = torch.empty((b, s, p.N, 2, h, w), device=proj.device, dtype=torch.float32) if want_coords else None
+    p.out, p.coords = out.data_ptr(), _ptr(coords)
+    check(_lib.load().itermvs_tap_indices(C.byref(p), _stream()), "itermvs_tap_indices")
+    return (out, coords) if want_coords else out
 
 
 def view_aggregate(corr: Tensor, w: Tensor) -> Tensor:

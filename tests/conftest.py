@@ -73,6 +73,24 @@ def weights_dtu():
     return load_weights("dtu")
 
 
+TAP_CASES = ["cfg1_l1", "cfg1_init", "mid_l2", "mid_l3", "mid_l1_smooth", "b2_l2", "behind_l1", "behind_l3"]
+
+
+def tap_planes(ix, iy, h1, w1):
+    """floor / bounds decisions of grid_sample(bilinear, zeros, align_corners=True) on un-normalised coordinates
+    [B,N,H,W] -> int32 [B,N,3,H,W] = (floor(ix), floor(iy), bits), with the conventions of itermvs_tap_indices and of
+    tests/golden/make_golden.py:tap_planes (NaN -> INT32_MIN, saturation at +-2^30; bit 0: x0 inside, 1: x0+1, 2: y0, 3: y0+1)"""
+    fx, fy = torch.floor(ix), torch.floor(iy)
+
+    def to_int(f):
+        o = torch.clamp(torch.nan_to_num(f, nan=0.0, posinf=2.0 ** 30, neginf=-2.0 ** 30), -2.0 ** 30, 2.0 ** 30).to(torch.int32)
+        return torch.where(torch.isnan(f), torch.full_like(o, -2 ** 31), o)
+
+    bits = ((fx >= 0) & (fx <= w1 - 1)).int() | (((fx + 1 >= 0) & (fx + 1 <= w1 - 1)).int() << 1) | \
+           (((fy >= 0) & (fy <= h1 - 1)).int() << 2) | (((fy + 1 >= 0) & (fy + 1 <= h1 - 1)).int() << 3)
+    return torch.stack([to_int(fx), to_int(fy), bits.to(torch.int32)], 2)
+
+
 def grad_slice(g, n=256):
     """``n`` evenly spaced elements of a gradient tensor (all of it when smaller); the indices tests/golden/make_golden.py
     recorded the reference's gradients at"""

@@ -127,6 +127,119 @@ def golden_warp():
 
 
 # ----------------------------------------------------------------------------
+# 2b. the reference's own SAMPLING GRIDS: tap indices of module.py:99-119
+# ----------------------------------------------------------------------------
+def tap_planes(grid, num_depth, height, width, h1, w1):
+    """floor / bounds decisions of F.grid_sample(bilinear, zeros, align_corners=True) on the reference's grid
+    (ATen GridSampler.h:31 un-normalisation ``((g + 1) / 2) * (size - 1)``, :205-207 floor, within_bounds_2d), in fp32 like
+    the op: grid [B, N*H, W, 2] -> int32 [B,N,3,H,W] = (floor(ix), floor(iy), bits); bit 0: x0 inside, 1: x0+1, 2: y0, 3: y0+1.
+    Same saturation as itermvs_tap_indices: NaN -> INT32_MIN, +-2^30."""
+    b = grid.shape[0]
+    g = grid.view(b, num_depth, height, width, 2)
+    ix = ((g[..., 0] + 1) / 2) * (w1 - 1)
+    iy = ((g[..., 1] + 1) / 2) * (h1 - 1)
+    fx, fy = torch.floor(ix), torch.floor(iy)
+
+    def to_int(f):
+        o = torch.clamp(torch.nan_to_num(f, nan=0.0, posinf=2.0 ** 30, neginf=-2.0 ** 30), -2.0 ** 30, 2.0 ** 30).to(torch.int32)
+        return torch.where(torch.isnan(f), torch.full_like(o, -2 ** 31), o)
+
+    bits = ((fx >= 0) & (fx <= w1 - 1)).int() | (((fx + 1 >= 0) & (fx + 1 <= w1 - 1)).int() << 1) | \
+           (((fy >= 0) & (fy <= h1 - 1)).int() << 2) | (((fy + 1 >= 0) & (fy + 1 <= h1 - 1)).int() << 3)
+    return torch.stack([to_int(fx), to_int(fy), bits.to(torch.int32)], 2)
+
+
+def reference_taps(pm, depth, h1, w1):
+    """run the reference's differentiable_warping per source view with torch.matmul and F.grid_sample observed (no source
+    edits): -> (its composed proj [B,S,4,4], tap planes int32 [B,S,N,3,H,W])"""
+    b, n, h, w = depth.shape
+    seen = {}
+    real_mm, real_gs = torch.matmul, torch.nn.functional.grid_sample
+
+    def mm(a, bb, *args, **kw):
+        out = real_mm(a, bb, *args, **kw)
+        if tuple(out.shape[-2:]) == (4, 4) and "proj" not in seen:
+            seen["proj"] = out.clone()
+        return out
+
+    def gs(inp, grid, *args, **kw):
+        seen["grid"] = grid.clone()
+        return real_gs(inp, grid, *args, **kw)
+
+    projs, planes = [], []
+    src = torch.zeros((b, 1, h1, w1))
+    for v in range(1, pm.shape[1]):
+        seen.clear()
+        torch.matmul, torch.nn.functional.grid_sample = mm, gs
+        try:
+            ref_module.differentiable_warping(src, pm[:, v], pm[:, 0], depth)
+        finally:
+            torch.matmul, torch.nn.functional.grid_sample = real_mm, real_gs
+        projs.append(seen["proj"])
+        planes.append(tap_planes(seen["grid"], n, h, w, h1, w1))
+    return torch.stack(projs, 1), torch.stack(planes, 1)
+
+
+def golden_taps():
+    """tap_cases.npz: for DTU-like cameras, the floor / bounds decisions of the reference's sampling for the hypotheses the
+    reference itself builds (itermvs.py:11-19 and :290-293) -- the `pixel indices bit-exact` pin of the fused kernels."""
+    import models.itermvs as ref_itermvs
+    gen = torch.Generator().manual_seed(23)
+    out = {}
+    core = ref_itermvs.IterMVS(iteration=1, feature_dim=32, hidden_dim=32, test=True)
+
+    def iter_samples(nd, inv_min, inv_max, lvl):           # itermvs.py:290-293, the reference's own expressions
+        ns = nd + core.corr_interval[f"level{lvl}"] * core.interval_scale
+        ns = torch.clamp(ns, min=0, max=1)
+        return ref_module.depth_unnormalization(ns, inv_min, inv_max)
+
+    cases = [
+        # name, batch, image H, W, views, level, kind
+        ("cfg1_l1", 1, 512, 640, 5, 1, "noise"),
+        ("cfg1_init", 1, 512, 640, 5, 3, "init"),
+        ("mid_l2", 1, 192, 256, 5, 2, "noise"),
+        ("mid_l3", 1, 192, 256, 5, 3, "noise"),
+        ("mid_l1_smooth", 1, 192, 256, 5, 1, "smooth"),
+        ("b2_l2", 2, 96, 128, 3, 2, "noise"),             # batch == 2 branch, module.py:78-84
+        ("behind_l1", 1, 96, 128, 3, 1, "behind"),        # Z <= 1e-2 -> (W, H, 1), lands inside the level-1 map
+        ("behind_l3", 1, 96, 128, 3, 3, "behind"),
+    ]
+    for name, b, hh, ww, views, lvl, kind in cases:
+        sample = synthetic.make_sample(batch=b, num_views=views, height=hh, width=ww, seed=5)
+        pm = sample["proj_matrices"][f"level_{lvl}"].clone()
+        if kind == "behind":
+            ang = np.radians(100.0)
+            ry = torch.tensor([[np.cos(ang), 0, np.sin(ang), 0], [0, 1, 0, 0],
+                               [-np.sin(ang), 0, np.cos(ang), 600.0], [0, 0, 0, 1]], dtype=torch.float32)
+            pm[:, 1] = pm[:, 1] @ ry
+        dmin, dmax = sample["depth_min"].float(), sample["depth_max"].float()
+        inv_min, inv_max = (1.0 / dmin).view(b, 1, 1, 1), (1.0 / dmax).view(b, 1, 1, 1)       # itermvs.py:267-268
+        h1, w1 = hh >> lvl, ww >> lvl
+        arrays = {}
+        if kind == "init":
+            h, w = hh // 8, ww // 8
+            depth = core.depth_initialization(inv_min, inv_max, h, w, torch.device("cpu"))   # itermvs.py:270
+        else:
+            h, w = hh // 4, ww // 4
+            if kind == "smooth":
+                yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
+                nd = (0.3 + 0.3 * xx + 0.1 * yy + 0.002 * torch.randn((h, w), generator=gen)).view(1, 1, h, w).repeat(b, 1, 1, 1)
+            else:
+                nd = torch.rand((b, 1, h, w), generator=gen)
+            depth = iter_samples(nd, inv_min, inv_max, lvl)
+            arrays["nd"] = npy(nd)
+        proj, planes = reference_taps(pm, depth.contiguous(), h1, w1)
+        arrays.update(proj=npy(proj), depth=npy(depth), taps=npy(planes), inv_min=npy(inv_min.view(b)), inv_max=npy(inv_max.view(b)),
+                      meta=np.array([lvl, h, w, h1, w1, 1 if kind == "init" else 0], dtype=np.int64))
+        for k, v in arrays.items():
+            out[f"{name}.{k}"] = v
+        bits = planes[:, :, :, 2]
+        print(f"  taps {name}: {planes[:, :, :, 0].numel()} footprints, all four taps inside {float((bits == 15).float().mean()):.3f}, "
+              f"no column inside {float(((bits & 3) == 0).float().mean()):.3f}")
+    save("tap_cases.npz", **out)
+
+
+# ----------------------------------------------------------------------------
 # 3. small end-to-end run with every seam recorded
 # ----------------------------------------------------------------------------
 def record_e2e(weights, tag, height=64, width=96, views=3, iteration=2, seed=11):
@@ -356,6 +469,8 @@ def main():
                                             weights_only=False)["model"])
     if want("warp"):
         golden_warp()
+    if want("taps"):
+        golden_taps()
     if want("upsample"):
         golden_upsample()
     if want("e2e"):

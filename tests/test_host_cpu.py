@@ -43,6 +43,7 @@ def test_struct_layout_matches_header_sizes():
     assert C.sizeof(_lib.LevelSrc) == 16 * 8 + 4 * 8 + 4 * 4
     assert C.sizeof(_lib.CorrIterParams) == 8 * 4 + 3 * C.sizeof(_lib.LevelSrc) + 3 * 8 + 3 * 8 + 3 * 8 + 8 + 8 + 3 * 8 * 4 + 2 * 8 + 3 * 8
     assert C.sizeof(_lib.CorrInitParams) == 6 * 4 + C.sizeof(_lib.LevelSrc) + C.sizeof(_lib.FMap) + 5 * 8
+    assert C.sizeof(_lib.TapParams) == 8 * 4 + 3 * 8 + 8 + 8 * 4 + 4 * 8
 
 
 def test_argument_validation_error_codes():
@@ -70,6 +71,16 @@ def test_argument_validation_error_codes():
     assert lib.itermvs_corr_init(C.byref(p), None) == -5                           # ERR_ALIGN
     p.S = 17
     assert lib.itermvs_corr_init(C.byref(p), None) == -4                           # ERR_VIEWS
+    # the tap-index diagnostic
+    assert lib.itermvs_tap_indices(None, None) == -1
+    t = _lib.TapParams()
+    t.B, t.S, t.H, t.W, t.N, t.H1, t.W1 = 1, 1, 4, 4, 4, 4, 4
+    t.proj = addr; t.inv_depth_min = addr; t.inv_depth_max = addr; t.out = addr
+    assert lib.itermvs_tap_indices(C.byref(t), None) == -1                         # no hypotheses source (ERR_NULL)
+    t.norm_depth = addr; t.N = 9
+    assert lib.itermvs_tap_indices(C.byref(t), None) == -2                         # more offsets than ITERMVS_MAX_HYP
+    t.S = 17
+    assert lib.itermvs_tap_indices(C.byref(t), None) == -4                         # ERR_VIEWS
     # training BatchNorm entry points: scratch size = one (count, mean, M2) triple per 8192-float slab + 3 floats per channel
     assert lib.itermvs_bn_workspace_floats(20, 8, 512 * 640) == 8 * 20 * 40 * 3 + 8 * 3
     assert lib.itermvs_bn_workspace_floats(3, 16, 33 * 20) == 16 * 3 * 1 * 3 + 16 * 3

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import check_gradient_slices, golden, load_weights
+from conftest import TAP_CASES, check_gradient_slices, golden, load_weights, tap_planes
 from oracle import itermvs_oracle as O
 
 WARP_CASES = ["l1", "l2_b2", "l3", "init", "l1_behind", "l3_behind"]
@@ -29,6 +29,28 @@ def test_warp_matches_reference(case):
     zr = ref.abs().sum(1) == 0
     zo = warped.abs().sum(1) == 0
     assert float((zr != zo).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("case", TAP_CASES)
+def test_sampling_positions_floor_equal_the_references(case):
+    """tap_cases.npz holds the floor / bounds decisions of the REFERENCE's own sampling grids (observed at F.grid_sample,
+    hypotheses built by the reference's DepthInitialization / iteration expressions).  The oracle's warp_source_coords on the
+    reference's composed projection reproduces every one of them: its coordinates are the reference's at the bit level where
+    it matters (module.py:99-115 restated op for op) -- which lets the GPU tests use the oracle as the tap-index checker at
+    sizes that have no fixture."""
+    g = golden("tap_cases.npz")
+    lvl, h, w, h1, w1, init = (int(v) for v in g.np(f"{case}.meta"))
+    proj, depth, want = g[f"{case}.proj"], g[f"{case}.depth"], g[f"{case}.taps"]
+    for s in range(proj.shape[1]):
+        ix, iy, _ = O.warp_source_coords(proj[:, s], depth, h1, w1)
+        got = tap_planes(ix, iy, h1, w1)
+        assert torch.equal(got, want[:, s]), (case, s, int((got != want[:, s]).sum()))
+    # the hypotheses themselves: the oracle's constructions equal the reference's (itermvs.py:11-19, :290-293)
+    inv_min, inv_max = g[f"{case}.inv_min"].view(-1, 1, 1, 1), g[f"{case}.inv_max"].view(-1, 1, 1, 1)
+    if init:
+        assert torch.equal(O.initial_depth_samples(inv_min, inv_max, h, w), depth)
+    else:
+        assert torch.equal(O.iteration_depth_samples(g[f"{case}.nd"], inv_min, inv_max)[lvl], depth)
 
 
 def test_resize_bilinear_equals_interpolate():
