@@ -124,7 +124,13 @@ def compose_projection(src_proj: Tensor, ref_proj: Tensor) -> Tensor:
     return proj
 
 
-def warp_source_coords(proj: Tensor, depth: Tensor, h1: int, w1: int
+def _fma32(a: Tensor, b: Tensor, c: Tensor) -> Tensor:
+    """fp32 fused multiply-add through fp64: the product of two floats is exact in double, so this differs from a hardware
+    fma only by a second rounding in ~2^-29 of the cases."""
+    return (a.double() * b.double() + c.double()).float()
+
+
+def warp_source_coords(proj: Tensor, depth: Tensor, h1: int, w1: int, ray_dot: str = "matmul"
                        ) -> Tuple[Tensor, Tensor, Tensor]:
     """module.py:89-115 + GridSampler.h:31 -- source-pixel coordinates.
 
@@ -132,6 +138,13 @@ def warp_source_coords(proj: Tensor, depth: Tensor, h1: int, w1: int
     depth [B,N,H,W] hypotheses on the sample grid
     returns (ix, iy, valid) each [B,N,H,W]: un-normalised sampling position in
     the H1 x W1 source map and the (never requested) valid mask.
+
+    ``ray_dot``: how ``rot @ xyz`` (module.py:99, a K = 3 dot product inside a BLAS sgemm) is rounded.  "matmul" calls
+    ``torch.matmul`` like the reference -- whose bits depend on the host: MKL evaluates it as the k-ordered fma chain
+    fma(r2, 1, fma(r1, y, r0 * x)) on the Intel host the golden vectors were captured on, and WITHOUT fma on an AMD
+    EPYC host (7 % of the coordinates then differ in the last bit, ~1e-6 of the floors; tools/tap_probe.py).  "fma" is that
+    k-ordered fma chain written out: host-independent, bit-identical to the reference on the golden host
+    (tests/test_oracle_golden.py::test_sampling_positions_floor_equal_the_references) -- the checker of the GPU tap tests.
     """
     b, n, h, w = depth.shape
     rot = proj[:, :3, :3]
@@ -141,8 +154,12 @@ def warp_source_coords(proj: Tensor, depth: Tensor, h1: int, w1: int
                             torch.arange(w, dtype=torch.float32, device=dev), indexing="ij")
     xs = xs * (w1 / w)                      # module.py:95-96 (python float ratio)
     ys = ys * (h1 / h)
-    pix = torch.stack((xs.reshape(-1), ys.reshape(-1), torch.ones(h * w, device=dev)))  # [3,HW]
-    ray = torch.matmul(rot, pix.unsqueeze(0).expand(b, 3, h * w))           # [B,3,HW]
+    if ray_dot == "fma":
+        xf, yf = xs.reshape(1, -1), ys.reshape(1, -1)
+        ray = torch.stack([_fma32(rot[:, i, 1:2], yf, rot[:, i, 0:1] * xf) + rot[:, i, 2:3] for i in range(3)], 1)
+    else:
+        pix = torch.stack((xs.reshape(-1), ys.reshape(-1), torch.ones(h * w, device=dev)))  # [3,HW]
+        ray = torch.matmul(rot, pix.unsqueeze(0).expand(b, 3, h * w))       # [B,3,HW]
     pts = ray.unsqueeze(2) * depth.reshape(b, 1, n, h * w)                  # [B,3,N,HW]
     pts = pts + trans.view(b, 3, 1, 1)
     X, Y, Z = pts[:, 0], pts[:, 1], pts[:, 2]

@@ -18,6 +18,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A/B runs of the suite against another BUILD of the library (tools/build_variants.sh, e.g. -DITERMVS_EXACT_DIV): test
+    # infrastructure only -- the product package has no such switch
+    alt = os.environ.get("ITERMVS_TEST_LIB")
+    if alt:
+        from itermvs_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(alt)
 
 
 def pytest_collection_modifyitems(config, items):
