@@ -363,7 +363,12 @@ int itermvs_bilinear_up2(const float* x, int32_t B, int32_t C, int32_t H, int32_
  *     implicit-GEMM kernel (any 1x1 / 3x3 shape);
  *   weight_format 2: [9][chunks][4][Cout_pad16][S] with element (tap, ch, q, co, s) = weight of input
  *     channel ch*4*S + q*S + s (S = 1 / 2 / 4 for Cin <= 4 / <= 8 / larger), zero padded -- the LDS-tiled
- *     persistent matrix-core kernel for 3x3, stride 1|2, dilation 1|2.  Up to three weight sets
+ *     persistent matrix-core kernel for 3x3, stride 1|2, dilation 1|2;
+ *   weight_format 3: bfloat16 [9][chunks][3][Cout_pad16][16] with element (tap, ch, p, co, c) = term p of the exact
+ *     three-term bf16 split (h = w truncated to 8 significant bits, m = (w - h) truncated, l = w - h - m) of the weight of
+ *     input channel ch*16 + c, zero padded -- the same LDS-tiled kernel on v_mfma_f32_16x16x32_bf16 for 3x3 layers with
+ *     Cin > 8: activations are split the same way when staged, the six largest cross terms are accumulated in fp32
+ *     (error ~2^-23 per product: fp32-rounding class, NOT bit-identical to the fp32 forms).  Up to three weight sets
  * per launch: batch items [0,seg_end[0]) use set 0, [seg_end[0],seg_end[1]) set 1, the rest set 2
  * (the three CorrNets of one iteration in one launch).
  * Epilogue `act`: 0 v+add | 1 relu(v+add) | 2 sigmoid | 3 tanh | 4 sigmoid(v)*aux1 (r*h) |

@@ -127,6 +127,7 @@ using namespace itermvs;
 int itermvs_conv2d_mfma(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);      // conv_mfma.hip
 int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);      // conv_tile.hip
 int itermvs_deconv2d_tile(const itermvs_conv_params* p, hipStream_t stream);                        // conv_tile.hip
+int itermvs_conv2d_tile3(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream);     // conv_tile3.hip
 
 static int conv2d_impl(const itermvs_conv_params* p, void* stream);
 
@@ -143,7 +144,7 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     ITERMVS_RETURN_IF(p->N < 1 || p->Cin < 1 || p->Cout < 1 || p->Hin < 1 || p->Win < 1, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(p->ksize != 1 && p->ksize != 3, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(p->n_seg < 1 || p->n_seg > 3 || p->act < 0 || p->act > 7, ITERMVS_ERR_DIMS);
-    ITERMVS_RETURN_IF((p->act == 6 || p->act == 7) && (!p->aux1 || p->add || p->out2 || p->out_layout != 0 || (p->Cout != 16 && p->Cout != 32) || p->weight_format != 2 || p->ksize != 3 ||
+    ITERMVS_RETURN_IF((p->act == 6 || p->act == 7) && (!p->aux1 || p->add || p->out2 || p->out_layout != 0 || (p->Cout != 16 && p->Cout != 32) || (p->weight_format != 2 && p->weight_format != 3) || p->ksize != 3 ||
                                       p->split_cout != 0 || p->transposed || p->n_seg != 1), ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF((p->act == 4 || p->act == 5 || p->act == 6 || p->act == 7) && !p->aux1, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->act == 5 && !p->aux2, ITERMVS_ERR_NULL);
@@ -151,7 +152,7 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     ITERMVS_RETURN_IF(p->add_mode < 0 || p->add_mode > 1, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(p->out_layout < 0 || p->out_layout > 3, ITERMVS_ERR_DIMS);
     if (p->split_cout != 0) {
-        ITERMVS_RETURN_IF(p->weight_format != 2 || p->transposed || p->out_layout != 0 || p->add || p->out2, ITERMVS_ERR_DIMS);
+        ITERMVS_RETURN_IF((p->weight_format != 2 && p->weight_format != 3) || p->transposed || p->out_layout != 0 || p->add || p->out2, ITERMVS_ERR_DIMS);
         ITERMVS_RETURN_IF(p->split_cout < 16 || p->split_cout >= p->Cout || (p->split_cout & 15), ITERMVS_ERR_DIMS);
         ITERMVS_RETURN_IF(!p->out_b || p->act_b < 0 || p->act_b > 4 || p->act > 4, ITERMVS_ERR_DIMS);
         ITERMVS_RETURN_IF(p->act_b == 4 && !p->aux1, ITERMVS_ERR_NULL);
@@ -188,6 +189,10 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     ITERMVS_RETURN_IF(p->add_mode == 1 && ((a.Hout | a.Wout) & 1), ITERMVS_ERR_DIMS);
     if (p->weight_format == 2) {   // LDS-tiled 3x3 kernels; the packed layout fits no other kernel
         const int rc = itermvs_conv2d_tile(p, a.Hout, a.Wout, (hipStream_t)stream);
+        return rc == 1 ? ITERMVS_ERR_DIMS : rc;
+    }
+    if (p->weight_format == 3) {   // bf16x3 split on the bf16 MFMA (3x3, more than 8 input channels)
+        const int rc = itermvs_conv2d_tile3(p, a.Hout, a.Wout, (hipStream_t)stream);
         return rc == 1 ? ITERMVS_ERR_DIMS : rc;
     }
     if (p->weight_format == 1) return itermvs_conv2d_mfma(p, a.Hout, a.Wout, (hipStream_t)stream);

@@ -26,31 +26,13 @@
 
 #include "common.hpp"
 #include "conv_epilogue.hpp"
+#include "conv_tile.hpp"
 
 namespace itermvs {
 
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
-struct TileArgs {
-    const float* in;
-    float* out;
-    float* out2;
-    const float* add;
-    const float* aux1;
-    const float* aux2;
-    int64_t in_sn, out_sn, add_sn, aux1_sn, aux2_sn;
-    const float* weight[3];   // packed [9][nchunk][4][CoutPad][S]
-    const float* bias[3];
-    int seg_end[3];
-    int N, Cin, Hin, Win, Cout, CoutPad, Hout, Wout;
-    float* out_b;             // second result (channels >= split) or nullptr
-    int64_t out_b_sn;
-    int split, act_b;
-    int pad, act, add_mode, out_nhwc, nchunk, nstage, tiles_x, tiles_y, ncb, total;
-    uint32_t rcp_tiles_x, rcp_tiles_y;   // floor(2^32 / d) + 1
-};
 
-constexpr uint32_t kTileOob = 0x7fffffffu;
 
 // -DITERMVS_TILE_TRACE (tools/ubench/conv_tile_trace.hip): wave 0 of workgroup 0 stamps the phases of its tiles
 #ifdef ITERMVS_TILE_TRACE

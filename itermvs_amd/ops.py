@@ -821,14 +821,36 @@ def tile_k_split(cin: int) -> int:
     return 1 if cin <= 4 else 2 if cin <= 8 else 4
 
 
+def split_bf16x3(t: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """fp32 tensor -> (h, m, l) bfloat16 tensors with h + m + l == t EXACTLY (finite t): h = t truncated to bf16's 8
+    significant bits, m = (t - h) truncated, l = t - h - m (at most 8 bits left).  The split conv_tile3.hip applies to the
+    activations when it stages them."""
+    t = t.float().contiguous()
+    mask = -65536
+    h = (t.view(torch.int32) & mask).view(torch.float32)
+    r = t - h
+    m = (r.view(torch.int32) & mask).view(torch.float32)
+    l = r - m
+    return h.to(torch.bfloat16), m.to(torch.bfloat16), l.to(torch.bfloat16)
+
+
+# Default arithmetic of the 3x3 convolutions with more than 8 input channels (MfmaWeight(split3=None)):
+#   True  -> bf16x3 split on v_mfma_f32_16x16x32_bf16 (conv_tile3.hip, weight_format 3): fp32-comparable error, 2.7x less matrix time
+#   False -> exact fp32 MFMA (conv_tile.hip, weight_format 2): bit-for-bit an fmaf chain
+MFMA_SPLIT3_DEFAULT = True
+
+
 class MfmaWeight:
     """Matrix-core formats of a Conv2d weight [Cout,Cin,k,k], zero padded:
     ``data`` (weight_format 1, conv_mfma.hip): [k*k, Cin_pad4, Cout_pad16];
     ``tile`` (weight_format 2, conv_tile.hip, 3x3 only): [9, chunks, 4, Cout_pad16, S] whose element
-    (tap, ch, q, co, s) is the weight of input channel ch*4*S + q*S + s."""
+    (tap, ch, q, co, s) is the weight of input channel ch*4*S + q*S + s;
+    ``tile3`` (weight_format 3, conv_tile3.hip, 3x3 with Cin > 8, ``split3``): bfloat16 [9, chunks, 3, Cout_pad16, 16] whose
+    element (tap, ch, p, co, c) is term p (h, m, l of ``split_bf16x3``) of the weight of input channel ch*16 + c."""
 
-    def __init__(self, w: Tensor, transposed: bool = False):
-        """``transposed``: ``w`` is a ConvTranspose2d weight [Cin,Cout,k,k] (only the tile format is built)."""
+    def __init__(self, w: Tensor, transposed: bool = False, split3: Optional[bool] = None):
+        """``transposed``: ``w`` is a ConvTranspose2d weight [Cin,Cout,k,k] (only the tile format is built).
+        ``split3``: build (and let conv2d use) the bf16x3 form; None = ``MFMA_SPLIT3_DEFAULT``."""
         self.transposed = transposed
         if transposed:
             w = w.permute(1, 0, 2, 3)
@@ -844,6 +866,13 @@ class MfmaWeight:
             t = torch.zeros((9, nch * 4 * s, cout_p), device=w.device, dtype=torch.float32)
             t[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(9, cin, cout)
             self.tile = t.reshape(9, nch, 4, s, cout_p).permute(0, 1, 2, 4, 3).contiguous()
+        self.tile3 = None
+        if k == 3 and cin > 8 and not transposed and (MFMA_SPLIT3_DEFAULT if split3 is None else split3):
+            nch = (cin + 15) // 16
+            t = torch.zeros((9, nch * 16, cout_p), device=w.device, dtype=torch.float32)
+            t[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(9, cin, cout)
+            t = t.reshape(9, nch, 16, cout_p).permute(0, 1, 3, 2)                      # [9, chunks, Cout_pad, 16]
+            self.tile3 = torch.stack(split_bf16x3(t), 2).contiguous()                  # [9, chunks, 3, Cout_pad, 16] bf16
 
 
 _TILE_SHAPES = {(1, 1), (2, 1), (1, 2)}   # (stride, dilation) instantiated in conv_tile.hip
@@ -879,7 +908,7 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     weights = list(weight) if isinstance(weight, (list, tuple)) else [weight]
     biases = list(bias) if isinstance(bias, (list, tuple)) else [bias] * len(weights)
     n, cin, hin, win = x.shape
-    mfma, tiled = isinstance(weights[0], MfmaWeight), False
+    mfma, tiled, split3 = isinstance(weights[0], MfmaWeight), False, False
     if mfma:
         if transposed != weights[0].transposed:
             raise RuntimeError("conv2d: weight was packed for the other direction (MfmaWeight(transposed=...))")
@@ -887,7 +916,10 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
             raise RuntimeError("conv2d: MfmaWeight does not match the input channels / kernel size")
         cout = weights[0].cout
         tiled = transposed or all(_use_tile(wt, stride, dilation) for wt in weights)
-        weights = [wt.tile if tiled else wt.data for wt in weights]
+        # (stride-2 layers keep the fp32 form: their halo tiles leave no LDS for two resident workgroups in the split form, and
+        #  the sweep measured no gain -- profiles/r05)
+        split3 = tiled and not transposed and stride == 1 and all(wt.tile3 is not None for wt in weights)
+        weights = [(wt.tile3 if split3 else wt.tile) if tiled else wt.data for wt in weights]
     else:
         cout = weights[0].shape[3]
     if transposed:
@@ -936,7 +968,10 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
             setattr(p, name + "_sn", sn)
     p.n_seg = len(weights)
     for i, (wt, bs) in enumerate(zip(weights, biases)):
-        _dev(wt, "weight")
+        if not (mfma and split3):
+            _dev(wt, "weight")
+        elif not wt.is_cuda:
+            raise RuntimeError("weight: expected a CUDA/ROCm tensor - the IterMVS HIP engine has no CPU path")
         if not mfma and (not wt.is_contiguous() or wt.shape != (cin, ksize, ksize, cout)):
             raise RuntimeError(f"conv2d: packed weight must be contiguous [{cin},{ksize},{ksize},{cout}], got {tuple(wt.shape)}")
         p.weight[i] = wt.data_ptr()
@@ -954,7 +989,7 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
         p.out_b, p.out_b_sn = _planes(ob, "split output")
     p.ksize, p.stride, p.pad, p.dilation = ksize, stride, pad, dilation
     p.transposed, p.act = int(transposed), ACT[act]
-    p.weight_format = (2 if tiled else 1) if mfma else 0
+    p.weight_format = ((3 if split3 else 2) if tiled else 1) if mfma else 0
     p.add_mode = int(add_up2)
     if CONV_FLOP_COUNTER["enabled"]:
         CONV_FLOP_COUNTER["flops"] += 2.0 * n * hout * wout * cout_total * cin * ksize * ksize / (4.0 if transposed else 1.0)

@@ -13,6 +13,16 @@ def ops():
     return _ops
 
 
+@pytest.fixture(autouse=True, params=["bf16x3", "fp32"])
+def conv_arithmetic(request):
+    """every test of this file runs with both forms of the 3x3 layers with more than 8 input channels: the bf16x3 split on the
+    bf16 MFMA (conv_tile3.hip, the default) and the exact fp32 MFMA (conv_tile.hip); the other layers have one form"""
+    was = ops().MFMA_SPLIT3_DEFAULT
+    ops().MFMA_SPLIT3_DEFAULT = request.param == "bf16x3"
+    yield request.param
+    ops().MFMA_SPLIT3_DEFAULT = was
+
+
 def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-6))
 

@@ -75,6 +75,12 @@ def time_layer(x, wt, k, stride, dil):
 
 
 def main():
+    if "--fp32" in sys.argv:        # the exact fp32 MFMA form of the layers that default to the bf16x3 split
+        ops.MFMA_SPLIT3_DEFAULT = False
+        sys.argv.remove("--fp32")
+    sweep3 = "--sweep3" in sys.argv  # every (tile shape, channel blocking) of the bf16x3 kernel via ITERMVS_TILE3_FORCE
+    if sweep3:
+        sys.argv.remove("--sweep3")
     argv = [a for a in sys.argv[1:] if a != "--sweep"]
     sweep = "--sweep" in sys.argv
     only = argv[0] if argv else ""
@@ -89,6 +95,9 @@ def main():
         wt = ops.MfmaWeight((torch.randn((cout, cin, k, k), generator=gen) / (cin * k * k) ** 0.5).to(dev))
         os.environ.pop("ITERMVS_TILE_FORCE", None)
         us, out = time_layer(x, wt, k, stride, dil)
+        if us is None:
+            print(f"{name:22s} not covered by this build / form", flush=True)
+            continue
         flops = 2.0 * out.numel() * cin * k * k
         total += us * count
         line = f"{name:22s} N={n:3d} {cin:3d}>{cout:3d} {h}x{w} k{k} s{stride} d{dil}: {us:7.1f} us {flops / us / 1e6:6.1f} TFLOP/s x{count}"
@@ -101,6 +110,17 @@ def main():
                     if t is not None:
                         res.append((t, shape, mb))
             os.environ.pop("ITERMVS_TILE_FORCE", None)
+            res.sort()
+            line += " | " + " ".join(f"s{sh}m{mb}:{t:.1f}" for t, sh, mb in res)
+        if sweep3 and k == 3 and cin > 8:
+            res = []
+            for shape in (2, 1, 0):
+                for mb in (3, 2, 1):
+                    os.environ["ITERMVS_TILE3_FORCE"] = f"{shape},{mb}"
+                    t, _ = time_layer(x, wt, k, stride, dil)
+                    if t is not None:
+                        res.append((t, shape, mb))
+            os.environ.pop("ITERMVS_TILE3_FORCE", None)
             res.sort()
             line += " | " + " ".join(f"s{sh}m{mb}:{t:.1f}" for t, sh, mb in res)
         print(line, flush=True)
