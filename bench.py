@@ -38,18 +38,9 @@ def pmc_summary_file():
 
 
 def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int, e: int = 4):
-    """DESIGN.md 'Algorithmic bytes': every required tensor moved once; ``e`` = bytes per stored feature element (4, or 2
-    with --feature-dtype bf16 / fp16), everything else fp32.
-    Returns (bytes per corr_iter launch, bytes per corr_init launch, bytes per depth map)."""
-    p1, p2, p3 = (h // 2) * (w // 2), (h // 4) * (w // 4), (h // 8) * (w // 8)
-    it = batch * (s * (16 * p1 + 32 * p2 + 48 * p3) * e     # source pyramids, each view once
-                  + 96 * p2 * 4                             # packed reference features at 1/4 res (kept fp32)
-                  + p2 * 4                                  # normalised depth (hypotheses built in-kernel)
-                  + s * p2 * 4                              # view weights
-                  + 80 * p2 * 4)                            # [B,10,8,H/4,W/4] aggregated correlations out
-    init = batch * (s * 48 * p3 * e + 48 * p3 * e           # level-3 source + reference features
-                    + s * 8 * 32 * p3 * 4)                  # per-view correlation volume out
-    return it, init, (init + iters * it) / batch
+    """DESIGN.md 'Algorithmic bytes' (shared with the other legs: itermvs_amd/benchmarks.py)"""
+    from itermvs_amd.benchmarks import algorithmic_bytes as impl
+    return impl(s, h, w, batch, iters, e)
 
 
 def workload_name(views: int, height: int, width: int, iters: int) -> str:
@@ -107,8 +98,7 @@ def cpu_baseline(args, target_seconds: float = 15.0):
             run()
         dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "depth-maps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} depth maps of the same cfg-1 workload after warm-ups, best of 8/16/32/64 torch threads "
-                      f"(oracle/itermvs_oracle.py, torch-CPU, {os.cpu_count()} logical CPUs on the box)",
+            "sample": f"{n} depth maps of the same workload, best of 8/16/32/64 torch threads (oracle, {os.cpu_count()} logical CPUs)",
             "s_per_depth_map": dt / n}
 
 
@@ -201,10 +191,7 @@ def transfers_leg(args, dev, samples, world, u8: bool = False, in_flight: int = 
             "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
             "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h, "depth_maps_in_flight": in_flight,
             "images": "uint8 RGB, normalised on the GPU (itermvs_image_pyramid)" if u8 else "float32 level_0 tensor",
-            "note": "pinned host inputs -> H2D on a copy stream into the static inputs of alternating hipGraph runners, "
-                    "compute stream(s), D2H of depth + confidence into pinned host buffers on a third stream, ordered by the host "
-                    "(the upload of the next sample and the download of the oldest map run beside the replays in flight; no "
-                    "stream waits on another stream's event); same steps / barrier / max-over-ranks timing as `value`"}
+"protocol": "pinned host in/out, copies on their own streams, ordered by the host (see transfers_leg)"}
 
 
 def main() -> None:
@@ -228,6 +215,8 @@ def main() -> None:
                          "to back; `value` / `ms_per_step` are the MEDIAN region, min / max are reported beside them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-transfers", action="store_true", help="skip the host-buffers-in / host-buffers-out leg")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` legs (BASELINE cfg 3 / cfg 5 shapes, cfg 4 training step) run after the timed region")
     ap.add_argument("--minimal", action="store_true",
                     help="only the timed region (no CPU baseline, pipelined / transfer legs, conv roofline pass): profiling runs")
     ap.add_argument("--streams", type=int, default=1,
@@ -237,7 +226,7 @@ def main() -> None:
                     help="extra measurement: throughput with this many reference views in flight (0/1 = skip)")
     args = ap.parse_args()
     if args.minimal:
-        args.no_cpu_baseline = args.no_transfers = True
+        args.no_cpu_baseline = args.no_transfers = args.no_other_configs = True
         args.pipeline_streams = 0
     if args.projection == "host_fp32":          # an A/B of the headline region only: the side legs keep the default composition
         args.no_transfers = True
@@ -255,8 +244,9 @@ def main() -> None:
     rank, local_rank, world = shard.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())      # (ranks share a GPU only in the gloo test of the N > 1 path)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     # graph mode, one stream: TWO runners replayed alternately on that stream -- while step i runs, the event pairs
     # embedded in the graph of step i-1 (around its corr_iter / corr_init launches) are read, so every launch of the
@@ -340,6 +330,10 @@ def main() -> None:
 
     regions = shard.timed_regions(step, args.steps, args.warmup, args.repeats)
     elapsed = shard.median(regions)                    # the contract's K-step region; median of --repeats of them
+    # this rank's own clock around the same regions (timed_regions reports the max over ranks): a straggler GPU shows up as
+    # min < max across ranks in SCALE_r*.json
+    own_ms = shard.median(shard.last_local_regions()) / args.steps * 1e3
+    rank_ms = shard.gather_over_ranks(own_ms)
     if ab == 4:
         read_pairs(args.warmup + total_steps - 1)
         prof = graph_prof
@@ -363,13 +357,11 @@ def main() -> None:
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": b_iter, "avg_launch_ms": avg_ms, "launches_timed": len(t_iter),
                     "iterations_sampled": sorted({0, min(2, args.iters - 1)}) if ab == 4 else list(range(args.iters)),
-                    "timing": ("external hipEvent record nodes around the launch inside the replayed hipGraph, read for every replay "
-                               "of the timed regions; of the four alternating runners one brackets the corr_iter launch of GRU "
-                               "iteration 0 (hypotheses around the first, noisy depth map), the other the launch of iteration 2 "
-                               "(smooth depth map, like iterations 1 and 3) and the corr_init launch, two more runners carry no timing "
-                               "nodes; avg_launch_ms is the mean over both positions (a bracket costs ~5 us of graph time: ~4 us per "
-                               "step on average, included in `value`)"
-                               if ab == 4 else "hipEvent pairs on the launch stream inside the timed region, every iteration")}
+                    # (graph mode: external hipEvent record nodes around the launch inside the replayed hipGraph, read for every replay of
+                    #  the timed regions; runner 0 brackets the corr_iter launch of GRU iteration 0 -- hypotheses around the first, noisy
+                    #  depth map --, runner 1 that of iteration 2 and the corr_init launch, runners 2 and 3 carry no timing nodes: a
+                    #  bracket costs ~5 us of graph time, ~4 us per step on average, included in `value`)
+                    "timing": "hipEvent nodes inside the replayed graphs" if ab == 4 else "hipEvent pairs on the launch stream"}
         # HBM bytes per launch: rocprofv3 --pmc passes of THIS command (tools/pmc_kernels.sh -> tools/pmc_summary.py ->
         # profiles/<round>_pmc_kernels.json); taken only if the summary names the kernel that ran here and the same workload
         pmc_file = pmc_summary_file()
@@ -399,7 +391,7 @@ def main() -> None:
         sel = shard.timed_steps(sstep, args.steps, 4)
         staged = {"value": world * args.steps * args.batch / sel, "unit": "depth-maps/s", "steps": args.steps,
                   "ms_per_step": sel / args.steps * 1e3,
-                  "what": "same graphs, inputs copied device-to-device into the static buffers each step (the r01/r02 definition of `value`)"}
+                  "what": "inputs copied device-to-device into the static buffers each step"}
 
     # extra: independent reference views pipelined on several HIP streams of the same GPU (each stream replays
     # its own hipGraph segments).  Reported separately: with concurrent streams the HIP-event bracket of a
@@ -471,8 +463,33 @@ def main() -> None:
                              "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
                              "launches_per_step": len(conv_ms) // n_extra, "ms_per_step": sum(conv_ms) / n_extra,
                              "gflop_per_step": ops.CONV_FLOP_COUNTER["flops"] / n_extra / 1e9,
-                             "timing": "hipEvent pairs around every launch (each pair adds ~3 us to a 5-60 us launch), 3 extra eager steps after the timed region",
-                             "peak_note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) = vector fp32 peak"}
+                             "timing": "hipEvent pairs around every launch, 3 extra eager steps",
+                             "peak_note": "fp32-input MFMA peak; the 3x3 layers with > 8 input channels run the bf16x3 split (3 bf16 MFMAs "
+                                          "per 4 fp32 ones): the FLOPs counted are the convolution's, not the instructions'"}
+
+    # the other BASELINE configurations on the driver's record (rank 0 of a 1-GPU run, after everything timed above):
+    # cfg-3 shape (5 views 1600x1152, fp32 and fp16 feature storage), cfg-5 shape (11 views 1920x1280, 8 iterations, fp16
+    # storage) -- one captured hipGraph each, 5 warm-up + 10 timed replays -- and cfg 4's per-GPU training step (B = 4, bf16
+    # feature storage, --regress, 3 warm-up + 5 timed steps)
+    other = None
+    if rank == 0 and world == 1 and not args.no_other_configs and (args.views, args.height, args.width, args.iters) == (5, 512, 640, 4):
+        from itermvs_amd import benchmarks
+        del models[:], streams[:]
+        resident.clear()
+        torch.cuda.empty_cache()
+        other = {}
+        for name, (v_, h_, w_, it_, ft_) in {"cfg3_fp32": (5, 1152, 1600, 4, "fp32"), "cfg3_fp16": (5, 1152, 1600, 4, "fp16"),
+                                             "cfg5_fp16": (11, 1280, 1920, 8, "fp16")}.items():
+            try:
+                other[name] = benchmarks.shape_leg(dev, v_, h_, w_, it_, ft_, warmup=5, steps=10)
+            except Exception as e:  # noqa: BLE001  (a leg that fails must not take the headline line with it)
+                other[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        try:
+            t = benchmarks.train_step_leg(dev, batch=4, feature_dtype="bf16", regress=True, warmup=3, steps=5)
+            t.pop("_step", None)
+            other["train_step_cfg4"] = t
+        except Exception as e:  # noqa: BLE001
+            other["train_step_cfg4"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
     if rank == 0:
         result = {
@@ -491,15 +508,16 @@ def main() -> None:
                                    f"{args.width}x{args.height}, {args.iters} GRU iterations, test mode, "
                                    f"random-init weights, {args.batch} ref view(s) per step and GPU",
                        "views": args.views, "height": args.height, "width": args.width, "iterations": args.iters,
-                       "value_is": "inputs resident in HBM when the timed region starts, outputs left in HBM (the bench contract); "
-                                   "`value_with_transfers` = host buffers in / host buffers out",
+                       "value_is": "inputs resident in HBM; `value_with_transfers` = host buffers in / out",
                        "batch_per_gpu": args.batch, "streams_per_gpu": args.streams, "feature_dtype": args.feature_dtype,
                        "launch": "eager" if args.eager else "one hipGraph per depth map",
                        "parallelism": f"ref-view sharding x{world}, no collective",
                        "projection": args.projection,
                        "process_group": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                        "algorithmic_MB_per_depth_map": b_map / 1e6},
+            "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms)},   # each rank's own median region (straggler check)
             "roofline": roofline,
+            "other_configs": other,
             "roofline_conv": conv_roofline,
             "staged_inputs": staged,
             "pipelined": pipelined,

@@ -1,0 +1,139 @@
+"""Measurement legs shared by bench.py and the tools/ scripts (GPU box only): one depth map per hipGraph replay at any of the
+BASELINE shapes, and the cfg-4 training step.  Nothing here is on the product path."""
+from __future__ import annotations
+
+import time
+from typing import Dict, Optional
+
+import torch
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int, e: int = 4):
+    """DESIGN.md 'Algorithmic bytes' (hypotheses built in-kernel): every required tensor moved once; ``e`` =
+    bytes per stored feature element (4, or 2 with bf16 / fp16 feature storage), everything else fp32.
+    Returns (bytes per corr_iter launch, bytes per corr_init launch, bytes per depth map)."""
+    p1, p2, p3 = (h // 2) * (w // 2), (h // 4) * (w // 4), (h // 8) * (w // 8)
+    it = batch * (s * (16 * p1 + 32 * p2 + 48 * p3) * e     # source pyramids, each view once
+                  + 96 * p2 * 4                             # packed reference features at 1/4 res (kept fp32)
+                  + p2 * 4                                  # normalised depth
+                  + s * p2 * 4                              # view weights
+                  + 80 * p2 * 4)                            # [B,10,8,H/4,W/4] aggregated correlations out
+    init = batch * (s * 48 * p3 * e + 48 * p3 * e           # level-3 source + reference features
+                    + s * 8 * 32 * p3 * 4)                  # per-view correlation volume out
+    return it, init, (init + iters * it) / batch
+
+
+def shape_leg(dev, views: int, height: int, width: int, iters: int, feature_dtype: str = "fp32", warmup: int = 5,
+              steps: int = 10) -> Dict[str, object]:
+    """depth-maps/s of ONE captured hipGraph (one reference view per replay, inputs resident) at another shape than the
+    headline's, with HIP-event brackets around every fused correlation launch inside the graph:
+    ``warmup`` + ``steps`` replays -> value, ms per depth map, mean corr_iter / corr_init launch time and their fraction of
+    the HBM roof on the algorithmic bytes of that shape."""
+    from . import ops, synthetic
+    from .engine import GraphedRunner, InferenceEngine
+    from .net import Pipeline
+    m = Pipeline(iteration=iters, test=True)
+    m.load_state_dict(synthetic.random_state_dict(0))
+    m = m.to(dev).eval()
+    eng = InferenceEngine(m.weights(), iters, feature_dtype)
+    s = synthetic.make_sample(batch=1, num_views=views, height=height, width=width, seed=0)
+    pj = {l: s["proj_matrices"][f"level_{l}"].float().to(dev) for l in (1, 2, 3)}
+    per_step = iters + 1
+    ops.profile_enable((warmup + steps + 4) * per_step + 8, mask=0x3)
+    r = GraphedRunner(eng, s["imgs"]["level_0"].float().to(dev), pj, s["depth_min"].float().to(dev), s["depth_max"].float().to(dev))
+    first, count = r.profile_pairs
+    for _ in range(warmup):
+        r.graph.replay()
+    torch.cuda.synchronize(dev)
+    prof = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.graph.replay()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    for _ in range(3):                                   # the brackets of three more replays, read one by one (each read waits
+        r.graph.replay()                                 # for its replay: outside the timed loop)
+        prof.extend(ops.profile_graph_read(first, count))
+    ops.profile_enable(0)
+    eng.check_projection_finite()
+    e = 4 if feature_dtype == "fp32" else 2
+    b_iter, b_init, b_map = algorithmic_bytes(views - 1, height, width, 1, iters, e)
+    t_iter = [ms for kind, ms in prof if kind == 1]
+    t_init = [ms for kind, ms in prof if kind == 2]
+    out = {"views": views, "height": height, "width": width, "iterations": iters, "feature_dtype": feature_dtype,
+           "value": steps / dt, "unit": "depth-maps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup}
+    if t_iter:
+        ms = sum(t_iter) / len(t_iter)
+        out["corr_iter"] = {"avg_launch_ms": ms, "launches_timed": len(t_iter), "frac": b_iter / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if t_init:
+        ms = sum(t_init) / len(t_init)
+        out["corr_init"] = {"avg_launch_ms": ms, "launches_timed": len(t_init), "frac": b_init / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del r, eng, m
+    torch.cuda.empty_cache()
+    return out
+
+
+def train_step_leg(dev, batch: int = 4, views: int = 5, height: int = 512, width: int = 640, iteration: int = 4,
+                   feature_dtype: str = "bf16", regress: bool = True, warmup: int = 3, steps: int = 5,
+                   phases: bool = False) -> Dict[str, object]:
+    """BASELINE cfg 4's per-GPU training step (train_dtu.sh: 5 views, 640x512, 4 GRU iterations, ``batch`` per GPU, Adam +
+    gradient clip 2.0; reference train.py:194-243): forward (training graph on the fused correlation kernels), full_loss,
+    backward, flat gradient all-reduce (a no-op on one rank), clip, Adam -- ``train.train_step`` without its two host
+    read-backs inside the timed region."""
+    from . import ddp, synthetic
+    from .net import Pipeline, full_loss
+    torch.manual_seed(1)
+    model = Pipeline(iteration=iteration, test=False).to(dev)
+    model.feature_dtype = feature_dtype
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    imgs, projs, dmin, dmax, gt, mask = synthetic.make_training_batch(batch, num_views=views, height=height, width=width)
+    to = lambda d: {k: v.to(dev) for k, v in d.items()}  # noqa: E731
+    imgs, projs, gt, mask, dmin, dmax = to(imgs), to(projs), to(gt), to(mask), dmin.to(dev), dmax.to(dev)
+    params = list(model.parameters())
+
+    def fwd():
+        out = model(imgs, projs, dmin, dmax)
+        return full_loss(out["depths"], out["depths_upsampled"], out["confidences"], gt, mask, dmin, dmax, regress)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = fwd()
+        loss.backward()
+        ddp.flat_allreduce_gradients(params)
+        torch.nn.utils.clip_grad_norm_(params, 2.0)
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    res = {"ms_per_step": ms, "samples_per_s": batch * 1e3 / ms, "batch": batch, "views": views, "wh": [width, height],
+           "iteration": iteration, "feature_dtype": feature_dtype, "regress": regress, "steps": steps, "warmup": warmup,
+           "loss": float(loss.detach()), "peak_mem_MiB": torch.cuda.max_memory_allocated(dev) / 2 ** 20}
+    if phases:
+        ph = {"forward": 0.0, "backward": 0.0, "clip+adam": 0.0}
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize(dev); t = time.perf_counter()
+            loss = fwd()
+            torch.cuda.synchronize(dev); t1 = time.perf_counter()
+            loss.backward()
+            torch.cuda.synchronize(dev); t2 = time.perf_counter()
+            torch.nn.utils.clip_grad_norm_(params, 2.0)
+            opt.step()
+            torch.cuda.synchronize(dev); t3 = time.perf_counter()
+            ph["forward"] += (t1 - t) * 1e3 / steps
+            ph["backward"] += (t2 - t1) * 1e3 / steps
+            ph["clip+adam"] += (t3 - t2) * 1e3 / steps
+        res["phases_ms"] = ph
+    res["_step"] = step              # (tools/train_bench.py --profile reuses the prepared step)
+    return res

@@ -133,7 +133,9 @@ class InferenceEngine:
         self.corrnet_w = {l: ops.pack_corrnet_weights(w, f"iter_mvs.evaluation.corr_conv1.{l - 1}.") for l in (1, 2, 3)}
         dh = "iter_mvs.update.depth_head."
         self.head_w1, self.head_w2 = ops.pack_head_weights(w[dh + "2.weight"], w[dh + "4.weight"])
-        self.pk_zr = ops.MfmaWeight(self.w_zr)
+        # (z / r gates, 43 -> 64 dilated at 1/4 resolution: the bf16x3 form measured 18.7 us against 18.2 us -- four channel
+        #  blocks stage and split each tile four times; the q convolution, two blocks, gains: 11.1 vs 13.1 us)
+        self.pk_zr = ops.MfmaWeight(self.w_zr, split3=False)
 
     def _conv(self, x: Tensor, name: str, bias: bool = False, **kw) -> Tensor:
         """one layer by state-dict name (``name`` + "weight"/"bias")"""
@@ -235,8 +237,17 @@ class InferenceEngine:
         return ws
 
     def _release_owner(self, token: int) -> None:
-        """drop the private workspaces of a GraphedRunner that went away (its finalizer calls this)"""
-        for key in [k for k in self._ws if k[3] == token]:
+        """drop the private workspaces of a GraphedRunner that went away (its finalizer calls this).  The buffers were allocated
+        on the runner's capture stream while its graph replays on the callers' streams: a replay may still be writing them, so
+        the device is drained before the caching allocator may hand the blocks to anyone else (a rare event: a runner is
+        dropped when its shape leaves the LRU cache of ``Pipeline`` or the weights change)"""
+        keys = [k for k in self._ws if k[3] == token]
+        if keys:
+            try:
+                torch.cuda.synchronize(self.device)
+            except Exception:      # interpreter shutdown: the context may already be gone
+                pass
+        for key in keys:
             del self._ws[key]
 
     # -- stages (each reads / writes the workspace; see the module docstring) ---------------------

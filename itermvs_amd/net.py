@@ -79,6 +79,7 @@ class Pipeline(nn.Module):
             _attach(self, name, _default_init(name, shape), is_buffer)
         self._engine = None
         self._runners = {}
+        self.max_runners = 2        # input shapes whose captured hipGraphs are kept (least recently used dropped first)
         self._engine_version = None
         self._version_tensors = None
         self.use_graphs = False        # test mode: replay one hipGraph per depth map instead of launching kernel by kernel
@@ -102,7 +103,9 @@ class Pipeline(nn.Module):
         ``load_state_dict``, ``.to()`` / ``.cuda()``, a train/eval mode change, and whenever an autograd-visible in-place
         update of a parameter or buffer is detected at the next forward (optimizer steps, ``p.copy_()`` under ``no_grad``:
         the tensors' version counters).  Edits that bypass the version counter (``p.data.copy_(...)``, raw pointer writes,
-        an EMA swap through ``.data``) must be followed by an explicit ``invalidate()``."""
+        an EMA swap through ``.data``, or REPLACING a Parameter object of a sub-module by assignment -- the polled tensor
+        list is collected once per packed engine; ``load_state_dict`` (also with ``assign=True``) and ``.to()`` do reset it)
+        must be followed by an explicit ``invalidate()``."""
         self._engine = None
         self._runners = {}
         self._engine_version = None
@@ -186,9 +189,15 @@ class Pipeline(nn.Module):
                                            "capturable -- pass proj_matrices as CPU tensors, or use eager mode")
                     from .engine import GraphedRunner
                     key = (tuple(x.shape), x.device.index, host_composed)
-                    runner = self._runners.get(key)
+                    runner = self._runners.pop(key, None)
                     if runner is None:
-                        runner = self._runners[key] = GraphedRunner(self._engine, x.float(), projs, depth_min, depth_max, composed=composed)
+                        # one captured graph + static inputs + private workspace per input shape (hundreds of MB at
+                        # 1920x1280): keep the ``max_runners`` most recently used shapes, drop the others (their
+                        # finalizers free the workspaces) -- a dataset with many image sizes must not grow without bound
+                        while len(self._runners) >= max(1, int(self.max_runners)):
+                            self._runners.pop(next(iter(self._runners)))
+                        runner = GraphedRunner(self._engine, x.float(), projs, depth_min, depth_max, composed=composed)
+                    self._runners[key] = runner            # (re-)inserted last: dict order = least recently used first
                     depth_up, conf_up = runner(x.float(), composed if host_composed else projs, depth_min, depth_max)
                 elif host_composed:
                     depth_up, conf_up = self._engine.run(x.float(), None, depth_min, depth_max,

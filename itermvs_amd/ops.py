@@ -315,8 +315,18 @@ class _FeatGradSink(torch.autograd.Function):
 
 def feature_grad_sink(pool: FeatureGradPool, feats: Dict[int, Tensor]) -> Dict[int, Tensor]:
     """route the feature gradients of every fused correlation call given ``pool=`` through ``pool`` (see FeatureGradPool)"""
+    pool.acc.clear()            # a new forward: accumulators a previous (partial or failed) backward left behind are not its
     f1, f2, f3 = _FeatGradSink.apply(pool, feats[1], feats[2], feats[3])
+    for t in (f1, f2, f3):
+        t._itermvs_sink_pool = pool        # corr_*_train(pool=...) accepts only these tensors (_check_sink)
     return {1: f1, 2: f2, 3: f3}
+
+
+def _check_sink(pool: Optional["FeatureGradPool"], feats: Sequence[Tensor], what: str) -> None:
+    """``pool=`` routes the feature gradient through the pool instead of returning it: that is only sound when the features
+    ARE the outputs of ``feature_grad_sink(pool, ...)`` -- otherwise the gradient would be dropped silently"""
+    if pool is not None and any(getattr(t, "_itermvs_sink_pool", None) is not pool for t in feats):
+        raise RuntimeError(f"{what}: pool= needs the feature tensors returned by feature_grad_sink(pool, ...)")
 
 
 class _CorrIterFn(torch.autograd.Function):
@@ -369,6 +379,7 @@ def corr_iter_train(feats: Dict[int, Tensor], b: int, v: int, ref_q: Tensor, pro
     views) and ``ref_q`` [B,H,W,96] (gradient) -> three [B,N_l,8,H,W] tensors.  ``stored[l]``: the 16-bit copies the kernels
     gather from (feature storage bf16 / fp16); default: ``feats`` themselves.  ``pool``: ``feats`` are the outputs of
     ``feature_grad_sink(pool, ...)`` and their gradient is accumulated there instead of being returned to autograd per call."""
+    _check_sink(pool, [feats[l] for l in (1, 2, 3)], "corr_iter_train")
     f = [_need_cl(_dev(feats[l], f"feature level {l}"), f"feature level {l}") for l in (1, 2, 3)]
     st = f if stored is None else [_need_cl(stored[l].detach(), f"stored feature level {l}") for l in (1, 2, 3)]
     if any(a.shape != c.shape for a, c in zip(f, st)):
@@ -425,6 +436,7 @@ def corr_init_train(f3: Tensor, b: int, v: int, proj: Tensor, inv_min: Tensor, i
                     stored: Optional[Tensor] = None, pool: Optional[FeatureGradPool] = None) -> Tensor:
     """differentiable itermvs_corr_init on the dense channels-last fp32 level-3 features [B*V,48,H,W]: -> [B,S,N,8,H,W];
     ``stored``: the bf16 / fp16 copy the kernel reads (16-bit feature storage), default ``f3`` itself"""
+    _check_sink(pool, [f3], "corr_init_train")
     f3 = _need_cl(_dev(f3, "feature level 3"), "feature level 3")
     s3 = f3 if stored is None else _need_cl(stored.detach(), "stored feature level 3")
     return _CorrInitFn.apply(f3, _dev(proj, "proj").contiguous(), inv_min, inv_max, num_samples, b, v, s3, pool)

@@ -43,7 +43,9 @@ def init_distributed(backend: str = None, force: bool = False) -> Tuple[int, int
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # ITERMVS_DIST_BACKEND=gloo: several ranks may then share one GPU (RCCL wants a device per rank) -- how the
+            # world > 1 path of bench.py / train.py is exercised on a 1-GPU box (tests/test_rccl_gpu.py)
+            backend = os.environ.get("ITERMVS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)           # RCCL binds the communicator to the current device
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -79,15 +81,39 @@ def timed_regions(step: Callable[[int], None], steps: int, warmup: int, repeats:
     for i in range(warmup):
         step(i)
     out, base = [], warmup
+    _LOCAL_REGIONS.clear()
     for _ in range(max(1, repeats)):
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
             step(base + i)
-        barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()                    # this rank's own work is done ...
+        local = time.perf_counter() - t0
+        barrier()                                       # ... the region ends when every rank's is
+        _LOCAL_REGIONS.append(local)
         out.append(max_over_ranks(time.perf_counter() - t0))
         base += steps
     return out
+
+
+_LOCAL_REGIONS: List[float] = []
+
+
+def last_local_regions() -> List[float]:
+    """THIS rank's elapsed seconds of the regions of the last ``timed_regions`` call (before the max over ranks)"""
+    return list(_LOCAL_REGIONS)
+
+
+def gather_over_ranks(value: float) -> List[float]:
+    """``value`` of every rank, in rank order, on every rank (one all-gather of a double)"""
+    if dist.is_available() and dist.is_initialized():
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+    return [value]
 
 
 def median(values: Sequence[float]) -> float:

@@ -105,3 +105,17 @@ def test_flat_gradient_allreduce_two_ranks():
         mean = (res[0][2][i] + res[1][2][i]) / 2
         assert torch.allclose(res[0][3][i], mean) and torch.allclose(res[1][3][i], mean)
     assert res[0][4] == res[1][4] == 5 * 3 + 3 and res[0][5] is None             # one bucket, unused parameter skipped
+
+
+def test_synthetic_batch_seeds_stay_in_range_for_validation_steps_at_scale():
+    """train.py's validation uses steps from 10_000_019 on: with train_dtu.sh's --batch_size 4, or 8 ranks, the scene seed
+    used to exceed numpy's 2**32 limit and crash at the end of epoch 0"""
+    import argparse
+    import train
+    args = argparse.Namespace(batch_size=4, n_views=3, img_wh=[64, 64])
+    imgs, projs, dmin, dmax, gt, mask = train.synthetic_batch(args, 10_000_019, 7, "cpu", world=8)
+    assert imgs["level_0"].shape == (4, 3, 3, 64, 64) and gt["level_0"].shape == (4, 1, 64, 64)
+    args.batch_size = 1
+    a = train.synthetic_batch(args, 10_000_020, 7, "cpu", world=8)
+    b = train.synthetic_batch(args, 10_000_020, 6, "cpu", world=8)
+    assert not torch.equal(a[0]["level_0"], b[0]["level_0"])          # ranks still see different scenes

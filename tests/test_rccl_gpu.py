@@ -66,3 +66,28 @@ def test_bench_self_launch_under_torch_distributed_run_with_one_rank():
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["steps"] == 2
     assert line["config"]["process_group"] == "nccl"
+
+
+def test_bench_with_two_ranks_sharing_one_gpu_over_gloo():
+    """bench.py's OWN world > 1 path -- rank-local samples, barrier-bracketed regions, max over ranks, `world * steps * batch /
+    elapsed`, ONE JSON line from rank 0, per-rank spread -- executed before the first 8-GPU box does it: two ranks under
+    torch.distributed.run share cuda:0, the process group is gloo (ITERMVS_DIST_BACKEND; RCCL wants a device per rank)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    args = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2", "--minimal",
+            "--height", "128", "--width", "160", "--views", "3", "--iters", "2"]
+    cmd = bench.self_launch_command(2, args)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ITERMVS_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                   # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["process_group"] == "gloo" and "x2" in line["config"]["parallelism"]
+    # whole-job aggregate: both ranks' depth maps over the slowest rank's clock
+    assert abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
+    spread = line["ms_per_step_ranks"]
+    assert 0 < spread["min"] <= spread["max"] <= line["ms_per_step_max"] * 1.001
+    assert line["roofline"] is not None and line["roofline"]["launches_timed"] > 0

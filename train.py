@@ -64,7 +64,9 @@ def parse_lrepochs(spec: str):
 
 def synthetic_batch(args, step: int, rank: int, dev, world: int = 1):
     """``--batch_size`` samples per GPU (train.py:89-90; train_dtu.sh: 4), every (step, rank, slot) a different scene."""
-    seed = ((step * world + rank) * args.batch_size) * 131
+    # np.random.RandomState (synthetic._texture) takes seeds below 2**32: validation steps start at 10_000_019, which times
+    # world * batch_size * 131 leaves that range from world * batch_size >= 4 on -- wrap (the slots of a batch add < 4096)
+    seed = (((step * world + rank) * args.batch_size) * 131) % (2 ** 32 - 4096)
     imgs, projs, dmin, dmax, gt, mask = synthetic.make_training_batch(
         args.batch_size, num_views=args.n_views, height=args.img_wh[1], width=args.img_wh[0], seed=seed)
     to = lambda d: {k: v.to(dev) for k, v in d.items()}  # noqa: E731
