@@ -43,6 +43,16 @@ def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int, e: int = 4
     return impl(s, h, w, batch, iters, e)
 
 
+def _round_floats(x, digits: int = 6):
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _round_floats(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round_floats(v, digits) for v in x]
+    return x
+
+
 def workload_name(views: int, height: int, width: int, iters: int) -> str:
     """which BASELINE.json config the shape is (the bench line must name what actually ran)"""
     key = (views, height, width, iters)
@@ -116,7 +126,7 @@ def transfers_leg(args, dev, samples, world, u8: bool = False, in_flight: int = 
     m = Pipeline(iteration=args.iters, test=True)
     m.load_state_dict(synthetic.random_state_dict(0))
     m = m.to(dev).eval()
-    eng = InferenceEngine(m.weights(), args.iters, args.feature_dtype)
+    eng = InferenceEngine(m.weights(), args.iters, args.feature_dtype, conv_arithmetic=args.conv_arithmetic)
     imgs0, projs0, dmin0, dmax0 = samples[0]
     pj = {l: projs0[f"level_{l}"].float() for l in (1, 2, 3)}
     nr = in_flight + 1
@@ -210,6 +220,9 @@ def main() -> None:
                     help="host_fp32: the cameras stay on the host and src @ inverse(ref) is composed there in fp32 like module.py:77-90 "
                          "(the reference's tap indices on this host), per step, inside the timed region; the graphs read the composed "
                          "matrices from a static buffer refreshed through pinned memory")
+    ap.add_argument("--conv-arithmetic", default="bf16x3", choices=["bf16x3", "fp32"],
+                    help="3x3 convolutions with more than 8 input channels: exact three-term bf16 split on the bf16 MFMA (default) or the "
+                         "exact fp32 MFMA (A/B on one box)")
     ap.add_argument("--repeats", type=int, default=9,
                     help="the --steps long timed region (barrier + device synchronise on both sides) is run this many times back "
                          "to back; `value` / `ms_per_step` are the MEDIAN region, min / max are reported beside them")
@@ -260,6 +273,7 @@ def main() -> None:
         m.use_graphs = not args.eager
         m.feature_dtype = args.feature_dtype
         m.projection = args.projection
+        m.conv_arithmetic = args.conv_arithmetic
         models.append(m.to(dev).eval())
         streams.append(torch.cuda.Stream(device=dev) if args.streams > 1 else torch.cuda.current_stream(dev))
     model = models[0]
@@ -316,7 +330,8 @@ def main() -> None:
                 from itermvs_amd.engine import InferenceEngine
                 # runner 0 brackets the corr_iter launch of GRU iteration 0, runner 1 that of iteration 2 and the corr_init launch,
                 # runners 2 and 3 carry no timing nodes at all (a bracket costs ~5 us of graph time)
-                models[k]._engine = InferenceEngine(models[k].weights(), models[k].iteration, args.feature_dtype, args.projection)
+                models[k]._engine = InferenceEngine(models[k].weights(), models[k].iteration, args.feature_dtype, args.projection,
+                                                    args.conv_arithmetic)
                 models[k]._engine_version = models[k]._weights_version()      # (the engine belongs to the current weights)
                 models[k]._engine.profile_iterations = {0} if k == 0 else ({min(2, args.iters - 1)} if k == 1 else set())
                 models[k]._engine.profile_init = (k == 1)
@@ -406,6 +421,7 @@ def main() -> None:
             m.load_state_dict(synthetic.random_state_dict(0))
             m.use_graphs = True
             m.feature_dtype = args.feature_dtype
+            m.conv_arithmetic = args.conv_arithmetic
             pm.append(m.to(dev).eval())
             pstreams.append(torch.cuda.Stream(device=dev))
         for k in range(ns):
@@ -445,6 +461,7 @@ def main() -> None:
         ops.CONV_FLOP_COUNTER.update(enabled=True, flops=0.0, launches=0)
         eager_model = Pipeline(iteration=args.iters, test=True)
         eager_model.feature_dtype = args.feature_dtype
+        eager_model.conv_arithmetic = args.conv_arithmetic
         eager_model.load_state_dict(synthetic.random_state_dict(0))
         eager_model = eager_model.to(dev).eval()
         eager_model(*samples[0])                       # warm-up (not timed: profiling collects below)
@@ -512,7 +529,7 @@ def main() -> None:
                        "batch_per_gpu": args.batch, "streams_per_gpu": args.streams, "feature_dtype": args.feature_dtype,
                        "launch": "eager" if args.eager else "one hipGraph per depth map",
                        "parallelism": f"ref-view sharding x{world}, no collective",
-                       "projection": args.projection,
+                       "projection": args.projection, "conv_arithmetic": args.conv_arithmetic,
                        "process_group": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                        "algorithmic_MB_per_depth_map": b_map / 1e6},
             "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms)},   # each rank's own median region (straggler check)
@@ -528,6 +545,10 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
             result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
+        # the driver keeps the tail of stdout: 6 significant digits on everything but the headline numbers keeps the line short
+        keep = {k: result[k] for k in ("value", "ms_per_step")}
+        result = _round_floats(result)
+        result.update(keep)
         print(json.dumps(result), flush=True)
     shard.barrier()
     if world > 1:

@@ -60,7 +60,8 @@ def fold_batchnorm(w: Mapping[str, Tensor], prefix: str, eps: float = 1e-5) -> T
 class InferenceEngine:
     """Test-mode ``IterMVS.forward`` (itermvs.py:253-329) on hand-written HIP kernels."""
 
-    def __init__(self, weights: Mapping[str, Tensor], iteration: int, feature_dtype: str = "fp32", projection: str = "device_fp64"):
+    def __init__(self, weights: Mapping[str, Tensor], iteration: int, feature_dtype: str = "fp32", projection: str = "device_fp64",
+                 conv_arithmetic: str = "bf16x3"):
         """``projection``: how ``src_proj @ inverse(ref_proj)`` (module.py:77-90) is composed.  "device_fp64" (default): on the
         GPU in fp64, rounded once, inside the launch that packs the reference features -- no host round trip, within 5e-5
         px of any fp32 evaluation.  "host_fp32": on the host with torch in fp32, operation for operation like the reference
@@ -73,7 +74,14 @@ class InferenceEngine:
         differs between CPU BLAS builds and from its own CUDA path.)
         ``feature_dtype``: storage type of the three feature pyramids the correlation kernels gather from -- "fp32"
         (default, the reference's numerics), "bf16" or "fp16" (BASELINE cfg 4 / cfg 5: half the gathered bytes, fp32
-        arithmetic; the output convolutions of FeatureNet round their fp32 results to nearest even)."""
+        arithmetic; the output convolutions of FeatureNet round their fp32 results to nearest even).
+        ``conv_arithmetic``: how the 3x3 convolutions with more than 8 input channels multiply (net.py:36-66, module.py:6-66,
+        itermvs.py:139-164): "bf16x3" (default) = both operands split EXACTLY into three bf16 terms, the six largest cross
+        products accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (csrc/conv_tile3.hip: error of the size of one fp32
+        rounding per product, 2.7x less matrix-pipe time); "fp32" = v_mfma_f32_16x16x4_f32, bit-for-bit an fmaf chain."""
+        if conv_arithmetic not in ("bf16x3", "fp32"):
+            raise ValueError(f"conv_arithmetic must be 'bf16x3' or 'fp32', got {conv_arithmetic!r}")
+        self.split3 = conv_arithmetic == "bf16x3"
         if feature_dtype not in ops.FEATURE_DTYPES:
             raise ValueError(f"feature_dtype must be one of {sorted(ops.FEATURE_DTYPES)}, got {feature_dtype!r}")
         self.feature_dtype = ops.FEATURE_DTYPES[feature_dtype]
@@ -115,7 +123,7 @@ class InferenceEngine:
         w, pk = self.w, self.pk
         # the two layers with almost no contraction to feed a matrix core (3 -> 8 on the full-resolution images,
         # 8 -> 1 at the end of CorrNet) run faster on the one-thread-per-pixel VALU kernel: 31 vs 39 us, 6.7 vs 10.2 us
-        pack = lambda wt: ops.pack_conv_weight(wt) if (wt.shape[1] <= 4 or wt.shape[0] == 1) and wt.shape[2] == 3 else ops.MfmaWeight(wt)
+        pack = lambda wt: ops.pack_conv_weight(wt) if (wt.shape[1] <= 4 or wt.shape[0] == 1) and wt.shape[2] == 3 else ops.MfmaWeight(wt, split3=self.split3)
         for n, (wt, _) in self.cbr.items():
             pk["feature_net." + n] = pack(wt)
         for k, v in w.items():
@@ -153,7 +161,7 @@ class InferenceEngine:
         key = "feature_net." + name + "conv1+downsample"
         if key not in self.pk:
             (w1, b1), (wd, bd) = self.cbr[name + "conv1."], self.cbr[name + "downsample."]
-            self.pk[key] = (ops.MfmaWeight(torch.cat([w1, wd])), torch.cat([b1, bd]).contiguous(), w1.shape[0])
+            self.pk[key] = (ops.MfmaWeight(torch.cat([w1, wd]), split3=self.split3), torch.cat([b1, bd]).contiguous(), w1.shape[0])
         wt, bias, c = self.pk[key]
         n, _, hh, ww = x.shape
         sc = torch.empty((n, c, (hh - 1) // 2 + 1, (ww - 1) // 2 + 1), device=x.device)
