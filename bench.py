@@ -501,12 +501,14 @@ def main() -> None:
                 other[name] = benchmarks.shape_leg(dev, v_, h_, w_, it_, ft_, warmup=5, steps=10)
             except Exception as e:  # noqa: BLE001  (a leg that fails must not take the headline line with it)
                 other[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
-        try:
-            t = benchmarks.train_step_leg(dev, batch=4, feature_dtype="bf16", regress=True, warmup=3, steps=5)
-            t.pop("_step", None)
-            other["train_step_cfg4"] = t
-        except Exception as e:  # noqa: BLE001
-            other["train_step_cfg4"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        for name, graph in (("train_step_cfg4", False), ("train_step_cfg4_graph", True)):      # eager, and the step as one hipGraph
+            try:
+                t = benchmarks.train_step_leg(dev, batch=4, feature_dtype="bf16", regress=True, warmup=3, steps=5, graph=graph)
+                t.pop("_step", None)
+                other[name] = t
+            except Exception as e:  # noqa: BLE001
+                other[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            torch.cuda.empty_cache()
 
     if rank == 0:
         result = {

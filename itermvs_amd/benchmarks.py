@@ -77,18 +77,18 @@ def shape_leg(dev, views: int, height: int, width: int, iters: int, feature_dtyp
 
 def train_step_leg(dev, batch: int = 4, views: int = 5, height: int = 512, width: int = 640, iteration: int = 4,
                    feature_dtype: str = "bf16", regress: bool = True, warmup: int = 3, steps: int = 5,
-                   phases: bool = False) -> Dict[str, object]:
+                   phases: bool = False, graph: bool = False) -> Dict[str, object]:
     """BASELINE cfg 4's per-GPU training step (train_dtu.sh: 5 views, 640x512, 4 GRU iterations, ``batch`` per GPU, Adam +
     gradient clip 2.0; reference train.py:194-243): forward (training graph on the fused correlation kernels), full_loss,
     backward, flat gradient all-reduce (a no-op on one rank), clip, Adam -- ``train.train_step`` without its two host
-    read-backs inside the timed region."""
+    read-backs inside the timed region.  ``graph``: the same step replayed as ONE hipGraph (train_step.CapturedTrainStep)."""
     from . import ddp, synthetic
     from .net import Pipeline, full_loss
     torch.manual_seed(1)
     model = Pipeline(iteration=iteration, test=False).to(dev)
     model.feature_dtype = feature_dtype
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    opt = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-3, device=dev) if graph else 1e-3, betas=(0.9, 0.999), capturable=graph)
     imgs, projs, dmin, dmax, gt, mask = synthetic.make_training_batch(batch, num_views=views, height=height, width=width)
     to = lambda d: {k: v.to(dev) for k, v in d.items()}  # noqa: E731
     imgs, projs, gt, mask, dmin, dmax = to(imgs), to(projs), to(gt), to(mask), dmin.to(dev), dmax.to(dev)
@@ -107,8 +107,17 @@ def train_step_leg(dev, batch: int = 4, views: int = 5, height: int = 512, width
         opt.step()
         return loss
 
-    for _ in range(warmup):
-        loss = step()
+    if graph:
+        from .train_step import CapturedTrainStep
+        cap = CapturedTrainStep(model, opt, regress, clip=2.0, warmup=max(1, warmup))
+        the_batch = (imgs, projs, dmin, dmax, gt, mask)
+        step = lambda: cap.step(the_batch)[0]  # noqa: E731
+        for _ in range(max(1, warmup) + 2):     # the eager warm-up steps, the capture, one replay
+            loss = step()
+        cap.check()
+    else:
+        for _ in range(warmup):
+            loss = step()
     torch.cuda.synchronize(dev)
     torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
@@ -117,7 +126,7 @@ def train_step_leg(dev, batch: int = 4, views: int = 5, height: int = 512, width
     torch.cuda.synchronize(dev)
     ms = (time.perf_counter() - t0) * 1e3 / steps
     res = {"ms_per_step": ms, "samples_per_s": batch * 1e3 / ms, "batch": batch, "views": views, "wh": [width, height],
-           "iteration": iteration, "feature_dtype": feature_dtype, "regress": regress, "steps": steps, "warmup": warmup,
+           "iteration": iteration, "feature_dtype": feature_dtype, "regress": regress, "steps": steps, "warmup": warmup, "graph": graph,
            "loss": float(loss.detach()), "peak_mem_MiB": torch.cuda.max_memory_allocated(dev) / 2 ** 20}
     if phases:
         ph = {"forward": 0.0, "backward": 0.0, "clip+adam": 0.0}

@@ -145,7 +145,11 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
 template <int TILE, int FT>
 __global__ void __launch_bounds__(kThreads) corr_iter_kernel(const IterArgs a) {
     __shared__ float lds[ITERMVS_MAX_HYP * ITERMVS_GROUPS * (TILE + 1)];
+#ifdef ITERMVS_ITER_ORDER       // A/B builds: dispatch order of the levels (heaviest first shortens the tail of the 1 920-workgroup launch?)
+    const int lvl = (ITERMVS_ITER_ORDER >> (4 * blockIdx.y)) & 3;
+#else
     const int lvl = blockIdx.y;
+#endif
     const IterLevel& L = a.lv[lvl];
     switch (L.C) {
         case 16: corr_iter_level<2, TILE, FT>(a, L, lvl, lds); break;

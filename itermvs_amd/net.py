@@ -87,6 +87,10 @@ class Pipeline(nn.Module):
         # after the launches are enqueued); the graph mode never stalls the host: call check_projection_finite() when the
         # outputs are fetched (eval.py does, per batch).  None = follow that default.
         self.check_nan = None
+        # training mode: a device int32[1] tensor here defers the same asserts (OR-ed with 1 by a forward that composed a NaN
+        # projection) instead of reading the flag back inside every forward -- no host synchronisation, capturable
+        # (train_step.CapturedTrainStep sets and checks it)
+        self.train_nan_flag = None
         # storage type of the feature pyramids the correlation kernels gather from, in test AND train mode: "fp32" (reference
         # numerics), "bf16" / "fp16" (BASELINE cfg 4 / 5: half the gathered bytes, fp32 arithmetic, fp32 gradients); set before
         # the first forward (or call invalidate())
@@ -212,7 +216,7 @@ class Pipeline(nn.Module):
             return {"depths_upsampled": depth_up, "confidence_upsampled": conf_up}
         from .train_graph import train_forward
         return train_forward(self.weights(), x.float(), projs, depth_min, depth_max, self.iteration,
-                             bn_training=self.training, feature_dtype=self.feature_dtype)
+                             bn_training=self.training, feature_dtype=self.feature_dtype, nan_flag=self.train_nan_flag)
 
 
 def full_loss(depths, depths_upsampled, confidences, depths_gt, mask, depth_min, depth_max, regress=True):

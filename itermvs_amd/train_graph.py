@@ -148,11 +148,16 @@ def _convex_upsample(nd: Tensor, weight: Tensor) -> Tensor:
 
 
 def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor], depth_min: Tensor,
-                  depth_max: Tensor, iteration: int, bn_training: bool = True, feature_dtype: str = "fp32"):
+                  depth_max: Tensor, iteration: int, bn_training: bool = True, feature_dtype: str = "fp32",
+                  nan_flag: Tensor = None):
     """``Pipeline(test=False).forward``: returns the reference's training dict (net.py:115-120).
     ``feature_dtype`` "bf16" / "fp16" (BASELINE cfg 4: bf16): the three pyramids are STORED in 16 bits for the fused
     correlation kernels (forward and backward gather half the bytes, fp32 arithmetic), exactly like test mode's
-    ``Pipeline.feature_dtype``; the rounding is straight-through for autograd (fp32 gradients, fp32 weights)."""
+    ``Pipeline.feature_dtype``; the rounding is straight-through for autograd (fp32 gradients, fp32 weights).
+    ``nan_flag`` (device int32[1]): the deferred form of the reference's NaN asserts on the composed projections
+    (module.py:83,87) -- OR-ed with 1 instead of being read back and asserted here, so that the forward issues no
+    device-to-host synchronisation and can be captured (train_step.CapturedTrainStep checks the flag after its replays)."""
+    deferred_nan = nan_flag is not None
     if feature_dtype not in ops.FEATURE_DTYPES:
         raise ValueError(f"feature_dtype must be one of {sorted(ops.FEATURE_DTYPES)}, got {feature_dtype!r}")
     store_dt = ops.FEATURE_DTYPES[feature_dtype]
@@ -171,7 +176,8 @@ def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor
     pool = ops.FeatureGradPool()
     cl = ops.feature_grad_sink(pool, cl)
     ref = {l: cl[l].view(b, v, *cl[l].shape[1:])[:, 0] for l in (1, 2, 3)}
-    nan_flag = torch.zeros((1,), device=imgs.device, dtype=torch.int32)
+    if nan_flag is None:
+        nan_flag = torch.zeros((1,), device=imgs.device, dtype=torch.int32)
     with torch.no_grad():
         proj = ops.compose_proj(torch.stack([projs[1], projs[2], projs[3]]).reshape(3 * b, v, 4, 4), nan_flag).view(3, b, s, 12)
     h, wd = feats[2].shape[2:]
@@ -232,15 +238,28 @@ def train_forward(w: Mapping[str, Tensor], imgs: Tensor, projs: Dict[int, Tensor
             conf_up = F.interpolate(torch.sigmoid(conf0), scale_factor=4, mode="bilinear")
         nd = nd.detach()
     # module.py:83,87: the reference asserts inside every warp; here once per forward, after everything is enqueued
-    assert int(nan_flag.item()) == 0, "nan in proj (singular or non-finite camera matrix, module.py:83,87)"
+    if not deferred_nan:
+        assert int(nan_flag.item()) == 0, "nan in proj (singular or non-finite camera matrix, module.py:83,87)"
     return {"depths": depths, "depths_upsampled": depths_up, "confidences": confidences,
             "confidence_upsampled": conf_up}
+
+
+def _masked_mean(values: Tensor, m: Tensor, empty_is_zero: bool = False) -> Tensor:
+    """mean of ``values`` over the True entries of ``m`` without boolean indexing: fixed shapes, no device-to-host
+    synchronisation (``x[mask]`` sizes its result on the host), so the loss can be captured into a hipGraph.  An empty
+    selection gives NaN like ``x[mask].mean()`` unless ``empty_is_zero`` (the reference's ``if torch.sum(mask_new) > 0``)."""
+    mf = m.to(values.dtype)
+    cnt = mf.sum()
+    total = (torch.where(m, values, torch.zeros_like(values))).sum()
+    return total / (torch.clamp(cnt, min=1.0) if empty_is_zero else cnt)
 
 
 def full_loss(depths, depths_upsampled, confidences, depths_gt, mask, depth_min, depth_max, regress=True):
     """models/net.py:131-190: cross-entropy on the 256-bin probabilities (one-hot GT bin), L1 on the
     normalised initial / windowed per-iteration / up-sampled depths, BCE on the confidence logits;
-    iteration k of n weighted by 0.8^(n-k-1)."""
+    iteration k of n weighted by 0.8^(n-k-1).  Every ``x[mask].mean()`` of the reference is a masked sum over a count here
+    (``_masked_mean``): same value up to the order of the summation, no host synchronisation -- the whole training step
+    (``train_step.CapturedTrainStep``) replays as one hipGraph."""
     probs = depths["probability"]
     bins = probs[0].size(1)
     m_full = mask["level_0"] > 0.5
@@ -254,20 +273,18 @@ def full_loss(depths, depths_upsampled, confidences, depths_gt, mask, depth_min,
     target = torch.zeros_like(probs[0]).scatter_(1, gt_bin, 1)
 
     n = len(depths["combine"])
-    total = (0.8 ** n) * BINS * F.l1_loss(_norm(depths["initial"][0], inv_min, inv_max)[m_q], ngt[m_q])
+    total = (0.8 ** n) * BINS * _masked_mean((_norm(depths["initial"][0], inv_min, inv_max) - ngt).abs(), m_q)
     for k in range(n):
         coff = 0.8 ** (n - k - 1)
         p = torch.clamp(probs[k], min=1e-5)
-        total = total + coff * (-(target * torch.log(p)).sum(1, keepdim=True))[m_q].mean()
+        total = total + coff * _masked_mean(-(target * torch.log(p)).sum(1, keepdim=True), m_q)
         if regress:
             with torch.no_grad():
                 best = torch.argmax(p, dim=1, keepdim=True).float()
                 near = (gt_bin >= best - RADIUS) & (gt_bin <= best + RADIUS)
             nd = _norm(depths["combine"][k], inv_min, inv_max)
-            sel = m_q & near
-            if sel.sum() > 0:
-                total = total + coff * BINS * F.l1_loss(nd[sel], ngt[sel])
-            conf_gt = (torch.abs(nd[m_q].detach() - ngt[m_q]) < 0.002).float()
-            total = total + coff * F.binary_cross_entropy_with_logits(confidences[k][m_q], conf_gt)
+            total = total + coff * BINS * _masked_mean((nd - ngt).abs(), m_q & near, empty_is_zero=True)   # net.py:175-176
+            conf_gt = ((nd.detach() - ngt).abs() < 0.002).float()
+            total = total + coff * _masked_mean(F.binary_cross_entropy_with_logits(confidences[k], conf_gt, reduction="none"), m_q)
     ngt_full = _norm(gt_full, inv_min, inv_max)
-    return total + BINS * F.l1_loss(_norm(depths_upsampled[0], inv_min, inv_max)[m_full], ngt_full[m_full])
+    return total + BINS * _masked_mean((_norm(depths_upsampled[0], inv_min, inv_max) - ngt_full).abs(), m_full)

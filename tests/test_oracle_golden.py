@@ -308,3 +308,35 @@ def test_train_step_cfg4_batch2(weights_seed0):
     d = out["depths_upsampled"][0].detach()
     rel = (d[:, :, ::8, ::8] - g["train.depth_sub"]).abs() / g["train.depth_sub"]
     assert float(rel.median()) <= 1e-6 and float((rel > 1e-4).float().mean()) <= 0.02
+
+
+@pytest.mark.parametrize("regress", [True, False])
+def test_product_full_loss_with_masked_sums_equals_the_indexed_form(regress):
+    """itermvs_amd.train_graph.full_loss replaces every ``x[mask].mean()`` of net.py:131-190 by a masked sum over a count (fixed
+    shapes, no host synchronisation: the training step can be captured).  Pure torch, so it is held HERE against the pinned
+    oracle's literal restatement: loss and gradients, incl. a batch whose windowed selection is EMPTY (net.py:175 skips it)."""
+    from itermvs_amd import train_graph as T
+    torch.manual_seed(0)
+    b, h, w, n = 2, 8, 10, 3
+    for spread in (300.0, 3.0):           # 300 mm off: no prediction inside the +-4-bin window -> the empty selection
+        probs = [torch.softmax(torch.randn(b, 256, h, w), 1).requires_grad_(True) for _ in range(n)]
+        dmin, dmax = torch.tensor([425.0, 430.0]), torch.tensor([935.0, 900.0])
+        gt_q, gt_f = 425 + torch.rand(b, 1, h, w) * 500, 425 + torch.rand(b, 1, 4 * h, 4 * w) * 500
+        comb = [(gt_q + torch.randn(b, 1, h, w) * spread).requires_grad_(True) for _ in range(n)]
+        init = [(gt_q + torch.randn(b, 1, h, w) * 30).requires_grad_(True)]
+        up = [(gt_f + torch.randn(b, 1, 4 * h, 4 * w) * 5).requires_grad_(True)]
+        confs = [torch.randn(b, 1, h, w).requires_grad_(True) for _ in range(n)]
+        mask = {"level_0": (torch.rand(b, 1, 4 * h, 4 * w) > 0.2).float(), "level_2": (torch.rand(b, 1, h, w) > 0.2).float()}
+        gt = {"level_0": gt_f, "level_2": gt_q}
+        d = {"probability": probs, "combine": comb, "initial": init}
+        got = T.full_loss(d, up, confs, gt, mask, dmin, dmax, regress)
+        want = O.full_loss(d, up, confs, gt, mask, dmin, dmax, regress)
+        assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
+        wrt = [probs[0], comb[1], up[0], init[0]] + ([confs[2]] if regress else [])
+        for a, r in zip(torch.autograd.grad(got, wrt, allow_unused=True), torch.autograd.grad(want, wrt, allow_unused=True)):
+            assert (a is None) == (r is None)
+            if a is not None:
+                assert float((a - r).abs().max()) <= 1e-6 * float(r.abs().max() + 1e-12)
+    # an empty level-2 mask is NaN in both forms (mean over nothing), not silently zero
+    mask["level_2"].zero_()
+    assert torch.isnan(T.full_loss(d, up, confs, gt, mask, dmin, dmax, regress)) and torch.isnan(O.full_loss(d, up, confs, gt, mask, dmin, dmax, regress))

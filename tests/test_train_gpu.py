@@ -272,3 +272,53 @@ def test_two_rank_training_step_on_one_gpu(feature_dtype):
         assert not torch.equal(l0[name], l1[name]) or float(l0[name].abs().max()) == 0.0, name   # the ranks really saw different data
         checked += 1
     assert checked >= 95
+
+
+def test_captured_training_step_equals_the_eager_step():
+    """train_step.CapturedTrainStep (forward + full_loss + backward + clip + Adam as ONE hipGraph; reference train.py:194-243) against
+    the eager step on the same batches from the same initial weights: the losses of six steps (three eager warm-ups, the
+    capture, two replays on NEW batches copied into the static buffers) and the final parameters."""
+    from itermvs_amd import synthetic
+    from itermvs_amd.net import Pipeline, full_loss
+    from itermvs_amd.train_step import CapturedTrainStep
+    to = lambda d: {k: v.to(DEV) for k, v in d.items()}  # noqa: E731
+    batches = []
+    for i in range(6):
+        imgs, projs, dmin, dmax, gt, mask = synthetic.make_training_batch(2, num_views=3, height=96, width=128, seed=10 * i, hole_fraction=0.1)
+        batches.append((to(imgs), to(projs), dmin.to(DEV), dmax.to(DEV), to(gt), to(mask)))
+
+    def fresh():
+        m = Pipeline(iteration=2, test=False)
+        m.load_state_dict(load_weights("seed0"))
+        return m.to(DEV).train()
+
+    eager, losses_e = fresh(), []
+    # (a small rate: at 1e-3 the random-init network on random scenes leaves the stable regime within five steps -- the loss
+    #  jumps from 95 to 800 -- and two trajectories that differ by Adam's device-side bias correction, 1e-7, drift percent apart)
+    lr = 1e-5
+    opt_e = torch.optim.Adam(eager.parameters(), lr=lr, betas=(0.9, 0.999))
+    for imgs, projs, dmin, dmax, gt, mask in batches:
+        opt_e.zero_grad(set_to_none=True)
+        out = eager(imgs, projs, dmin, dmax)
+        loss = full_loss(out["depths"], out["depths_upsampled"], out["confidences"], gt, mask, dmin, dmax, True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(eager.parameters(), 2.0)
+        opt_e.step()
+        losses_e.append(float(loss))
+
+    graphed = fresh()
+    opt_g = torch.optim.Adam(graphed.parameters(), lr=torch.tensor(lr, device=DEV), betas=(0.9, 0.999), capturable=True)
+    cap = CapturedTrainStep(graphed, opt_g, regress=True, clip=2.0, warmup=3)
+    losses_g = [float(cap.step(bt)[0]) for bt in batches]
+    cap.check()
+    assert cap.graph is not None and cap.calls == 6
+    assert abs(losses_g[0] - losses_e[0]) <= 1e-5 * abs(losses_e[0])
+    for a, b in zip(losses_g, losses_e):
+        assert abs(a - b) <= 2e-3 * abs(b), (losses_g, losses_e)
+    w0 = load_weights("seed0")
+    moved = max(float((p.detach().cpu() - w0[name]).abs().max()) for name, p in graphed.named_parameters())
+    worst = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(graphed.parameters(), eager.parameters()))
+    assert 2e-5 <= moved <= 6.1e-5, moved              # six Adam steps of 1e-5 each really happened ...
+    assert worst <= 0.1 * moved, (worst, moved)        # ... and both trajectories took them together
+    with pytest.raises(ValueError):
+        CapturedTrainStep(graphed, torch.optim.Adam(graphed.parameters(), lr=1e-3), regress=True)

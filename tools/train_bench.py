@@ -27,12 +27,13 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--profile", type=int, default=0, help="after the timing: torch.profiler over this many steady-state steps, top kernels by device time")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (train_step.CapturedTrainStep)")
     ap.add_argument("--phases", action="store_true", help="also time forward / backward / optimizer separately (synchronising)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     res = benchmarks.train_step_leg(dev, batch=args.batch, views=args.views, height=args.wh[1], width=args.wh[0], iteration=args.iteration,
                                     feature_dtype=args.feature_dtype, regress=args.regress, warmup=args.warmup, steps=args.steps,
-                                    phases=args.phases)
+                                    phases=args.phases, graph=args.graph)
     step = res.pop("_step")
     res = {"metric": "training step (cfg 4 per-GPU workload)", **res}
     print(json.dumps(res))

@@ -50,6 +50,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--n_views", type=int, default=5)
     p.add_argument("--img_wh", nargs="+", type=int, default=[640, 512])
     p.add_argument("--steps_per_epoch", type=int, default=8, help="synthetic dataset only")
+    p.add_argument("--graph", action="store_true",
+                   help="replay the whole step (forward, loss, backward, all-reduce, clip, Adam) as ONE hipGraph after three eager "
+                        "warm-up steps (itermvs_amd.train_step.CapturedTrainStep): the eager step is launch-bound")
     p.add_argument("--feature_dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
                    help="storage type of the feature pyramids the fused correlation kernels gather from (BASELINE cfg 4: bf16); "
                         "arithmetic, gradients and weights stay fp32")
@@ -151,7 +154,10 @@ def main() -> None:
     dev = torch.device("cuda", local_rank)
     model = Pipeline(iteration=args.iteration, test=False).to(dev)
     model.feature_dtype = args.feature_dtype
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, betas=(0.9, 0.999), weight_decay=args.wd)  # train.py:98
+    # train.py:98.  --graph: Adam's step counter and the learning rate live on the device (capturable; MultiStepLR fills the
+    # rate tensor in place)
+    optimizer = torch.optim.Adam(model.parameters(), lr=torch.tensor(args.lr, device=dev) if args.graph else args.lr, betas=(0.9, 0.999),
+                                 weight_decay=args.wd, capturable=args.graph)
     start_epoch = 0
     ckpt = latest_checkpoint(args.logdir) if args.resume else args.loadckpt
     if ckpt:
@@ -171,11 +177,19 @@ def main() -> None:
             print("final", means)
         shard.barrier()
         return
+    captured = None
+    if args.graph:
+        from itermvs_amd.train_step import CapturedTrainStep
+        captured = CapturedTrainStep(model, optimizer, args.regress, clip=GRAD_CLIP)
     for epoch in range(start_epoch, args.epochs):
         for step in range(args.steps_per_epoch):
             t0 = time.time()
-            loss, err = train_step(model, optimizer, synthetic_batch(args, epoch * args.steps_per_epoch + step, rank, dev, world),
-                                   args.regress)
+            batch = synthetic_batch(args, epoch * args.steps_per_epoch + step, rank, dev, world)
+            if captured is not None:
+                loss, err = (float(t) for t in captured.step(batch))
+                captured.check()
+            else:
+                loss, err = train_step(model, optimizer, batch, args.regress)
             if rank == 0 and step % args.summary_freq == 0:
                 print("Epoch {}/{}, Iter {}/{}, train loss = {:.3f}, abs depth error = {:.3f} mm, time = {:.3f}".format(
                     epoch, args.epochs, step, args.steps_per_epoch, loss, err, time.time() - t0))
