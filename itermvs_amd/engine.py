@@ -25,6 +25,7 @@ CorrNet inputs); ``run`` is their composition, the teacher-forced parity tests d
 """
 from __future__ import annotations
 
+import gc
 import itertools
 import weakref
 from typing import Dict, List, Mapping, Tuple
@@ -106,6 +107,7 @@ class InferenceEngine:
         self.b_zr = torch.cat([w[g + "convz.bias"], w[g + "convr.bias"]], 0).contiguous()
         self.offsets = sample_offsets()
         self._ws: Dict[tuple, dict] = {}
+        self._released: list = []                    # workspaces of dropped runners, parked until their last replay is done
         self._ws_owner = None
         self._owner_tokens = itertools.count(1)      # never reused, unlike id(): a new runner cannot alias an old workspace
         # OR-ed with 1 by itermvs_compose_proj when a composed projection is NaN (module.py:83,87 assert on the host);
@@ -219,6 +221,7 @@ class InferenceEngine:
         # one workspace per (shape, owner): eager calls share the engine's; every GraphedRunner captures onto its OWN
         # (``_ws_owner`` is set while a runner warms up / captures), so runners replayed on different streams never
         # share GRU buffers
+        self._purge_released()
         key = (b, h, w, self._ws_owner)
         ws = self._ws.get(key)
         if ws is None:
@@ -245,18 +248,37 @@ class InferenceEngine:
         return ws
 
     def _release_owner(self, token: int) -> None:
-        """drop the private workspaces of a GraphedRunner that went away (its finalizer calls this).  The buffers were allocated
-        on the runner's capture stream while its graph replays on the callers' streams: a replay may still be writing them, so
-        the device is drained before the caching allocator may hand the blocks to anyone else (a rare event: a runner is
-        dropped when its shape leaves the LRU cache of ``Pipeline`` or the weights change)"""
+        """drop the private workspaces of a GraphedRunner that went away (its finalizer calls this -- from the garbage collector,
+        i.e. at ANY point, also in the middle of another runner's stream capture, where every synchronising or recording HIP
+        call is illegal and invalidates that capture).  The buffers were allocated on the runner's capture stream while its graph
+        replays on the callers' streams, so a replay may still be writing them: they are parked, and handed back to the caching
+        allocator by ``_purge_released`` once an event recorded AFTER the drop has completed."""
         keys = [k for k in self._ws if k[3] == token]
-        if keys:
-            try:
-                torch.cuda.synchronize(self.device)
-            except Exception:      # interpreter shutdown: the context may already be gone
-                pass
-        for key in keys:
-            del self._ws[key]
+        if not keys:
+            return
+        parked = [self._ws.pop(k) for k in keys]
+        ev = None
+        try:
+            if not torch.cuda.is_current_stream_capturing():
+                ev = torch.cuda.Event()
+                ev.record()                      # everything enqueued so far on the stream that replayed
+        except Exception:                        # interpreter shutdown: the context may already be gone
+            ev = None
+        self._released.append((parked, ev))
+
+    def _purge_released(self) -> None:
+        """free parked workspaces whose guarding event has completed (called where no capture is in progress)"""
+        if not self._released or torch.cuda.is_current_stream_capturing():
+            return
+        keep = []
+        for parked, ev in self._released:
+            if ev is None:                       # dropped during a capture: guard it now, free it at a later purge
+                ev = torch.cuda.Event()
+                ev.record()
+                keep.append((parked, ev))
+            elif not ev.query():
+                keep.append((parked, ev))
+        self._released = keep
 
     # -- stages (each reads / writes the workspace; see the module docstring) ---------------------
     def stage_init(self, ws: dict, src3: List[Tensor], ref3: Tensor, proj3: Tensor, inv_min: Tensor, inv_max: Tensor,
@@ -478,9 +500,18 @@ class GraphedRunner:
                 torch.cuda.synchronize(imgs.device)
                 first = ops.profile_graph_count()
                 self.graph = torch.cuda.CUDAGraph()
-                self.graph.capture_begin()
-                self.out = engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max, composed=self.composed)
-                self.graph.capture_end()
+                # finalizers of dropped runners / graphs must not run in the middle of the capture (a destroyed hipGraph or any
+                # synchronising call from the collector invalidates it): collect now, keep the collector off until the end
+                gc.collect()
+                gc_was_on = gc.isenabled()
+                gc.disable()
+                try:
+                    self.graph.capture_begin()
+                    self.out = engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max, composed=self.composed)
+                    self.graph.capture_end()
+                finally:
+                    if gc_was_on:
+                        gc.enable()
                 self.profile_pairs = (first, ops.profile_graph_count() - first)
         finally:
             engine._ws_owner = None

@@ -316,9 +316,12 @@ def test_captured_training_step_equals_the_eager_step():
     for a, b in zip(losses_g, losses_e):
         assert abs(a - b) <= 2e-3 * abs(b), (losses_g, losses_e)
     w0 = load_weights("seed0")
-    moved = max(float((p.detach().cpu() - w0[name]).abs().max()) for name, p in graphed.named_parameters())
-    worst = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(graphed.parameters(), eager.parameters()))
-    assert 2e-5 <= moved <= 6.1e-5, moved              # six Adam steps of 1e-5 each really happened ...
-    assert worst <= 0.1 * moved, (worst, moved)        # ... and both trajectories took them together
+    moved = torch.cat([(p.detach().cpu() - w0[name]).abs().reshape(-1) for name, p in graphed.named_parameters()])
+    apart = torch.cat([(p.detach() - q.detach()).abs().reshape(-1).cpu() for p, q in zip(graphed.parameters(), eager.parameters())])
+    assert 2e-5 <= float(moved.max()) <= 6.1e-5, float(moved.max())          # six Adam steps of 1e-5 each really happened ...
+    # ... and both trajectories took them together.  (Adam normalises every update to ~lr: an element whose gradient is rounding
+    # noise may step the other way in one run -- a few elements apart by a step or two, none by the distance travelled)
+    assert float(apart.mean()) <= 0.02 * float(moved.mean()), (float(apart.mean()), float(moved.mean()))
+    assert float(apart.max()) <= 0.5 * float(moved.max()), (float(apart.max()), float(moved.max()))
     with pytest.raises(ValueError):
         CapturedTrainStep(graphed, torch.optim.Adam(graphed.parameters(), lr=1e-3), regress=True)
