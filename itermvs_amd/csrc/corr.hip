@@ -158,6 +158,143 @@ __global__ void __launch_bounds__(kThreads) corr_iter_kernel(const IterArgs a) {
     }
 }
 
+#ifdef ITERMVS_ITER_TWO_PHASE
+// ---------------------------------------------------------------------------------------------
+// MEASURED AND NOT SHIPPED (round 5, profiles/r05/r05t_corr_iter_two_phase.txt): 27.9 / 25.8 us against 24.4 / 21.9 us (noise / smooth
+// depth) at cfg 1, 632 / 463 against 589 / 345 us at the cfg-5 shape.  The barrier-separated phases and the LDS round trip of the
+// footprints cost more than the leaner gather loop wins (108 VGPRs: still 4 waves per SIMD).
+// iteration branch, two-phase form (A/B builds only: -DITERMVS_ITER_TWO_PHASE).  Phase A: one thread per (pixel, hypothesis,
+// view) of a batch of four views computes the projection, the footprint and the view weight and parks them in LDS (36 bytes);
+// phase B: the quads gather -- footprints from LDS (quad-uniform addresses: broadcast reads), no projection code and no DPP
+// traffic in the loop, fewer live registers.  Same arithmetic, same order of the view sum: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+template <int CPG, int TILE, int FT>
+__device__ __forceinline__ void corr_iter2_level(const IterArgs& a, const IterLevel& L, int lvl, float* __restrict__ lds, uint32_t* __restrict__ fpl,
+                                                 float* __restrict__ wl) {
+    using K = Chunk<CPG>;
+    constexpr int LS = TILE + 1;
+    const int N = L.N;
+    const int b = blockIdx.z;
+    const int P = a.H * a.W;
+    constexpr int TW = kIterTW, TH = TILE / kIterTW;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int tile = xcd_tile(tiles_x * tiles_y);
+    if (tile >= tiles_x * tiles_y) return;
+    const int tile_ty = tile / tiles_x, tile_tx = tile - tile_ty * tiles_x;
+    const int x0 = tile_tx * TW, y0 = tile_ty * TH;
+    constexpr int LPT = K::LPT, NGL = K::NG;
+    const WarpGeom g = make_geom(a.W, a.H, L.W1, L.H1);
+    const WarpRcp rc = make_rcp(g);
+    const float inv_min = a.inv_min[b], inv_max = a.inv_max[b];
+    const float* proj = a.proj + ((size_t)(lvl * a.B + b) * a.S) * 12;
+    const uint32_t sy = (uint32_t)L.sy * feat_bytes<FT>(), sx = (uint32_t)L.sx * feat_bytes<FT>();
+    const int per_px = N * LPT;                 // gather items per pixel
+    const int items = TILE * per_px;
+    for (int s0 = 0; s0 < a.S; s0 += 4) {
+        const int nb = min(4, a.S - s0);
+        // ---- phase A: footprints of (pixel, hypothesis, view s0 + v) -> LDS [(px * N + n) * 4 + v][9]
+        const int fitems = TILE * N * 4;
+#pragma unroll 1
+        for (int it = threadIdx.x; it < fitems; it += kThreads) {
+            const int v = it & 3, pn = it >> 2;
+            const int n = pn % N, px = pn / N;
+            const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
+            Footprint f = {0u, 0u, 0u, 0u, 0.0f, 0.0f, 0.0f, 0.0f};
+            float wv = 0.0f;
+            if (v < nb && x < a.W && y < a.H) {
+                const int p = y * a.W + x;
+                const float d = L.depth ? L.depth[((size_t)b * N + n) * P + p] : iter_hypothesis(a.nd[b * a.nd_sb + p], L.offs[n], inv_min, inv_max);
+                const float* m = proj + (s0 + v) * 12;
+                float rx, ry, rz, ix, iy;
+                ray_dir(m, (float)x * g.xr, (float)y * g.yr, rx, ry, rz);
+                project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
+                f = make_footprint(ix, iy, L.W1, L.H1, sy, sx);
+                wv = a.view_w[(int64_t)b * a.vw_sb + (int64_t)(s0 + v) * a.vw_ss + (int64_t)p * a.vw_sp];
+            }
+            uint32_t* o = fpl + it * 9;
+            o[0] = f.r0; o[1] = f.r1; o[2] = f.c0; o[3] = f.c1;
+            o[4] = __float_as_uint(f.nw); o[5] = __float_as_uint(f.ne); o[6] = __float_as_uint(f.sw); o[7] = __float_as_uint(f.se);
+            o[8] = __float_as_uint(wv);
+        }
+        __syncthreads();
+        // ---- phase B: gather; the running sums of an item live in LDS between the batches of views (same thread, same slots)
+#pragma unroll 1
+        for (int item = threadIdx.x; item < items; item += kThreads) {
+            const int px = item / per_px;
+            const int rem = item - px * per_px;
+            const int n = rem / LPT, j = rem - n * LPT;
+            const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
+            if (x >= a.W || y >= a.H) continue;
+            const int p = y * a.W + x;
+            float refv[K::VEC];
+            if constexpr (FT == ITERMVS_F32) load_vec<K::VEC>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff + j * 4, refv);
+            else load_ref16<CPG>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff, j, refv);
+            const uint32_t joff = (uint32_t)(j * 4) * feat_bytes<FT>();
+            const uint32_t* fb = fpl + (size_t)(px * N + n) * 4 * 9;
+            float acc[NGL], wsum = 1e-5f;
+            int slot[NGL];
+#pragma unroll
+            for (int q = 0; q < NGL; ++q) {
+                slot[q] = (n * ITERMVS_GROUPS + (FT == ITERMVS_F32 ? K::group(j, q) : group16<CPG>(j, q))) * LS + px;
+                acc[q] = s0 == 0 ? 0.0f : lds[slot[q]];
+            }
+            if (s0 != 0) wsum = wl[item];
+#pragma unroll 1
+            for (int k = 0; k < nb; ++k) {
+                const uint32_t* o = fb + k * 9;
+                Footprint tp;
+                tp.r0 = o[0]; tp.r1 = o[1]; tp.c0 = o[2]; tp.c1 = o[3];
+                tp.nw = __uint_as_float(o[4]); tp.ne = __uint_as_float(o[5]); tp.sw = __uint_as_float(o[6]); tp.se = __uint_as_float(o[7]);
+                const float wv = __uint_as_float(o[8]);
+                float corr[NGL];
+                if constexpr (FT == ITERMVS_F32) chunk_corr<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), joff, tp, refv, corr);
+                else chunk_corr16<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), j, tp, refv, corr);
+#pragma unroll
+                for (int q = 0; q < NGL; ++q) acc[q] = acc[q] + corr[q] * wv;
+                wsum = wsum + wv;
+            }
+            const bool last = s0 + 4 >= a.S;
+#pragma unroll
+            for (int q = 0; q < NGL; ++q) lds[slot[q]] = last ? acc[q] / wsum : acc[q];
+            if (!last) wl[item] = wsum;
+        }
+        __syncthreads();
+    }
+    const int rows = N * ITERMVS_GROUPS;
+    if ((a.W & 3) == 0 && ((uintptr_t)L.out & 15) == 0) {
+        for (int idx = threadIdx.x; idx < rows * (TILE / 4); idx += kThreads) {
+            const int row = idx / (TILE / 4), px = (idx - row * (TILE / 4)) * 4;
+            const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
+            if (x < a.W && y < a.H) {
+                const float* __restrict__ l = lds + row * LS + px;
+                *reinterpret_cast<float4*>(L.out + ((size_t)b * rows + row) * P + (size_t)y * a.W + x) = make_float4(l[0], l[1], l[2], l[3]);
+            }
+        }
+        return;
+    }
+    for (int idx = threadIdx.x; idx < rows * TILE; idx += kThreads) {
+        const int row = idx / TILE, px = idx - row * TILE;
+        const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
+        if (x < a.W && y < a.H) L.out[((size_t)b * rows + row) * P + (size_t)y * a.W + x] = lds[row * LS + px];
+    }
+}
+
+template <int TILE, int FT>
+__global__ void __launch_bounds__(kThreads) corr_iter2_kernel(const IterArgs a, int nmax) {
+    extern __shared__ __attribute__((aligned(16))) float dyn2[];
+    float* lds = dyn2;                                                            // [nmax * 8][TILE + 1]
+    float* wl = lds + nmax * ITERMVS_GROUPS * (TILE + 1);                        // [TILE * nmax * 4]
+    uint32_t* fpl = reinterpret_cast<uint32_t*>(wl + TILE * nmax * 4);            // [TILE * nmax * 4][9]
+    const int lvl = blockIdx.y;
+    const IterLevel& L = a.lv[lvl];
+    switch (L.C) {
+        case 16: corr_iter2_level<2, TILE, FT>(a, L, lvl, lds, fpl, wl); break;
+        case 32: corr_iter2_level<4, TILE, FT>(a, L, lvl, lds, fpl, wl); break;
+        default: corr_iter2_level<6, TILE, FT>(a, L, lvl, lds, fpl, wl); break;
+    }
+}
+#endif  // ITERMVS_ITER_TWO_PHASE
+
 // ---------------------------------------------------------------------------------------------
 // initialisation branch: per-view correlation volume for PixelViewWeight (itermvs.py:48-53)
 // grid = (pixel tiles, S * hypothesis blocks, B)
@@ -860,7 +997,17 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
         switch (dtype) {
             case ITERMVS_F16: hipLaunchKernelGGL((corr_iter_kernel<TILE, ITERMVS_F16>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
             case ITERMVS_BF16: hipLaunchKernelGGL((corr_iter_kernel<TILE, ITERMVS_BF16>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
+#ifdef ITERMVS_ITER_TWO_PHASE
+            default: {
+                int nmax = 1;
+                for (int l = 0; l < 3; ++l) nmax = p->N[l] > nmax ? p->N[l] : nmax;
+                const size_t shm = (size_t)nmax * (ITERMVS_GROUPS * (TILE + 1) + TILE * 4 + TILE * 4 * 9) * 4;
+                hipLaunchKernelGGL((corr_iter2_kernel<TILE, ITERMVS_F32>), grid, dim3(kThreads), shm, (hipStream_t)stream, a, nmax);
+                break;
+            }
+#else
             default: hipLaunchKernelGGL((corr_iter_kernel<TILE, ITERMVS_F32>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
+#endif
         }
     }
     itermvs_profile_end(1, (hipStream_t)stream);
