@@ -55,6 +55,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help="how src_proj @ inverse(ref_proj) (module.py:77-90) is composed: on the GPU in fp64 rounded once (default), or "
                         "on the host in fp32 operation for operation like the reference (tap indices of a reference run on this "
                         "host); the cameras then stay on the host, no synchronisation")
+    p.add_argument("--conv_arithmetic", default="bf16x3", choices=["bf16x3", "fp32"],
+                   help="3x3 convolutions with more than 8 input channels: exact three-term bf16 split of both operands on the bf16 "
+                        "matrix instructions (default, fp32-rounding-class error) or the exact fp32 MFMA (bit-for-bit an fmaf chain)")
     p.add_argument("--feature_dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
                    help="storage type of the feature pyramids (BASELINE cfg 5: fp16); arithmetic stays fp32")
     p.add_argument("--no_graphs", action="store_true",
@@ -127,6 +130,7 @@ def load_model(args, dev) -> Pipeline:
     model = Pipeline(iteration=args.iteration, test=True)
     model.feature_dtype = getattr(args, "feature_dtype", "fp32")
     model.projection = getattr(args, "projection", "device_fp64")
+    model.conv_arithmetic = getattr(args, "conv_arithmetic", "bf16x3")
     # one hipGraph replay per depth map (bit-identical to the eager launches); host_fp32 with device-resident cameras cannot be
     # captured -- save_depth keeps the cameras on the host for that mode
     model.use_graphs = not getattr(args, "no_graphs", False)

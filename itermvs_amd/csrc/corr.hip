@@ -145,11 +145,7 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
 template <int TILE, int FT>
 __global__ void __launch_bounds__(kThreads) corr_iter_kernel(const IterArgs a) {
     __shared__ float lds[ITERMVS_MAX_HYP * ITERMVS_GROUPS * (TILE + 1)];
-#ifdef ITERMVS_ITER_ORDER       // A/B builds: dispatch order of the levels (heaviest first shortens the tail of the 1 920-workgroup launch?)
-    const int lvl = (ITERMVS_ITER_ORDER >> (4 * blockIdx.y)) & 3;
-#else
-    const int lvl = blockIdx.y;
-#endif
+    const int lvl = blockIdx.y;      // (dispatching the heaviest level first measured slower: profiles/r05/r05m_corr_iter_level_order.txt)
     const IterLevel& L = a.lv[lvl];
     switch (L.C) {
         case 16: corr_iter_level<2, TILE, FT>(a, L, lvl, lds); break;
@@ -158,142 +154,9 @@ __global__ void __launch_bounds__(kThreads) corr_iter_kernel(const IterArgs a) {
     }
 }
 
-#ifdef ITERMVS_ITER_TWO_PHASE
-// ---------------------------------------------------------------------------------------------
-// MEASURED AND NOT SHIPPED (round 5, profiles/r05/r05t_corr_iter_two_phase.txt): 27.9 / 25.8 us against 24.4 / 21.9 us (noise / smooth
-// depth) at cfg 1, 632 / 463 against 589 / 345 us at the cfg-5 shape.  The barrier-separated phases and the LDS round trip of the
-// footprints cost more than the leaner gather loop wins (108 VGPRs: still 4 waves per SIMD).
-// iteration branch, two-phase form (A/B builds only: -DITERMVS_ITER_TWO_PHASE).  Phase A: one thread per (pixel, hypothesis,
-// view) of a batch of four views computes the projection, the footprint and the view weight and parks them in LDS (36 bytes);
-// phase B: the quads gather -- footprints from LDS (quad-uniform addresses: broadcast reads), no projection code and no DPP
-// traffic in the loop, fewer live registers.  Same arithmetic, same order of the view sum: bit-identical results.
-// ---------------------------------------------------------------------------------------------
-template <int CPG, int TILE, int FT>
-__device__ __forceinline__ void corr_iter2_level(const IterArgs& a, const IterLevel& L, int lvl, float* __restrict__ lds, uint32_t* __restrict__ fpl,
-                                                 float* __restrict__ wl) {
-    using K = Chunk<CPG>;
-    constexpr int LS = TILE + 1;
-    const int N = L.N;
-    const int b = blockIdx.z;
-    const int P = a.H * a.W;
-    constexpr int TW = kIterTW, TH = TILE / kIterTW;
-    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-    const int tile = xcd_tile(tiles_x * tiles_y);
-    if (tile >= tiles_x * tiles_y) return;
-    const int tile_ty = tile / tiles_x, tile_tx = tile - tile_ty * tiles_x;
-    const int x0 = tile_tx * TW, y0 = tile_ty * TH;
-    constexpr int LPT = K::LPT, NGL = K::NG;
-    const WarpGeom g = make_geom(a.W, a.H, L.W1, L.H1);
-    const WarpRcp rc = make_rcp(g);
-    const float inv_min = a.inv_min[b], inv_max = a.inv_max[b];
-    const float* proj = a.proj + ((size_t)(lvl * a.B + b) * a.S) * 12;
-    const uint32_t sy = (uint32_t)L.sy * feat_bytes<FT>(), sx = (uint32_t)L.sx * feat_bytes<FT>();
-    const int per_px = N * LPT;                 // gather items per pixel
-    const int items = TILE * per_px;
-    for (int s0 = 0; s0 < a.S; s0 += 4) {
-        const int nb = min(4, a.S - s0);
-        // ---- phase A: footprints of (pixel, hypothesis, view s0 + v) -> LDS [(px * N + n) * 4 + v][9]
-        const int fitems = TILE * N * 4;
-#pragma unroll 1
-        for (int it = threadIdx.x; it < fitems; it += kThreads) {
-            const int v = it & 3, pn = it >> 2;
-            const int n = pn % N, px = pn / N;
-            const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
-            Footprint f = {0u, 0u, 0u, 0u, 0.0f, 0.0f, 0.0f, 0.0f};
-            float wv = 0.0f;
-            if (v < nb && x < a.W && y < a.H) {
-                const int p = y * a.W + x;
-                const float d = L.depth ? L.depth[((size_t)b * N + n) * P + p] : iter_hypothesis(a.nd[b * a.nd_sb + p], L.offs[n], inv_min, inv_max);
-                const float* m = proj + (s0 + v) * 12;
-                float rx, ry, rz, ix, iy;
-                ray_dir(m, (float)x * g.xr, (float)y * g.yr, rx, ry, rz);
-                project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
-                f = make_footprint(ix, iy, L.W1, L.H1, sy, sx);
-                wv = a.view_w[(int64_t)b * a.vw_sb + (int64_t)(s0 + v) * a.vw_ss + (int64_t)p * a.vw_sp];
-            }
-            uint32_t* o = fpl + it * 9;
-            o[0] = f.r0; o[1] = f.r1; o[2] = f.c0; o[3] = f.c1;
-            o[4] = __float_as_uint(f.nw); o[5] = __float_as_uint(f.ne); o[6] = __float_as_uint(f.sw); o[7] = __float_as_uint(f.se);
-            o[8] = __float_as_uint(wv);
-        }
-        __syncthreads();
-        // ---- phase B: gather; the running sums of an item live in LDS between the batches of views (same thread, same slots)
-#pragma unroll 1
-        for (int item = threadIdx.x; item < items; item += kThreads) {
-            const int px = item / per_px;
-            const int rem = item - px * per_px;
-            const int n = rem / LPT, j = rem - n * LPT;
-            const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
-            if (x >= a.W || y >= a.H) continue;
-            const int p = y * a.W + x;
-            float refv[K::VEC];
-            if constexpr (FT == ITERMVS_F32) load_vec<K::VEC>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff + j * 4, refv);
-            else load_ref16<CPG>(a.ref_q + ((size_t)b * P + p) * a.CQ + L.coff, j, refv);
-            const uint32_t joff = (uint32_t)(j * 4) * feat_bytes<FT>();
-            const uint32_t* fb = fpl + (size_t)(px * N + n) * 4 * 9;
-            float acc[NGL], wsum = 1e-5f;
-            int slot[NGL];
-#pragma unroll
-            for (int q = 0; q < NGL; ++q) {
-                slot[q] = (n * ITERMVS_GROUPS + (FT == ITERMVS_F32 ? K::group(j, q) : group16<CPG>(j, q))) * LS + px;
-                acc[q] = s0 == 0 ? 0.0f : lds[slot[q]];
-            }
-            if (s0 != 0) wsum = wl[item];
-#pragma unroll 1
-            for (int k = 0; k < nb; ++k) {
-                const uint32_t* o = fb + k * 9;
-                Footprint tp;
-                tp.r0 = o[0]; tp.r1 = o[1]; tp.c0 = o[2]; tp.c1 = o[3];
-                tp.nw = __uint_as_float(o[4]); tp.ne = __uint_as_float(o[5]); tp.sw = __uint_as_float(o[6]); tp.se = __uint_as_float(o[7]);
-                const float wv = __uint_as_float(o[8]);
-                float corr[NGL];
-                if constexpr (FT == ITERMVS_F32) chunk_corr<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), joff, tp, refv, corr);
-                else chunk_corr16<CPG, FT>(feat_base<FT>(L.src[s0 + k], (int64_t)b * L.sb), j, tp, refv, corr);
-#pragma unroll
-                for (int q = 0; q < NGL; ++q) acc[q] = acc[q] + corr[q] * wv;
-                wsum = wsum + wv;
-            }
-            const bool last = s0 + 4 >= a.S;
-#pragma unroll
-            for (int q = 0; q < NGL; ++q) lds[slot[q]] = last ? acc[q] / wsum : acc[q];
-            if (!last) wl[item] = wsum;
-        }
-        __syncthreads();
-    }
-    const int rows = N * ITERMVS_GROUPS;
-    if ((a.W & 3) == 0 && ((uintptr_t)L.out & 15) == 0) {
-        for (int idx = threadIdx.x; idx < rows * (TILE / 4); idx += kThreads) {
-            const int row = idx / (TILE / 4), px = (idx - row * (TILE / 4)) * 4;
-            const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
-            if (x < a.W && y < a.H) {
-                const float* __restrict__ l = lds + row * LS + px;
-                *reinterpret_cast<float4*>(L.out + ((size_t)b * rows + row) * P + (size_t)y * a.W + x) = make_float4(l[0], l[1], l[2], l[3]);
-            }
-        }
-        return;
-    }
-    for (int idx = threadIdx.x; idx < rows * TILE; idx += kThreads) {
-        const int row = idx / TILE, px = idx - row * TILE;
-        const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
-        if (x < a.W && y < a.H) L.out[((size_t)b * rows + row) * P + (size_t)y * a.W + x] = lds[row * LS + px];
-    }
-}
-
-template <int TILE, int FT>
-__global__ void __launch_bounds__(kThreads) corr_iter2_kernel(const IterArgs a, int nmax) {
-    extern __shared__ __attribute__((aligned(16))) float dyn2[];
-    float* lds = dyn2;                                                            // [nmax * 8][TILE + 1]
-    float* wl = lds + nmax * ITERMVS_GROUPS * (TILE + 1);                        // [TILE * nmax * 4]
-    uint32_t* fpl = reinterpret_cast<uint32_t*>(wl + TILE * nmax * 4);            // [TILE * nmax * 4][9]
-    const int lvl = blockIdx.y;
-    const IterLevel& L = a.lv[lvl];
-    switch (L.C) {
-        case 16: corr_iter2_level<2, TILE, FT>(a, L, lvl, lds, fpl, wl); break;
-        case 32: corr_iter2_level<4, TILE, FT>(a, L, lvl, lds, fpl, wl); break;
-        default: corr_iter2_level<6, TILE, FT>(a, L, lvl, lds, fpl, wl); break;
-    }
-}
-#endif  // ITERMVS_ITER_TWO_PHASE
+#ifdef ITERMVS_ITER_TWO_PHASE       // A/B builds only: measured and not shipped (experiments/corr_iter_two_phase.inc)
+#include "experiments/corr_iter_two_phase.inc"
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // initialisation branch: per-view correlation volume for PixelViewWeight (itermvs.py:48-53)
@@ -425,295 +288,9 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
 }
 
 
-#ifdef ITERMVS_INIT_SWEEP_BUILD
-// ---------------------------------------------------------------------------------------------
-// MEASURED AND NOT SHIPPED (round 5; compiled only with -DITERMVS_INIT_SWEEP_BUILD for A/B runs, tools/build_variants.sh
-// CORR_VARIANTS="sweep:-DITERMVS_INIT_SWEEP_BUILD"; profiles/r05/r05l_corr_init_plane_sweep.txt): bit-identical results, but
-// 43.8 us against the gather form's 23.5 us at cfg 1 and 454 against 347 us at the cfg-5 shape.  The patch per wave (19 KB) and
-// 226 VGPRs allow two waves per SIMD, and a wave walks its planes as one dependent chain (project -> box reduction -> offsets ->
-// loads -> LDS -> taps): knock-outs put 20 us of the 44 in that skeleton alone (no loads, no LDS traffic, no tap arithmetic), 14 us
-// in the LDS taps + blend, 5 us in the LDS stores, 4 us in the box reduction, 0 in the staging loads (hidden).  The gather form
-// hides its L1 latency with 8 waves per SIMD; this form cannot.
-//
-// initialisation branch as a PLANE SWEEP through LDS (C = 48, fp32 storage).
-// The generated hypotheses are planes (itermvs.py:11-19): all pixels of a tile share the depth, so the bilinear footprints of
-// an 8 x 8 pixel tile on one (view, plane) fall into ONE compact patch of the source map -- 81 pixels (median; 100 at the 99th
-// percentile) against 256 taps, at every resolution (tools/plane_patch_count.py, profiles/r05/r05_plane_patch_count.txt).
-// The gather form above fetches every tap through the vector L1 (503 MB per launch at cfg 1: the kernel sat at 60 % of the L1's
-// rate and 0.13 of the HBM roof).  Here a WAVE owns (tile, view, a few planes), lane = pixel, and per plane
-//   1. every lane projects its pixel with the same device functions as before (project_fast, make_taps: identical indices and
-//      weights), the wave reduces the bounding box of the valid taps (packed 16-bit min / max, 6 butterfly steps);
-//   2. the box is copied to the wave's own LDS region with coalesced 16-byte loads (lanes walk the 12 four-channel pieces of a
-//      pixel, then the pixels: 64-byte runs), stored [piece][pixel] with an odd 16-byte plane stride so that the stores (8
-//      lanes = 8 pieces of a pixel) and the reads (16 lanes = neighbouring pixels of one piece) hit distinct banks;
-//      the NEXT plane's loads are issued before the current plane's arithmetic (registers), no workgroup barrier anywhere;
-//   3. the four taps of the 12 pieces come from LDS (ds_read_b128 with the piece in the immediate offset); blend, products with the
-//      lane's 48 reference values (registers, loaded once per wave) and the 8 group means follow the gather form's
-//      arithmetic and association exactly (chunk_corr<6>) -- results are bit-identical;
-//   4. a lane stores its 8 results: 32-byte runs per plane row, no transposing LDS pass.
-// A box that exceeds the LDS patch (grazing planes, explicit per-pixel hypotheses) takes the same arithmetic with the taps
-// loaded from memory.
-// ---------------------------------------------------------------------------------------------
-constexpr int kSweepCap = 100;                        // pixels of a staged box
-constexpr int kSweepPl = kSweepCap * 16 + 16;         // bytes between the [piece] planes: an odd number of 16-byte slots
-constexpr int kSweepWaveLds = 12 * kSweepPl;          // 19 392 B per wave: two workgroups of four waves per CU
-using sweep_f4 = __attribute__((ext_vector_type(4))) float;      // (native vector: HIP's float4 class kept the staging array in scratch)
-constexpr int kSweepLoads = (kSweepCap * 6 + 63) / 64;    // 16-byte pieces per lane of HALF a full box (6 of the 12 pieces per pixel)
-
-struct SweepTaps {
-    uint32_t o00, o01, o10, o11;      // byte offsets of the four taps (LDS: inside piece 0 of the box; memory: inside the map)
-    float nw, ne, sw, se;
-};
-
-// reduction over the wave of two packed unsigned 16-bit values per lane (min of both halves)
-__device__ __forceinline__ uint32_t wave_pk_min_u16(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
-        const uint32_t lo = min(v & 0xffffu, o & 0xffffu), hi = min(v >> 16, o >> 16);
-        v = lo | (hi << 16);
-    }
-    return v;
-}
-
-// channel-pair products of pieces 6 * HALF .. 6 * HALF + 5 (24 channels): chunk_corr's per-channel fma chain over the four taps,
-// then its pair products
-template <bool FROM_LDS, int HALF>
-__device__ __forceinline__ void sweep_pairs(const char* __restrict__ base, const SweepTaps& t, const float (&refv)[48], float (&pair)[24]) {
-#pragma unroll
-    for (int cb = 6 * HALF; cb < 6 * HALF + 6; ++cb) {
-        constexpr int kStep = FROM_LDS ? kSweepPl : 16;
-        const float4 v00 = *reinterpret_cast<const float4*>(base + t.o00 + cb * kStep);
-        const float4 v01 = *reinterpret_cast<const float4*>(base + t.o01 + cb * kStep);
-        const float4 v10 = *reinterpret_cast<const float4*>(base + t.o10 + cb * kStep);
-        const float4 v11 = *reinterpret_cast<const float4*>(base + t.o11 + cb * kStep);
-        const float w0 = fmaf(t.se, v11.x, fmaf(t.sw, v10.x, fmaf(t.ne, v01.x, t.nw * v00.x)));
-        const float w1 = fmaf(t.se, v11.y, fmaf(t.sw, v10.y, fmaf(t.ne, v01.y, t.nw * v00.y)));
-        const float w2 = fmaf(t.se, v11.z, fmaf(t.sw, v10.z, fmaf(t.ne, v01.z, t.nw * v00.z)));
-        const float w3 = fmaf(t.se, v11.w, fmaf(t.sw, v10.w, fmaf(t.ne, v01.w, t.nw * v00.w)));
-        const float* r = refv + 4 * cb;
-        pair[2 * cb] = fmaf(w1, r[1], w0 * r[0]);
-        pair[2 * cb + 1] = fmaf(w3, r[3], w2 * r[2]);
-        // two pieces' taps in flight at most: hoisting all reads ahead of the arithmetic costs a hundred registers
-        if (cb & 1) __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-struct SweepBox {
-    int bx, by, bw, npx;      // origin, width, pixels (0: nothing to stage); wave-uniform
-    bool fits;
-};
-
-// HALF a box -> registers -> LDS: piece i = lane + 64 k of a half is (pixel i / 6, four-channel piece 6 h + i % 6); the lanes walk
-// the six pieces of a pixel, then the pixels: 96-byte runs in memory, distinct banks in LDS (odd plane stride).
-// The split of i is the lane's own constant (SweepLane, once per wave); per plane only pixel -> (row, column) of the box remains,
-// by a float reciprocal ((px + 0.5) / bw is at least 0.5 / bw away from an integer: exact for these sizes) and 24-bit
-// multiplies -- 32-bit integer multiplies run at a quarter of the rate and, six per piece, cost this kernel more than its
-// arithmetic.
-struct SweepLane {
-    uint32_t px[kSweepLoads];        // pixel index of piece k inside a box
-    uint32_t lds[kSweepLoads];       // LDS byte offset of piece k of half 0 (+ 6 * kSweepPl for half 1)
-    uint32_t cb16[kSweepLoads];      // 16 * (piece of the pixel, 0..5): its byte offset inside the pixel's vector
-};
-__device__ __forceinline__ void sweep_lane_init(SweepLane& L, int lane) {
-#pragma unroll
-    for (int k = 0; k < kSweepLoads; ++k) {
-        const uint32_t i = (uint32_t)lane + 64u * k;
-        const uint32_t px = __umulhi(i, 715827883u);              // i / 6 for i < 2^16  (2^32 / 6 + 1)
-        L.px[k] = px;
-        L.cb16[k] = (i - px * 6u) * 16u;
-        L.lds[k] = (i - px * 6u) * (uint32_t)kSweepPl + px * 16u;
-    }
-}
-// memory byte offsets of piece k of half 0 (half 1: + 96 bytes) for this plane's box
-__device__ __forceinline__ void sweep_offsets(uint32_t (&goff)[kSweepLoads], const SweepLane& L, const SweepBox& box, uint32_t sy, uint32_t sx) {
-    const float inv_bw = 1.0f / (float)box.bw;
-    const uint32_t last = (uint32_t)max(box.npx, 1) - 1u;
-    const uint32_t base = __umul24((uint32_t)box.by, sy) + __umul24((uint32_t)box.bx, sx);
-#pragma unroll
-    for (int k = 0; k < kSweepLoads; ++k) {
-        // (lanes past the end re-read the last pixel: an unconditional load keeps the staging registers out of control flow)
-        const uint32_t px = min(L.px[k], last);
-        const uint32_t r = (uint32_t)(((float)px + 0.5f) * inv_bw);
-        const uint32_t c = px - __umul24(r, (uint32_t)box.bw);
-        goff[k] = base + __umul24(r, sy) + __umul24(c, sx) + L.cb16[k];
-    }
-}
-#ifndef ITERMVS_SWEEP_KO          // knock-out builds (timing only): bit 0 no staging loads, 1 no LDS stores, 2 no tap arithmetic, 3 no box reduction
-#define ITERMVS_SWEEP_KO 0
+#ifdef ITERMVS_INIT_SWEEP_BUILD     // A/B builds only: measured and not shipped (experiments/corr_init_plane_sweep.inc)
+#include "experiments/corr_init_plane_sweep.inc"
 #endif
-__device__ __forceinline__ void sweep_fetch_half(sweep_f4 (&stage)[kSweepLoads], const uint32_t (&goff)[kSweepLoads], const SweepBox& box, int h,
-                                                 const char* __restrict__ fsrc) {
-    if (!box.fits || box.npx == 0) return;
-#if ITERMVS_SWEEP_KO & 1
-#pragma unroll
-    for (int k = 0; k < kSweepLoads; ++k) stage[k] = sweep_f4{(float)goff[k], 1.0f, 2.0f, (float)h};
-    return;
-#endif
-#pragma unroll
-    for (int k = 0; k < kSweepLoads; ++k) stage[k] = *reinterpret_cast<const sweep_f4*>(fsrc + goff[k] + 96u * (uint32_t)h);
-}
-__device__ __forceinline__ void sweep_store_half(const sweep_f4 (&stage)[kSweepLoads], const SweepLane& L, const SweepBox& box, int h,
-                                                 char* __restrict__ patch) {
-    if (!box.fits || box.npx == 0) return;
-    const uint32_t npx = (uint32_t)box.npx;
-#if ITERMVS_SWEEP_KO & 2
-#pragma unroll
-    for (int k = 0; k < kSweepLoads; ++k) asm volatile("" ::"v"(stage[k]));
-    return;
-#endif
-#pragma unroll
-    for (int k = 0; k < kSweepLoads; ++k)
-        if (L.px[k] < npx) *reinterpret_cast<sweep_f4*>(patch + L.lds[k] + (uint32_t)(6 * kSweepPl) * (uint32_t)h) = stage[k];
-}
-
-__global__ void __launch_bounds__(256) corr_init_sweep_kernel(const InitArgs a, int planes_per_wave, int tiles_x, int tiles_y) {
-    extern __shared__ __attribute__((aligned(16))) char sweep_lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char* __restrict__ patch = sweep_lds + wave * kSweepWaveLds;
-    const int tile = xcd_tile(tiles_x * tiles_y);
-    if (tile >= tiles_x * tiles_y) return;
-    const int b = blockIdx.z;
-    const int groups = (a.N + 4 * planes_per_wave - 1) / (4 * planes_per_wave);     // workgroups per (tile, view)
-    const int s = blockIdx.y / groups;
-    const int n_begin = ((blockIdx.y - s * groups) * 4 + wave) * planes_per_wave;
-    const int n_end = min(a.N, n_begin + planes_per_wave);
-    if (n_begin >= n_end) return;                       // (no barriers in this kernel: a wave may leave)
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
-    const bool live = x < a.W && y < a.H;
-    const int P = a.H * a.W;
-    const int p = live ? y * a.W + x : 0;
-    const WarpGeom g = make_geom(a.W, a.H, a.W1, a.H1);
-    const WarpRcp rc = make_rcp(g);
-    const float inv_min = a.inv_min[b], inv_max = a.inv_max[b];
-    const float* m = a.proj + ((size_t)b * a.S + s) * 12;
-    const char* __restrict__ fsrc = reinterpret_cast<const char*>(a.src[s] + (int64_t)b * a.sb);
-    const uint32_t sy = (uint32_t)a.sy * 4u, sx = (uint32_t)a.sx * 4u;      // byte strides of the source map
-
-    float refv[48];
-    {
-        const float* rp = (const float*)a.ref.data + (int64_t)b * a.ref.sb + (live ? y * a.ref.sy + x * a.ref.sx : 0);
-        if (a.ref.sc == 1) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                const float4 t = *reinterpret_cast<const float4*>(rp + 4 * i);
-                refv[4 * i] = t.x; refv[4 * i + 1] = t.y; refv[4 * i + 2] = t.z; refv[4 * i + 3] = t.w;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 48; ++c) refv[c] = rp[c * a.ref.sc];
-        }
-    }
-    float rx, ry, rz;
-    ray_dir(m, (float)x * g.xr, (float)y * g.yr, rx, ry, rz);
-
-    // the sampling taps of this lane's pixel on plane n (LDS offsets once the box is known) + the wave's box of valid taps
-    auto project_plane = [&](int n, SweepTaps& st, SweepBox& box) __attribute__((always_inline)) {
-        const float d = a.depth ? a.depth[((size_t)b * a.N + n) * P + p] : init_hypothesis(n, a.N, inv_min, inv_max);
-        float ix, iy;
-        project_fast(g, rc, m, rx, ry, rz, d, ix, iy);
-        TapDiag dg;
-        const Taps t = make_taps(ix, iy, a.W1, a.H1, &dg);
-        const int vx = dg.bits & 3, vy = (dg.bits >> 2) & 3;
-        const bool any = live && vx && vy;                    // no valid column or row: all four weights are zero
-        // columns / rows this lane needs: the valid ones (make_taps clamps an invalid index to 0)
-        const int lx0 = (vx & 1) ? t.x0 : t.x1, lx1 = (vx & 2) ? t.x1 : t.x0;
-        const int ly0 = (vy & 1) ? t.y0 : t.y1, ly1 = (vy & 2) ? t.y1 : t.y0;
-        // packed unsigned 16-bit: (min x | 0xffff - max x), (min y | 0xffff - max y); idle lanes are neutral
-        uint32_t kx = 0xffffffffu, ky = 0xffffffffu;
-        if (any) {
-            kx = (uint32_t)lx0 | ((0xffffu - (uint32_t)lx1) << 16);
-            ky = (uint32_t)ly0 | ((0xffffu - (uint32_t)ly1) << 16);
-        }
-#if ITERMVS_SWEEP_KO & 8
-        kx = __builtin_amdgcn_readfirstlane(kx) & 0xfff0fff0u; ky = __builtin_amdgcn_readfirstlane(ky) & 0xfff0fff0u;      // (a box of 16 x 16: does not fit -> only with bit 0..2 builds)
-        kx = (kx & 0xffffu) | ((0xffffu - ((kx & 0xffffu) + 9u)) << 16); ky = (ky & 0xffffu) | ((0xffffu - ((ky & 0xffffu) + 9u)) << 16);
-#else
-        kx = __builtin_amdgcn_readfirstlane(wave_pk_min_u16(kx));
-        ky = __builtin_amdgcn_readfirstlane(wave_pk_min_u16(ky));
-#endif
-        st.nw = any ? t.nw : 0.0f; st.ne = any ? t.ne : 0.0f; st.sw = any ? t.sw : 0.0f; st.se = any ? t.se : 0.0f;
-        if (kx == 0xffffffffu) {
-            box.bx = box.by = 0; box.bw = 1; box.npx = 0; box.fits = true;
-            st.o00 = st.o01 = st.o10 = st.o11 = 0u;
-            return;
-        }
-        box.bx = (int)(kx & 0xffffu);
-        box.by = (int)(ky & 0xffffu);
-        box.bw = (int)(0xffffu - (kx >> 16)) - box.bx + 1;
-        const int bh = (int)(0xffffu - (ky >> 16)) - box.by + 1;
-        box.npx = box.bw * bh;
-        box.fits = box.npx <= kSweepCap;
-        if (box.fits) {
-            // an invalid column / row reads its valid partner (weight 0); a lane without any valid tap reads the box origin
-            const int cx0 = any ? lx0 : box.bx, cx1 = any ? lx1 : box.bx, cy0 = any ? ly0 : box.by, cy1 = any ? ly1 : box.by;
-            const uint32_t r0 = __umul24((uint32_t)(cy0 - box.by), (uint32_t)box.bw), r1 = __umul24((uint32_t)(cy1 - box.by), (uint32_t)box.bw);
-            const uint32_t c0 = (uint32_t)(cx0 - box.bx), c1 = (uint32_t)(cx1 - box.bx);
-            st.o00 = (r0 + c0) * 16u; st.o01 = (r0 + c1) * 16u; st.o10 = (r1 + c0) * 16u; st.o11 = (r1 + c1) * 16u;
-        } else {
-            const uint32_t r0 = (uint32_t)t.y0 * sy, r1 = (uint32_t)t.y1 * sy, c0 = (uint32_t)t.x0 * sx, c1 = (uint32_t)t.x1 * sx;
-            st.o00 = r0 + c0; st.o01 = r0 + c1; st.o10 = r1 + c0; st.o11 = r1 + c1;
-        }
-    };
-    sweep_f4 stage[kSweepLoads];
-    uint32_t goff[kSweepLoads];
-    SweepLane L;
-    sweep_lane_init(L, lane);
-    // Software pipeline over the wave's planes, ONE LDS image: while plane n's pieces 0..5 are multiplied, the next plane's
-    // pieces 0..5 are in flight to registers; they are stored once plane n has read its own (the LDS executes a wave's
-    // operations in order), then the same registers take pieces 6..11 during the second half of the arithmetic.
-    SweepTaps cur, nxt;
-    SweepBox box, nbox;
-    project_plane(n_begin, cur, box);
-    sweep_offsets(goff, L, box, sy, sx);
-    sweep_fetch_half(stage, goff, box, 0, fsrc);
-    sweep_store_half(stage, L, box, 0, patch);
-    sweep_fetch_half(stage, goff, box, 1, fsrc);
-    sweep_store_half(stage, L, box, 1, patch);
-    for (int n = n_begin; n < n_end; ++n) {
-        const bool more = n + 1 < n_end;                // wave-uniform
-        nbox.npx = 0; nbox.fits = true; nbox.bx = nbox.by = 0; nbox.bw = 1;
-        if (more) {
-            project_plane(n + 1, nxt, nbox);
-            sweep_offsets(goff, L, nbox, sy, sx);
-            sweep_fetch_half(stage, goff, nbox, 0, fsrc);
-        }
-        float pair[24];
-#if ITERMVS_SWEEP_KO & 4
-#pragma unroll
-        for (int q = 0; q < 24; ++q) pair[q] = refv[q] * cur.nw + __uint_as_float(cur.o00);
-#define SWEEP_PAIRS(H)
-#else
-#define SWEEP_PAIRS(H)                                                   \
-        if (box.npx != 0) {                                              \
-            if (box.fits) sweep_pairs<true, H>(patch, cur, refv, pair);  \
-            else sweep_pairs<false, H>(fsrc, cur, refv, pair);           \
-        }
-#endif
-        SWEEP_PAIRS(0)
-        if (more) {
-            sweep_store_half(stage, L, nbox, 0, patch);
-            sweep_fetch_half(stage, goff, nbox, 1, fsrc);
-        }
-        SWEEP_PAIRS(1)
-#undef SWEEP_PAIRS
-        if (more) sweep_store_half(stage, L, nbox, 1, patch);
-        if (live) {
-            float* o = a.out + ((((size_t)b * a.S + s) * a.N + n) * ITERMVS_GROUPS) * P + p;
-            // group q = channel pairs 3q, 3q+1, 3q+2; even groups (A + B) + C, odd groups A + (B + C)  (chunk_corr<6>'s association)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float A = pair[3 * q], B = pair[3 * q + 1], Cc = pair[3 * q + 2];
-                const float sum = (q & 1) ? A + (B + Cc) : (A + B) + Cc;
-                o[(size_t)q * P] = box.npx != 0 ? div_rcp(sum, 6.0f, 1.0f / 6.0f) : 0.0f;
-            }
-        }
-        cur = nxt;
-        box = nbox;
-    }
-}
-#endif  // ITERMVS_INIT_SWEEP_BUILD
 
 constexpr int kInitNB = 8;  // hypotheses per block
 

@@ -879,7 +879,8 @@ class MfmaWeight:
             t[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(9, cin, cout)
             self.tile = t.reshape(9, nch, 4, s, cout_p).permute(0, 1, 2, 4, 3).contiguous()
         self.tile3 = None
-        if k == 3 and cin > 8 and not transposed and (MFMA_SPLIT3_DEFAULT if split3 is None else split3):
+        # (up to 64 input channels: the split weights of a 16-channel block -- 13.8 KB per input chunk -- share the LDS with the tile)
+        if k == 3 and 8 < cin <= 64 and not transposed and (MFMA_SPLIT3_DEFAULT if split3 is None else split3):
             nch = (cin + 15) // 16
             t = torch.zeros((9, nch * 16, cout_p), device=w.device, dtype=torch.float32)
             t[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(9, cin, cout)
