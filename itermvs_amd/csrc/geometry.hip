@@ -187,13 +187,17 @@ __global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fma
     const int H = r2.H, W = r2.W;
     const int CQ = r1.C + r2.C + r3.C;
     const int quads = CQ / 4;
-    const int64_t total = (int64_t)B * H * W * quads;
-    const int64_t t = (int64_t)((int)blockIdx.x - n_comp) * blockDim.x + threadIdx.x;
+    // 32-bit index arithmetic (the launcher guarantees total < 2^31): the three 64-bit divisions of the first form were most of
+    // this kernel's instructions -- 14 us for 8 MB of output
+    const uint32_t total = (uint32_t)B * (uint32_t)H * (uint32_t)W * (uint32_t)quads;
+    const uint32_t t = ((uint32_t)blockIdx.x - (uint32_t)n_comp) * blockDim.x + threadIdx.x;
     if (t >= total) return;
-    const int q = (int)(t % quads);
-    const int x = (int)((t / quads) % W);
-    const int y = (int)((t / ((int64_t)quads * W)) % H);
-    const int b = (int)(t / ((int64_t)quads * W * H));
+    const uint32_t px = t / (uint32_t)quads;
+    const int q = (int)(t - px * (uint32_t)quads);
+    const uint32_t row = px / (uint32_t)W;
+    const int x = (int)(px - row * (uint32_t)W);
+    const int b = (int)(row / (uint32_t)H);
+    const int y = (int)(row - (uint32_t)b * (uint32_t)H);
     int c = q * 4;
     float v[4];
     if (c < r1.C) {
@@ -287,6 +291,7 @@ static int launch_ref_quarter(const itermvs_fmap* r1, const itermvs_fmap* r2, co
                           ITERMVS_ERR_DIMS);
     }
     const int64_t total = (int64_t)B * r2->H * r2->W * ((r1->C + r2->C + r3->C) / 4);
+    ITERMVS_RETURN_IF(total >= ((int64_t)1 << 31) - 512, ITERMVS_ERR_DIMS);        // 32-bit thread index in the kernel
     ITERMVS_RETURN_IF(r1->dtype != r2->dtype || r1->dtype != r3->dtype, ITERMVS_ERR_DTYPE);
     const int n_ref = (int)((total + 255) / 256);
     ComposeArgs c{};
