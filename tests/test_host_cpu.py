@@ -318,3 +318,29 @@ def test_library_load_brings_torch_in_first():
             "from itermvs_amd import _lib; _lib.load()")
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "TORCH_FIRST True" in p.stdout, (p.stdout, p.stderr[-800:])
+
+
+def test_algorithmic_bytes_are_the_designs_figures():
+    """bench.py's roofline numerators (SURVEY 8(d) with hypotheses built in-kernel): DESIGN.md section 4 quotes these figures"""
+    from itermvs_amd.benchmarks import algorithmic_bytes
+    it, init, per_map = algorithmic_bytes(4, 512, 640, 1, 4)                       # cfg 1, fp32
+    assert round(it / 1e6, 1) == 50.2 and round(init / 1e6, 1) == 25.9 and round(per_map / 1e6, 1) == 226.8
+    it16, init16, _ = algorithmic_bytes(4, 512, 640, 1, 4, e=2)                    # 16-bit feature storage
+    assert round(it16 / 1e6, 1) == 32.5 and init16 < init
+    it5, _, _ = algorithmic_bytes(10, 1280, 1920, 1, 8)                            # cfg-5 shape, fp32
+    assert 770e6 < it5 < 790e6
+
+
+def test_split_bf16x3_is_exact_and_conv_arithmetic_is_validated():
+    """the host side of the bf16x3 convolutions: h + m + l reproduces every finite fp32 value exactly (three bf16 terms), and
+    the engine rejects unknown arithmetic names before touching the GPU"""
+    from itermvs_amd import ops
+    from itermvs_amd.engine import InferenceEngine
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(4096, generator=g) * s for s in (1e-20, 1e-3, 1.0, 1e6)] + [torch.tensor([0.0, -0.0, 1.0, -1.5, 3.4e38, 1.2e-38])])      # (fp32 subnormals below bf16's resolution are out of the split's range)
+    h, m, l = ops.split_bf16x3(x)
+    assert h.dtype == m.dtype == l.dtype == torch.bfloat16
+    back = h.double() + m.double() + l.double()
+    assert torch.equal(back, x.double())
+    with pytest.raises(ValueError):
+        InferenceEngine({}, 4, conv_arithmetic="tf32")
