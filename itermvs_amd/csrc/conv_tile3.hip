@@ -3,7 +3,8 @@
 //
 // v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (one instruction per 32 cycles, 64 FLOP/clk/SIMD);
 // v_mfma_f32_16x16x32_bf16 at 16x that.  An fp32 value is EXACTLY the sum of three bf16 values
-//     x = h + m + l,   h = x truncated to 8 significant bits, m = (x - h) truncated, l = x - h - m  (all three exact),
+//     x = h + m + l,   h = x truncated to 8 significant bits, m = (x - h) truncated, l = x - h - m  (all three exact for
+//     |x| >= ~1e-33; below that the low terms fall under bf16's smallest subnormal: absolute error < 1e-40),
 // so a product of two fp32 values is the sum of nine bf16 x bf16 products (each exact in fp32).  The six largest,
 //     xh wh  +  (xh wm + xm wh)  +  (xm wm + xh wl + xl wh),
 // leave out terms below 2^-23 of |x w| -- the size of one fp32 rounding of the product itself.  They cost three MFMAs per
