@@ -70,7 +70,7 @@ struct Tile3Geom {
 #define ITERMVS_TILE3_DBUF 1
 #endif
 #ifndef ITERMVS_TILE3_KO          // knock-out builds (tools only): bit 0 no split arithmetic, 1 one LDS store per item, 2 one operand read per block,
-#define ITERMVS_TILE3_KO 0        // 3 no MFMAs
+#define ITERMVS_TILE3_KO 0        // 3 no MFMAs, 4 no staging loads, 5 no epilogue
 #endif
 
 template <int MB, int STRIDE, int DIL, int TH, int TWT, int CPS>
@@ -170,8 +170,12 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
         for (int e = 0; e < kLoads; ++e)
             if (e * kParts / kLoads == part) {
                 const int c = e / (G::ITEMS * 8), j = (e / 8) % G::ITEMS, k = e % 8;
+#if ITERMVS_TILE3_KO & 16     // knock-out: no staging loads
+                stage[c][j][k] = __uint_as_float(goff[j] + soff + (uint32_t)k);
+#else
                 stage[c][j][k] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(ir, goff[j], soff + c * chunk_b + k * plane * 4u, 0));
+#endif
             }
     };
     auto fetch = [&](uint32_t soff) {
@@ -337,7 +341,18 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
                 e.Cout = a.split;
             }
         }
+#if ITERMVS_TILE3_KO & 32     // knock-out: no epilogue (one dword per lane keeps the accumulators alive)
+        {
+            float keep = 0.0f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) keep += acc[mb][nb][0] + acc[mb][nb][1] + acc[mb][nb][2] + acc[mb][nb][3];
+            if (keep == 1.2345e-30f) e.out[0] = keep;
+        }
+#else
         conv_epilogue<MB, NB>(e, acc, me, q, pix_off, py, px);
+#endif
         if (wn >= a.total) break;
         w = wn;
         cur = nxt;
