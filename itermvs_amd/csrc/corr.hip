@@ -174,10 +174,21 @@ struct InitArgs {
     int B, S, H, W, N, C, H1, W1, NB;  // NB = hypotheses per block
 };
 
+constexpr int kInitNB = 8;  // hypotheses per block
+// LDS row pitch = TILE + kInitPad.  A store instruction of the gather loop writes, per half wave, rows {32 grp + 2j (+q)} x 4
+// consecutive pixels (lane = pixel * 8 + grp * 4 + j): with a pitch of 41 dwords the row offsets 82 j + 1312 grp fall on banks
+// 18 j + 32 grp (mod 64) -- eight disjoint runs of four banks.  (Pitch 33 put 2j + px of one grp on the same bank for up to
+// four lanes: 60 % of this kernel's LDS cycles were conflict cycles, profiles/r04_pmc_kernels.json.  The kernel's time did
+// not change -- its LDS pipeline is busy 1.3 us of 24: profiles/r05/r05ad_corr_init_lds_pitch.txt.)
+#ifndef ITERMVS_INIT_PAD
+#define ITERMVS_INIT_PAD 9
+#endif
+constexpr int kInitPad = ITERMVS_INIT_PAD;
+
 template <int CPG, int TILE, int FT>
 __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restrict__ lds) {
     using K = Chunk<CPG>;
-    constexpr int LS = TILE + 1;
+    constexpr int LS = TILE + kInitPad;
     const int nblocks = (a.N + a.NB - 1) / a.NB;
     const int s = blockIdx.y / nblocks;
     const int n0 = (blockIdx.y - s * nblocks) * a.NB;
@@ -292,11 +303,10 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
 #include "experiments/corr_init_plane_sweep.inc"
 #endif
 
-constexpr int kInitNB = 8;  // hypotheses per block
 
 template <int TILE, int FT>
 __global__ void __launch_bounds__(kThreads) corr_init_kernel(const InitArgs a) {
-    __shared__ float lds[kInitNB * ITERMVS_GROUPS * (TILE + 1)];
+    __shared__ float lds[kInitNB * ITERMVS_GROUPS * (TILE + kInitPad)];
     switch (a.C) {
         case 16: corr_init_body<2, TILE, FT>(a, lds); break;
         case 32: corr_init_body<4, TILE, FT>(a, lds); break;
