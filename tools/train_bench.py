@@ -27,10 +27,14 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--profile", type=int, default=0, help="after the timing: torch.profiler over this many steady-state steps, top kernels by device time")
+    ap.add_argument("--cudnn-benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (reference train.py:23): MIOpen times its "
+                    "applicable solvers per convolution shape once instead of taking the immediate-mode pick.  On a box without a MIOpen "
+                    "kernel cache the search compiles every candidate: > 11 minutes before the first step at B = 4 (profiles/r05/r05af)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (train_step.CapturedTrainStep)")
     ap.add_argument("--phases", action="store_true", help="also time forward / backward / optimizer separately (synchronising)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
+    torch.backends.cudnn.benchmark = args.cudnn_benchmark
     res = benchmarks.train_step_leg(dev, batch=args.batch, views=args.views, height=args.wh[1], width=args.wh[0], iteration=args.iteration,
                                     feature_dtype=args.feature_dtype, regress=args.regress, warmup=args.warmup, steps=args.steps,
                                     phases=args.phases, graph=args.graph)
