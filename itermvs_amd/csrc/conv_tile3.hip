@@ -359,6 +359,14 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
     }
 }
 
+
+#ifndef ITERMVS_TILE3_SPEC
+#define ITERMVS_TILE3_SPEC 0
+#endif
+#if ITERMVS_TILE3_SPEC       // producer / consumer form of the kernel above: A/B builds only (measured slower)
+#include "experiments/conv_tile3_producer_consumer.inc"
+#endif
+
 constexpr int kLds3Budget = 80 * 1024;     // per workgroup: two workgroups fit the CU's 160 KB
 
 template <int MB, int STRIDE, int DIL, int TH, int TWT, int CPS>
@@ -394,6 +402,13 @@ static int launch_tile3(TileArgs& a, int mt, hipStream_t stream) {
 // chunks per stage: all chunks of a 2..4-chunk layer at once when the stages + weights fit the LDS budget
 template <int MB, int STRIDE, int DIL, int TH, int TWT>
 static int launch_cps3(TileArgs& a, int mt, hipStream_t stream) {
+#if ITERMVS_TILE3_SPEC
+    if (a.nchunk == 3 && tile3s_lds_bytes<MB, STRIDE, DIL, TH, TWT, 3>(3) <= kLds3sBudget)
+        return launch_tile3s<MB, STRIDE, DIL, TH, TWT, 3>(a, mt, stream);
+    if ((a.nchunk == 2 || a.nchunk == 4) && tile3s_lds_bytes<MB, STRIDE, DIL, TH, TWT, 2>(a.nchunk) <= kLds3sBudget)
+        return launch_tile3s<MB, STRIDE, DIL, TH, TWT, 2>(a, mt, stream);
+    return launch_tile3s<MB, STRIDE, DIL, TH, TWT, 1>(a, mt, stream);
+#endif
     if (a.nchunk == 3 && tile3_lds_bytes<MB, STRIDE, DIL, TH, TWT, 3>(3) <= kLds3Budget)
         return launch_tile3<MB, STRIDE, DIL, TH, TWT, 3>(a, mt, stream);
     if ((a.nchunk == 2 || a.nchunk == 4) && tile3_lds_bytes<MB, STRIDE, DIL, TH, TWT, 2>(a.nchunk) <= kLds3Budget)
