@@ -498,7 +498,7 @@ def main() -> None:
         for name, (v_, h_, w_, it_, ft_) in {"cfg3_fp32": (5, 1152, 1600, 4, "fp32"), "cfg3_fp16": (5, 1152, 1600, 4, "fp16"),
                                              "cfg5_fp16": (11, 1280, 1920, 8, "fp16")}.items():
             try:
-                other[name] = benchmarks.shape_leg(dev, v_, h_, w_, it_, ft_, warmup=5, steps=10)
+                other[name] = benchmarks.shape_leg(dev, v_, h_, w_, it_, ft_, warmup=5, steps=10, conv_arithmetic=args.conv_arithmetic)
             except Exception as e:  # noqa: BLE001  (a leg that fails must not take the headline line with it)
                 other[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
         for name, graph in (("train_step_cfg4", False), ("train_step_cfg4_graph", True)):      # eager, and the step as one hipGraph

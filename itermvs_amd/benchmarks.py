@@ -26,7 +26,7 @@ def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int, e: int = 4
 
 
 def shape_leg(dev, views: int, height: int, width: int, iters: int, feature_dtype: str = "fp32", warmup: int = 5,
-              steps: int = 10) -> Dict[str, object]:
+              steps: int = 10, conv_arithmetic: str = "bf16x3") -> Dict[str, object]:
     """depth-maps/s of ONE captured hipGraph (one reference view per replay, inputs resident) at another shape than the
     headline's, with HIP-event brackets around every fused correlation launch inside the graph:
     ``warmup`` + ``steps`` replays -> value, ms per depth map, mean corr_iter / corr_init launch time and their fraction of
@@ -37,7 +37,7 @@ def shape_leg(dev, views: int, height: int, width: int, iters: int, feature_dtyp
     m = Pipeline(iteration=iters, test=True)
     m.load_state_dict(synthetic.random_state_dict(0))
     m = m.to(dev).eval()
-    eng = InferenceEngine(m.weights(), iters, feature_dtype)
+    eng = InferenceEngine(m.weights(), iters, feature_dtype, conv_arithmetic=conv_arithmetic)
     s = synthetic.make_sample(batch=1, num_views=views, height=height, width=width, seed=0)
     pj = {l: s["proj_matrices"][f"level_{l}"].float().to(dev) for l in (1, 2, 3)}
     per_step = iters + 1
@@ -45,16 +45,16 @@ def shape_leg(dev, views: int, height: int, width: int, iters: int, feature_dtyp
     r = GraphedRunner(eng, s["imgs"]["level_0"].float().to(dev), pj, s["depth_min"].float().to(dev), s["depth_max"].float().to(dev))
     first, count = r.profile_pairs
     for _ in range(warmup):
-        r.graph.replay()
+        r.replay()
     torch.cuda.synchronize(dev)
     prof = []
     t0 = time.perf_counter()
     for _ in range(steps):
-        r.graph.replay()
+        r.replay()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     for _ in range(3):                                   # the brackets of three more replays, read one by one (each read waits
-        r.graph.replay()                                 # for its replay: outside the timed loop)
+        r.replay()                                 # for its replay: outside the timed loop)
         prof.extend(ops.profile_graph_read(first, count))
     ops.profile_enable(0)
     eng.check_projection_finite()
@@ -63,7 +63,7 @@ def shape_leg(dev, views: int, height: int, width: int, iters: int, feature_dtyp
     t_iter = [ms for kind, ms in prof if kind == 1]
     t_init = [ms for kind, ms in prof if kind == 2]
     out = {"views": views, "height": height, "width": width, "iterations": iters, "feature_dtype": feature_dtype,
-           "value": steps / dt, "unit": "depth-maps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup}
+           "conv_arithmetic": conv_arithmetic, "value": steps / dt, "unit": "depth-maps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup}
     if t_iter:
         ms = sum(t_iter) / len(t_iter)
         out["corr_iter"] = {"avg_launch_ms": ms, "launches_timed": len(t_iter), "frac": b_iter / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}

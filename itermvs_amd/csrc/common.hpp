@@ -18,6 +18,14 @@ static inline int itermvs_launch_status() {
     return hipGetLastError() == hipSuccess ? ITERMVS_OK : ITERMVS_ERR_LAUNCH;
 }
 
+// Results-corrupting knock-out switches (timing-only forms of the kernels: csrc/experiments/*.patch, *.inc) must never reach a
+// product build: they exist only in experiment sources, and any of their macros on the command line of a build without
+// -DITERMVS_TUNING stops the compilation here.  (The Makefile additionally rejects every -DITERMVS_* it does not know.)
+#if !defined(ITERMVS_TUNING) && (defined(ITERMVS_TILE3_KO) || defined(ITERMVS_TILE_KO_BF16) || defined(ITERMVS_SWEEP_KO) || \
+                                 defined(ITERMVS_CORRNET_KO) || defined(ITERMVS_HEAD_KO))
+#error "knock-out switches (ITERMVS_*_KO*) compute WRONG results: experiment builds only (make TUNING=1 ...)"
+#endif
+
 // Tile shapes, persistence and kernel forms are compile-time choices of the shipped library (each one measured, DESIGN.md
 // section 4).  Only a library built with `make TUNING=1` (-DITERMVS_TUNING; the sweeps of tools/conv_bench.py) reads the
 // ITERMVS_* environment overrides; in the product build this is a constant nullptr and the overrides do not exist.

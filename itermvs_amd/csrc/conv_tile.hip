@@ -281,24 +281,6 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
             for (int u = 0; u < kParts; ++u) {
                 if (u + 1 < kParts) read_operands(u + 1, (u + 1) & 1);
                 if (prefetch) fetch_part(pf_soff, u);
-#ifdef ITERMVS_TILE_KO_BF16
-                // knock-out build (timing only, WRONG results; tools/build_variants.sh TILE_VARIANTS): the four fp32 MFMAs of a
-                // 16-channel tap are replaced by the three v_mfma_f32_16x16x32_bf16 a bf16x3 split would issue, fed with the
-                // operand registers as they are -- bounds what the matrix pipe's share of the kernel is worth
-                if constexpr (S == 4) {
-                    using bf8 = __attribute__((ext_vector_type(8))) __bf16;
-#pragma unroll
-                    for (int rep = 0; rep < ITERMVS_TILE_KO_BF16; ++rep)
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb)
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, av[u & 1][mb]),
-                                                                                      __builtin_bit_cast(bf8, bv[u & 1][nb]), acc[mb][nb], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    continue;
-                }
-#endif
 #pragma unroll
                 for (int s2 = 0; s2 < S; ++s2)
 #pragma unroll

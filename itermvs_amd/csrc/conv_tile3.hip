@@ -69,9 +69,6 @@ struct Tile3Geom {
 #ifndef ITERMVS_TILE3_DBUF
 #define ITERMVS_TILE3_DBUF 1
 #endif
-#ifndef ITERMVS_TILE3_KO          // knock-out builds (tools only): bit 0 no split arithmetic, 1 one LDS store per item, 2 one operand read per block,
-#define ITERMVS_TILE3_KO 0        // 3 no MFMAs, 4 no staging loads, 5 no epilogue
-#endif
 
 template <int MB, int STRIDE, int DIL, int TH, int TWT, int CPS>
 __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
@@ -170,12 +167,8 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
         for (int e = 0; e < kLoads; ++e)
             if (e * kParts / kLoads == part) {
                 const int c = e / (G::ITEMS * 8), j = (e / 8) % G::ITEMS, k = e % 8;
-#if ITERMVS_TILE3_KO & 16     // knock-out: no staging loads
-                stage[c][j][k] = __uint_as_float(goff[j] + soff + (uint32_t)k);
-#else
                 stage[c][j][k] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(ir, goff[j], soff + c * chunk_b + k * plane * 4u, 0));
-#endif
             }
     };
     auto fetch = [&](uint32_t soff) {
@@ -219,21 +212,13 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             uint32_t h, m, l;
-#if ITERMVS_TILE3_KO & 1      // knock-out (timing only, WRONG results): no split arithmetic
-                            h = __float_as_uint(stage[c][j][2 * k]); m = __float_as_uint(stage[c][j][2 * k + 1]); l = h ^ m;
-#else
                             split_pair(stage[c][j][2 * k], stage[c][j][2 * k + 1], h, m, l);
-#endif
                             H[k] = h; M[k] = m; L[k] = l;
                         }
                         char* d = tile + c * CH_BYTES + loff[j];
                         *reinterpret_cast<u32x4*>(d) = H;
-#if ITERMVS_TILE3_KO & 2      // knock-out: one LDS store per item instead of three
-                        asm volatile("" ::"v"(M), "v"(L));
-#else
                         *reinterpret_cast<u32x4*>(d + 2 * PLB) = M;
                         *reinterpret_cast<u32x4*>(d + 4 * PLB) = L;
-#endif
                     }
             __syncthreads();
             const int wst = st * (CPS * 9 * WBLK);
@@ -258,24 +243,15 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
                 for (int mb = 0; mb < MB; ++mb) {
                     const int o = wst + (c * 9 + tap) * WBLK + mb * 16 * 32;
                     a1[set][mb] = *reinterpret_cast<const bf8*>(abase + o);
-#if ITERMVS_TILE3_KO & 4      // knock-out: one A and one B operand read per block instead of 3 + 2
-                    a2[set][mb] = a1[set][mb];
-                    a3[set][mb] = a1[set][mb];
-#else
                     a2[set][mb] = *reinterpret_cast<const bf8*>(abase + o + WPL);
                     a3[set][mb] = *reinterpret_cast<const bf8*>(abase3 + o);
-#endif
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const int r = nb / TWT, cc = nb % TWT;
                     const int o = c * CH_BYTES + ((r * STRIDE + ky * DIL) * G::IN_W + cc * 16 * STRIDE + kx * DIL) * 16;
                     b1[set][nb] = *reinterpret_cast<const bf8*>(bbase1 + o);
-#if ITERMVS_TILE3_KO & 4
-                    b3[set][nb] = b1[set][nb];
-#else
                     b3[set][nb] = *reinterpret_cast<const bf8*>(bbase3 + o);
-#endif
                 }
             };
             if constexpr (kDbuf) read_operands(0, 0);
@@ -288,11 +264,6 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
                 }
                 if (prefetch) fetch_part(pf_soff, u);
                 const int s = kDbuf ? (u & 1) : 0;
-#if ITERMVS_TILE3_KO & 8
-                asm volatile("" ::"v"(a1[s][0]), "v"(a2[s][0]), "v"(a3[s][0]), "v"(b1[s][0]), "v"(b3[s][0]));
-                __builtin_amdgcn_sched_barrier(0);
-                continue;
-#endif
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -341,18 +312,7 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
                 e.Cout = a.split;
             }
         }
-#if ITERMVS_TILE3_KO & 32     // knock-out: no epilogue (one dword per lane keeps the accumulators alive)
-        {
-            float keep = 0.0f;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) keep += acc[mb][nb][0] + acc[mb][nb][1] + acc[mb][nb][2] + acc[mb][nb][3];
-            if (keep == 1.2345e-30f) e.out[0] = keep;
-        }
-#else
         conv_epilogue<MB, NB>(e, acc, me, q, pix_off, py, px);
-#endif
         if (wn >= a.total) break;
         w = wn;
         cur = nxt;

@@ -247,37 +247,48 @@ class InferenceEngine:
             self._ws[key] = ws
         return ws
 
-    def _release_owner(self, token: int) -> None:
+    def _release_owner(self, token: int, streams: dict = None) -> None:
         """drop the private workspaces of a GraphedRunner that went away (its finalizer calls this -- from the garbage collector,
-        i.e. at ANY point, also in the middle of another runner's stream capture, where every synchronising or recording HIP
-        call is illegal and invalidates that capture).  The buffers were allocated on the runner's capture stream while its graph
-        replays on the callers' streams, so a replay may still be writing them: they are parked, and handed back to the caching
-        allocator by ``_purge_released`` once an event recorded AFTER the drop has completed."""
+        i.e. at ANY point, in any thread, also in the middle of another runner's stream capture, where every synchronising or
+        recording HIP call is illegal and invalidates that capture).  The buffers were allocated on the runner's capture stream
+        while its graph replays on the callers' streams, so a replay may still be writing them: they are parked, and handed back
+        to the caching allocator by ``_purge_released`` once events recorded AFTER the drop ON EVERY STREAM THE RUNNER EVER
+        REPLAYED ON (``streams``: the runner's own record, handed over by value) have completed -- the collector's current
+        stream says nothing about where the replays ran."""
         keys = [k for k in self._ws if k[3] == token]
         if not keys:
             return
         parked = [self._ws.pop(k) for k in keys]
-        ev = None
+        streams = dict(streams or {})
+        self._released.append((parked, self._guard_events(streams) or streams))    # a dict = "not guarded yet"
+
+    def _guard_events(self, streams: dict):
+        """events recorded now on each of ``streams`` (plus the current one); None while a capture is in progress or at shutdown"""
         try:
-            if not torch.cuda.is_current_stream_capturing():
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            todo = dict(streams or {})
+            cur = torch.cuda.current_stream(self.device)
+            todo.setdefault(cur.cuda_stream, cur)
+            evs = []
+            for st in todo.values():
                 ev = torch.cuda.Event()
-                ev.record()                      # everything enqueued so far on the stream that replayed
+                ev.record(st)                    # everything enqueued so far on a stream that replayed
+                evs.append(ev)
+            return evs
         except Exception:                        # interpreter shutdown: the context may already be gone
-            ev = None
-        self._released.append((parked, ev))
+            return None
 
     def _purge_released(self) -> None:
         """free parked workspaces whose guarding event has completed (called where no capture is in progress)"""
         if not self._released or torch.cuda.is_current_stream_capturing():
             return
         keep = []
-        for parked, ev in self._released:
-            if ev is None:                       # dropped during a capture: guard it now, free it at a later purge
-                ev = torch.cuda.Event()
-                ev.record()
-                keep.append((parked, ev))
-            elif not ev.query():
-                keep.append((parked, ev))
+        for parked, guard in self._released:
+            if isinstance(guard, dict):          # dropped during a capture: guard it now, free it at a later purge
+                keep.append((parked, self._guard_events(guard) or guard))
+            elif not all(ev.query() for ev in guard):
+                keep.append((parked, guard))
         self._released = keep
 
     # -- stages (each reads / writes the workspace; see the module docstring) ---------------------
@@ -449,10 +460,10 @@ class InferenceEngine:
             raise AssertionError("nan in proj (singular or non-finite camera matrix, module.py:83,87)")
 
 
-def _release_workspace(engine_ref, token: int) -> None:
+def _release_workspace(engine_ref, token: int, streams: dict) -> None:
     engine = engine_ref()
     if engine is not None:
-        engine._release_owner(token)
+        engine._release_owner(token, streams)
 
 
 class GraphedRunner:
@@ -492,7 +503,10 @@ class GraphedRunner:
         # engine._ws for the engine's lifetime
         self._ws_token = next(engine._owner_tokens)
         engine._ws_owner = self._ws_token
-        weakref.finalize(self, _release_workspace, weakref.ref(engine), self._ws_token)
+        # every stream this runner's graph is ever launched on ({handle: Stream}); the finalizer gets the dict itself, so what
+        # __call__ / replay() add later is seen when the runner is dropped
+        self._replay_streams = {self.stream.cuda_stream: self.stream}
+        weakref.finalize(self, _release_workspace, weakref.ref(engine), self._ws_token, self._replay_streams)
         try:
             with torch.cuda.stream(self.stream):
                 for _ in range(2):                              # warm-up: allocates the workspaces, primes caches
@@ -556,5 +570,11 @@ class GraphedRunner:
             else:
                 for d, t in zip(dst, src):
                     d.copy_(t, non_blocking=True)
+        return self.replay()
+
+    def replay(self):
+        """launch the captured graph on the current stream as it is (static inputs already hold the sample)"""
+        cur = torch.cuda.current_stream(self.imgs.device)
+        self._replay_streams.setdefault(cur.cuda_stream, cur)
         self.graph.replay()
         return self.out

@@ -34,7 +34,9 @@ class CapturedTrainStep:
     depth_min, depth_max, depth_gt, mask) like ``train.synthetic_batch`` / the reference's collated sample, always of the
     same shapes.  The optimizer must be created with ``capturable=True`` (its step counter lives on the device); learning
     rate schedules keep working when the rate is a device tensor (``lr=torch.tensor(...)``), which torch's schedulers fill
-    in place.  ``check()`` raises the deferred NaN assert of module.py:83,87 (one 4-byte read-back)."""
+    in place.  ``check()`` raises the deferred NaN assert of module.py:83,87 (one 4-byte read-back); the flagged step itself
+    was a no-op on the weights (see ``_step``).  The flag is shared with every forward of the model: call ``check()`` after
+    validation forwards too, so a bad validation sample is not attributed to the next training step."""
 
     def __init__(self, model, optimizer, regress: bool, clip: float = 2.0, warmup: int = 3):
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
@@ -63,7 +65,21 @@ class CapturedTrainStep:
         loss.backward()
         ddp.flat_allreduce_gradients(self.params)
         torch.nn.utils.clip_grad_norm_(self.params, self.clip)
+        # The reference asserts on a NaN projection BEFORE any update (module.py:83,87); here the assert is deferred to
+        # ``check()``, so a flagged step must leave the weights alone: its (NaN) gradients are replaced by zeros and the
+        # learning rate of this one step by 0 -- the parameters do not move, Adam's moments only decay by their betas
+        # (they stay finite), and ``check()`` raises afterwards on a model that can still be saved or resumed.
+        ok = self.nan_flag == 0
+        zero = torch.zeros((), device=ok.device)
+        for p in self.params:
+            if p.grad is not None:
+                p.grad = torch.where(ok, p.grad, zero)
+        rates = [(g, g["lr"].clone()) for g in self.opt.param_groups if torch.is_tensor(g["lr"])]
+        for g, _ in rates:
+            g["lr"].mul_(ok.to(g["lr"].dtype).reshape(g["lr"].shape))
         self.opt.step()
+        for g, saved in rates:
+            g["lr"].copy_(saved)
         err = (out["depths_upsampled"][0].detach() - gt["level_0"]).abs().mean()
         return loss.detach(), err
 

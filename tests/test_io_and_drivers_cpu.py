@@ -46,6 +46,50 @@ def test_train_recipe_and_checkpoint_format(tmp_path):
     assert args.regress and args.resume and args.lr == 0.002 and args.epochs == 16
 
 
+def test_checkpoint_optimizer_state_is_mode_independent(tmp_path):
+    """train.py:152-157 / :103-117: a checkpoint's optimizer state must not carry the saving run's launch mode.  ``--graph``
+    keeps the rate and Adam's counters in tensors and sets ``capturable``; ``optimizer.load_state_dict`` REPLACES the fresh
+    groups with the saved ones, so without ``restore_optimizer_mode`` a resumed run inherits the wrong mode (an eager checkpoint
+    makes CapturedTrainStep raise, a --graph checkpoint freezes the learning-rate schedule inside the graph)."""
+    import train as T
+    w = torch.nn.Parameter(torch.ones(3))
+    # what a --graph run's optimizer looks like (CPU stand-in: tensor rate, capturable flag in the group)
+    opt = torch.optim.Adam([w], lr=1e-3)
+    w.grad = torch.ones(3)
+    opt.step()
+    opt.param_groups[0]["lr"] = torch.tensor(5e-4)
+    opt.param_groups[0]["capturable"] = True
+    sd = T.portable_optimizer_state(opt)
+    g = sd["param_groups"][0]
+    assert isinstance(g["lr"], float) and abs(g["lr"] - 5e-4) < 1e-9 and g["capturable"] is False
+    assert all(st["step"].device.type == "cpu" and float(st["step"]) == 1.0 for st in sd["state"].values())
+    torch.save({"optimizer": sd}, str(tmp_path / "o.ckpt"))
+    sd = torch.load(str(tmp_path / "o.ckpt"), map_location="cpu", weights_only=False)["optimizer"]
+    # eager resume from it: plain float rate, host counters, the scheduler moves the rate
+    w2 = torch.nn.Parameter(torch.ones(3))
+    opt2 = torch.optim.Adam([w2], lr=1e-3)
+    opt2.load_state_dict(sd)
+    T.restore_optimizer_mode(opt2, graph=False, dev="cpu")
+    g2 = opt2.param_groups[0]
+    assert isinstance(g2["lr"], float) and g2["capturable"] is False
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt2, [1], gamma=0.5)
+    w2.grad = torch.ones(3)
+    opt2.step()
+    sched.step()
+    assert abs(opt2.param_groups[0]["lr"] - 2.5e-4) < 1e-9
+    assert float(next(iter(opt2.state.values()))["step"]) == 2.0
+    # a "graph" resume: the rate becomes a tensor the scheduler fills IN PLACE (the captured step reads that tensor)
+    w3 = torch.nn.Parameter(torch.ones(3))
+    opt3 = torch.optim.Adam([w3], lr=1e-3)
+    opt3.load_state_dict(sd)
+    T.restore_optimizer_mode(opt3, graph=True, dev="cpu")
+    lr_t = opt3.param_groups[0]["lr"]
+    assert torch.is_tensor(lr_t) and opt3.param_groups[0]["capturable"] is True
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt3, [1], gamma=0.5)
+    sched.step()
+    assert opt3.param_groups[0]["lr"] is lr_t and abs(float(lr_t) - 2.5e-4) < 1e-10
+
+
 def test_train_driver_builds_the_batch_it_is_asked_for():
     """train.py --batch_size N (train.py:89-90, train_dtu.sh: 4): B = N different samples per rank, the reference's collated
     training schema (datasets/dtu_yao.py:227-232); ranks and steps never see the same scene"""

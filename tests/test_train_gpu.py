@@ -325,3 +325,73 @@ def test_captured_training_step_equals_the_eager_step():
     assert float(apart.max()) <= 0.5 * float(moved.max()), (float(apart.max()), float(moved.max()))
     with pytest.raises(ValueError):
         CapturedTrainStep(graphed, torch.optim.Adam(graphed.parameters(), lr=1e-3), regress=True)
+
+
+@pytest.mark.gpu
+def test_resume_across_launch_modes(tmp_path):
+    """reference train.py:103-117,152-157 (--resume) with this repo's --graph: a checkpoint written by an eager run resumes as a
+    captured step and one written by a captured run resumes eagerly -- ``optimizer.load_state_dict`` replaces the param groups
+    with the saved ones, ``train.restore_optimizer_mode`` puts this run's mode back (capturable flag, tensor / float learning
+    rate, where Adam's counters live) and MultiStepLR still reaches the replayed step."""
+    import train as T
+    from itermvs_amd import synthetic
+    from itermvs_amd.net import Pipeline
+    from itermvs_amd.train_step import CapturedTrainStep
+    to = lambda d: {k: v.to(DEV) for k, v in d.items()}  # noqa: E731
+    batches = []
+    for i in range(5):
+        imgs, projs, dmin, dmax, gt, mask = synthetic.make_training_batch(1, num_views=3, height=64, width=96, seed=7 * i)
+        batches.append((to(imgs), to(projs), dmin.to(DEV), dmax.to(DEV), to(gt), to(mask)))
+
+    def fresh():
+        m = Pipeline(iteration=1, test=False)
+        m.load_state_dict(load_weights("seed0"))
+        return m.to(DEV).train()
+
+    # eager run -> checkpoint -> --graph resume
+    m = fresh()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-5)
+    T.train_step(m, opt, batches[0], True)
+    T.save_checkpoint(str(tmp_path / "a" / "model_000000.ckpt"), 0, m, opt)
+    state = torch.load(str(tmp_path / "a" / "model_000000.ckpt"), map_location="cpu", weights_only=False)
+    g = state["optimizer"]["param_groups"][0]
+    assert isinstance(g["lr"], float) and g.get("capturable", False) is False
+    m2 = fresh()
+    m2.load_checkpoint_state(state["model"], strict=False)
+    opt2 = torch.optim.Adam(m2.parameters(), lr=torch.tensor(1e-5, device=DEV), capturable=True)
+    opt2.load_state_dict(state["optimizer"])
+    T.restore_optimizer_mode(opt2, True, DEV)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt2, [1], gamma=0.5)
+    cap = CapturedTrainStep(m2, opt2, regress=True, warmup=1)
+    before = [p.detach().clone() for p in m2.parameters()]
+    for bt in batches[1:4]:
+        cap.step(bt)
+    cap.check()
+    assert cap.graph is not None
+    lr_t = opt2.param_groups[0]["lr"]
+    sched.step()                                              # halves the rate IN the tensor the graph reads
+    assert opt2.param_groups[0]["lr"] is lr_t and abs(float(lr_t) - 5e-6) < 1e-10
+    mid = [p.detach().clone() for p in m2.parameters()]
+    cap.step(batches[4])
+    torch.cuda.synchronize()
+    step_full = max(float((a - b).abs().max()) for a, b in zip(before, mid))
+    step_half = max(float((a - b).abs().max()) for a, b in zip(mid, m2.parameters()))
+    assert 0 < step_half <= 0.75e-5 and step_full >= 1e-5 * 0.9, (step_half, step_full)   # Adam moves ~lr per step
+    steps = {float(st["step"]) for st in opt2.state.values()}
+    assert steps == {5.0}, steps                              # 1 eager + 4 resumed steps, counted on the device
+
+    # --graph run -> checkpoint -> eager resume
+    T.save_checkpoint(str(tmp_path / "b" / "model_000001.ckpt"), 1, m2, opt2)
+    state = torch.load(str(tmp_path / "b" / "model_000001.ckpt"), map_location="cpu", weights_only=False)
+    g = state["optimizer"]["param_groups"][0]
+    assert isinstance(g["lr"], float) and g["capturable"] is False
+    assert all(st["step"].device.type == "cpu" for st in state["optimizer"]["state"].values())
+    m3 = fresh()
+    m3.load_checkpoint_state(state["model"], strict=False)
+    opt3 = torch.optim.Adam(m3.parameters(), lr=1e-5)
+    opt3.load_state_dict(state["optimizer"])
+    T.restore_optimizer_mode(opt3, False, DEV)
+    g3 = opt3.param_groups[0]
+    assert isinstance(g3["lr"], float) and abs(g3["lr"] - 5e-6) < 1e-10 and g3["capturable"] is False
+    loss, _ = T.train_step(m3, opt3, batches[0], True)
+    assert loss == loss and {float(st["step"]) for st in opt3.state.values()} == {6.0}

@@ -20,4 +20,4 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- $CMD > $OUT.pass$i.log 2>&1
   echo "pass $i ($set): exit $?"
 done
-python $R/tools/pmc_summary.py $OUT $R/gpurun_out/${TAG}_pmc_kernels.json | tail -60
+PMC_CMD_USED="$CMD" python $R/tools/pmc_summary.py $OUT $R/gpurun_out/${TAG}_pmc_kernels.json | tail -60

@@ -54,8 +54,21 @@ for k, cs in sorted(vals.items()):
         # MFMA-busy cycles summed over the 1024 SIMDs / (busy cycles of the SQs x SIMDs per SQ): see profiles/README.md
         e["mfma_busy_cycles_per_simd"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0
     kernels[k] = e
-res = {"workload": [5, 512, 640, 1],
-       "source": "rocprofv3 --pmc (one pass per counter set, tools/pmc_kernels.sh) on `python bench.py --steps 3 --warmup 2 --eager --minimal`; FETCH_SIZE x2 per MI355X_MICROARCH.md",
+# the workload the counters belong to = the flags of the profiled command (tools/pmc_kernels.sh exports it as PMC_CMD_USED);
+# bench.py takes roofline.traffic from this file only when `workload` equals what it runs
+import os
+cmd = os.environ.get("PMC_CMD_USED", "python bench.py --steps 3 --warmup 2 --repeats 1 --eager --minimal")
+
+
+def flag(name: str, default: int) -> int:
+    m = re.search(rf"--{name}[ =](\d+)", cmd)
+    return int(m.group(1)) if m else default
+
+
+fd = re.search(r"--feature-dtype[ =](\w+)", cmd)
+res = {"workload": [flag("views", 5), flag("height", 512), flag("width", 640), flag("batch", 1)],
+       "iterations": flag("iters", 4), "feature_dtype": fd.group(1) if fd else "fp32",
+       "source": f"rocprofv3 --pmc (one pass per counter set, tools/pmc_kernels.sh) on `{re.sub(r'/[^ ]*/bench.py', 'bench.py', cmd)}`; FETCH_SIZE x2 per MI355X_MICROARCH.md",
        "kernels": kernels}
 json.dump(res, open(out, "w"), indent=1)
 for k, e in kernels.items():

@@ -38,14 +38,14 @@ s = synthetic.make_sample(batch=1, num_views=args.views, height=args.height, wid
 pj = {l: s["proj_matrices"][f"level_{l}"].float().to(dev) for l in (1, 2, 3)}
 r = GraphedRunner(eng, s["imgs"]["level_0"].float().to(dev), pj, s["depth_min"].float().to(dev), s["depth_max"].float().to(dev))
 for _ in range(10):
-    r.graph.replay()
+    r.replay()
 torch.cuda.synchronize()
 best = 1e9
 for rep in range(5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(args.steps):
-        r.graph.replay()
+        r.replay()
     e1.record()
     torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / args.steps)

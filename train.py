@@ -76,11 +76,49 @@ def synthetic_batch(args, step: int, rank: int, dev, world: int = 1):
     return to(imgs), to(projs), dmin.to(dev), dmax.to(dev), to(gt), to(mask)
 
 
+def portable_optimizer_state(optimizer) -> dict:
+    """``optimizer.state_dict()`` in the form the reference's checkpoints have (train.py:152-157), whatever mode produced it:
+    the learning rate a Python float and ``capturable`` off in every group, Adam's step counters on the host.  (A ``--graph``
+    run keeps the rate and the counters in device tensors; written as they are they would be baked into -- or rejected by --
+    the next run's optimizer.)"""
+    sd = optimizer.state_dict()
+    groups = []
+    for g in sd["param_groups"]:
+        g = dict(g)
+        g["lr"] = float(g["lr"])
+        if "capturable" in g:
+            g["capturable"] = False
+        groups.append(g)
+    state = {}
+    for k, st in sd["state"].items():
+        st = dict(st)
+        if torch.is_tensor(st.get("step")):
+            st["step"] = st["step"].detach().to("cpu", torch.float32)
+        state[k] = st
+    return {"state": state, "param_groups": groups}
+
+
+def restore_optimizer_mode(optimizer, graph: bool, dev) -> None:
+    """after ``optimizer.load_state_dict``: the loaded groups REPLACE the freshly built ones, so ``capturable`` and the type of
+    ``lr`` would come from the checkpoint.  Put back what this run asked for: ``--graph`` = capturable, the rate and Adam's step
+    counters in device tensors (MultiStepLR fills the rate in place and the captured step reads it); eager = plain float rate,
+    host counters."""
+    for g in optimizer.param_groups:
+        g["capturable"] = bool(graph)
+        lr = float(g["lr"])
+        g["lr"] = torch.tensor(lr, device=dev) if graph else lr
+        if "initial_lr" in g:
+            g["initial_lr"] = float(g["initial_lr"])
+    for st in optimizer.state.values():
+        if torch.is_tensor(st.get("step")):
+            st["step"] = st["step"].detach().to(dev if graph else "cpu", torch.float32)
+
+
 def save_checkpoint(path: str, epoch: int, model: torch.nn.Module, optimizer) -> None:
     """train.py:152-157: keys carry the DataParallel 'module.' prefix so the reference's eval.py loads them."""
     os.makedirs(os.path.dirname(path), exist_ok=True)
     torch.save({"epoch": epoch, "model": {"module." + k: v.cpu() for k, v in model.state_dict().items()},
-                "optimizer": optimizer.state_dict()}, path)
+                "optimizer": portable_optimizer_state(optimizer)}, path)
 
 
 def latest_checkpoint(logdir: str):
@@ -165,6 +203,7 @@ def main() -> None:
         model.load_checkpoint_state(state["model"], strict=False)
         if args.resume:
             optimizer.load_state_dict(state["optimizer"])
+            restore_optimizer_mode(optimizer, args.graph, dev)          # the loaded groups carry the SAVING run's mode
             start_epoch = state["epoch"] + 1
     ddp.broadcast_parameters(model)
     milestones, gamma = parse_lrepochs(args.lrepochs)
@@ -197,6 +236,8 @@ def main() -> None:
         if rank == 0 and (epoch + 1) % args.save_freq == 0:
             save_checkpoint("{}/model_{:0>6}.ckpt".format(args.logdir, epoch), epoch, model, optimizer)
         means = validate(model, args, rank, world, dev)                                   # train.py:160-175
+        if captured is not None:
+            captured.check()                       # a projection flagged by a validation forward belongs to THIS phase
         if rank == 0:
             print("avg_test_scalars:", means)
     shard.barrier()
