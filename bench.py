@@ -260,6 +260,12 @@ def main() -> None:
     dev_index = local_rank % max(1, torch.cuda.device_count())      # (ranks share a GPU only in the gloo test of the N > 1 path)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # this rank's host threads and (first-touch) pinned buffers next to its GPU: before any pinned allocation below
+    affinity = shard.bind_to_gpu_numa(dev_index)
+    # box calibration (two fixed micro-kernels, <= 0.3 s): what THIS chip delivers, printed beside `value` so that driver
+    # lines from different boxes of the pool can be compared (`value_normalised`)
+    from itermvs_amd import benchmarks as _bm
+    box = _bm.box_probe(dev) if rank == 0 else None
 
     # graph mode, one stream: TWO runners replayed alternately on that stream -- while step i runs, the event pairs
     # embedded in the graph of step i-1 (around its corr_iter / corr_init launches) are read, so every launch of the
@@ -533,8 +539,11 @@ def main() -> None:
                        "parallelism": f"ref-view sharding x{world}, no collective",
                        "projection": args.projection, "conv_arithmetic": args.conv_arithmetic,
                        "process_group": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+                       "cpu_affinity": affinity,
                        "algorithmic_MB_per_depth_map": b_map / 1e6},
             "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms)},   # each rank's own median region (straggler check)
+            # this box against the pool (benchmarks.POOL_MEDIAN): `value` x (pool median / this box), per probe
+            "box": box, "value_normalised": _bm.normalised(value, box), "box_pool_median": _bm.POOL_MEDIAN,
             "roofline": roofline,
             "other_configs": other,
             "roofline_conv": conv_roofline,
@@ -545,8 +554,13 @@ def main() -> None:
         if with_transfers is not None:
             result["value_with_transfers"] = with_transfers.get("uint8_images", with_transfers)["value"]
         if world == 1 and not args.no_cpu_baseline:
+            shard.restore_affinity()                   # the CPU path gets the whole host, not the GPU's NUMA node
             result["cpu_baseline"] = cpu_baseline(args)
             result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
+        elif world > 1:
+            # (the CPU port, the other BASELINE shapes and the training legs are timed on rank 0 of a 1-GPU run only)
+            result["cpu_baseline"] = "world>1: see the N=1 line"
+            result["other_configs"] = "world>1: see the N=1 line"
         # the driver keeps the tail of stdout: 6 significant digits on everything but the headline numbers keeps the line short
         keep = {k: result[k] for k in ("value", "ms_per_step")}
         result = _round_floats(result)

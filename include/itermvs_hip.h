@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define ITERMVS_ABI_VERSION 8
+#define ITERMVS_ABI_VERSION 9
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -138,6 +138,14 @@ int itermvs_ref_quarter_compose(const itermvs_fmap* r1, const itermvs_fmap* r2, 
  * cameras + depth range) into the static input buffers a captured hipGraph reads (engine.GraphedRunner).  src / dst / bytes
  * are HOST arrays. */
 int itermvs_copy_multi(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream);
+
+/* itermvs_box_probe -- a fixed micro-kernel for bench.py's box calibration (no reference counterpart: the reference prints
+ * wall-clock only, eval.py:130-137): `blocks` workgroups of 4 waves issue `iters` x 4 independent v_mfma_f32_16x16x4_f32 per
+ * wave (2*16*16*4 FLOP each) and store one float per thread to sink[blocks*256].  clocks (device, 2 x uint64, may be NULL):
+ * workgroup 0 writes its shader-clock ticks (s_memtime) and its constant-rate 100 MHz ticks (s_memrealtime) across the loop
+ * -> the sustained shader clock of THIS chip under matrix load.  The companion bandwidth probe is itermvs_copy_multi on a
+ * 256 MB buffer.  Timed by the caller with events on `stream`. */
+int itermvs_box_probe(float* sink, int32_t blocks, int32_t iters, uint64_t* clocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * itermvs_corr_iter -- models/itermvs.py:84-120 (Evaluation.forward, iteration branch, up to

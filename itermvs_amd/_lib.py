@@ -14,7 +14,7 @@ MAX_SRC = 16
 MAX_HYP = 8
 GROUPS = 8
 F32, F16, BF16 = 0, 1, 2      # itermvs_dtype: storage type of feature maps
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitermvs_hip.so")
@@ -96,6 +96,7 @@ PROTOTYPES = {
                                          C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                          C.c_void_p]),
     "itermvs_copy_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p]),
+    "itermvs_box_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "itermvs_corr_iter": (C.c_int, [C.POINTER(CorrIterParams), C.c_void_p]),
     "itermvs_corr_init": (C.c_int, [C.POINTER(CorrInitParams), C.c_void_p]),
     "itermvs_tap_indices": (C.c_int, [C.POINTER(TapParams), C.c_void_p]),

@@ -25,6 +25,58 @@ def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int, e: int = 4
     return it, init, (init + iters * it) / batch
 
 
+# Pool reference of the box probe: medians over the fresh MI355X boxes this repository was measured on (profiles/r06_box_probe.md
+# lists every box).  `value_normalised` = value x (POOL_MEDIAN / this box), one figure per probe -- `value` itself is never touched.
+POOL_MEDIAN = {"mfma_f32_tflops": None, "copy_GBps": None, "sclk_MHz": None}
+
+
+def box_probe(dev, repeats: int = 5) -> Dict[str, float]:
+    """Two fixed micro-kernels that say what THIS box (chip, clocks, HBM stack) delivers, run before the timed regions
+    (<= 0.3 s together): (1) itermvs_box_probe -- 2048 workgroups x 4 waves x 4 independent fp32 MFMAs, 3000 rounds: sustained
+    fp32-MFMA TFLOP/s and the shader clock it ran at (s_memtime ticks per 100 MHz s_memrealtime tick); (2) a 256 MB float4
+    stream copy (itermvs_copy_multi: read + write = 512 MB of traffic).  Best of ``repeats`` event-bracketed launches each."""
+    from . import ops
+    blocks, iters = 2048, 3000
+    sink = torch.empty((blocks * 256,), device=dev)
+    clocks = torch.zeros((2,), device=dev, dtype=torch.int64)
+    src = torch.empty((64 * 1024 * 1024,), device=dev)            # 256 MB
+    src.normal_()
+    dst = torch.empty_like(src)
+    ops.box_probe(sink, blocks, 50, clocks)
+    ops.copy_multi([dst], [src])
+    torch.cuda.synchronize(dev)
+    best_m, best_c, mhz = None, None, 0.0
+    for _ in range(repeats):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        ops.box_probe(sink, blocks, iters, clocks)
+        e1.record()
+        ops.copy_multi([dst], [src])
+        e2.record()
+        torch.cuda.synchronize(dev)
+        tm, tc = e0.elapsed_time(e1), e1.elapsed_time(e2)
+        if best_m is None or tm < best_m:
+            best_m = tm
+            c = clocks.tolist()
+            mhz = c[0] / max(c[1], 1) * 100.0
+        best_c = tc if best_c is None else min(best_c, tc)
+    flops = 2.0 * 16 * 16 * 4 * 4 * iters * blocks * 4
+    out = {"mfma_f32_tflops": flops / (best_m * 1e-3) / 1e12, "copy_GBps": 2.0 * src.numel() * 4 / (best_c * 1e-3) / 1e9,
+           "sclk_MHz": mhz}
+    del sink, src, dst
+    torch.cuda.empty_cache()
+    return out
+
+
+def normalised(value: float, box: Dict[str, float]) -> Optional[Dict[str, float]]:
+    """``value`` scaled to the pool-median box, per probe (None until POOL_MEDIAN is filled in)"""
+    out = {}
+    for k, ref in POOL_MEDIAN.items():
+        if ref and box.get(k):
+            out["by_" + k] = value * ref / box[k]
+    return out or None
+
+
 def shape_leg(dev, views: int, height: int, width: int, iters: int, feature_dtype: str = "fp32", warmup: int = 5,
               steps: int = 10, conv_arithmetic: str = "bf16x3") -> Dict[str, object]:
     """depth-maps/s of ONE captured hipGraph (one reference view per replay, inputs resident) at another shape than the

@@ -218,3 +218,39 @@ extern "C" int itermvs_copy_multi(const void* const* src, void* const* dst, cons
     hipLaunchKernelGGL(copy_multi_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
     return itermvs_launch_status();
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// itermvs_box_probe: bench.py's box calibration (a fixed fp32-MFMA issue loop; clocks of workgroup 0)
+// ---------------------------------------------------------------------------------------------
+namespace itermvs {
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__global__ void __launch_bounds__(256) box_probe_kernel(float* __restrict__ sink, int iters, unsigned long long* __restrict__ clocks) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    sink[blockIdx.x * 256 + threadIdx.x] = s;
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (clocks && blockIdx.x == 0 && threadIdx.x == 0) {
+        clocks[0] = c1 - c0;
+        clocks[1] = r1 - r0;
+    }
+}
+}  // namespace itermvs
+
+extern "C" int itermvs_box_probe(float* sink, int32_t blocks, int32_t iters, uint64_t* clocks, void* stream) {
+    ITERMVS_RETURN_IF(!sink, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(blocks < 1 || iters < 1, ITERMVS_ERR_DIMS);
+    hipLaunchKernelGGL(itermvs::box_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, sink, iters,
+                       reinterpret_cast<unsigned long long*>(clocks));
+    return itermvs_launch_status();
+}

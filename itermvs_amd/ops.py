@@ -163,6 +163,14 @@ def copy_multi(dst: Sequence[Tensor], src: Sequence[Tensor]) -> None:
     check(_lib.load().itermvs_copy_multi(sp, dp, nb, n, _stream()), "itermvs_copy_multi")
 
 
+def box_probe(sink: Tensor, blocks: int, iters: int, clocks: Optional[Tensor] = None) -> None:
+    """itermvs_box_probe: the fixed fp32-MFMA issue loop of bench.py's box calibration (sink: float32[blocks*256];
+    clocks: int64[2] -> shader-clock ticks, 100 MHz ticks of workgroup 0)"""
+    if not sink.is_cuda or sink.dtype != torch.float32 or sink.numel() < blocks * 256:
+        raise RuntimeError("box_probe: sink must be a float32 CUDA/ROCm tensor of blocks*256 elements")
+    check(_lib.load().itermvs_box_probe(sink.data_ptr(), blocks, iters, _ptr(clocks), _stream()), "itermvs_box_probe")
+
+
 def ref_quarter_compose(ref1: Tensor, ref2: Tensor, ref3: Tensor, mats: Tensor, nan_flag: Optional[Tensor], depth_range):
     """ref_quarter and compose_proj (with the inverse depth range) in ONE launch -- two independent pieces of work that both
     precede the correlation kernels.  Returns (ref_q, proj, inv_min, inv_max)."""

@@ -52,6 +52,114 @@ def init_distributed(backend: str = None, force: bool = False) -> Tuple[int, int
     return rank, local_rank, world
 
 
+# -- host side of a rank: CPUs next to its GPU ----------------------------------------------------------------------------
+# Eight ranks on a two-socket node: a rank whose pinned staging buffers (value_with_transfers, eval.py's prefetcher) and
+# Python threads live on the other socket pays the inter-socket hop on every H2D / D2H copy.  Each rank therefore binds itself
+# to the CPUs of its GPU's NUMA node BEFORE it allocates pinned memory (first touch then places the buffers on that node).
+# The reference has no counterpart (one process, nn.DataParallel: eval.py:119, train.py:95).
+_ORIGINAL_AFFINITY = None
+
+
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' (sysfs cpulist) -> [0, 1, 2, 3, 8, 10, 11]"""
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            lo, hi = part.split("-", 1)
+            cpus.extend(range(int(lo), int(hi) + 1))
+        else:
+            cpus.append(int(part))
+    return sorted(set(cpus))
+
+
+def format_cpulist(cpus: Sequence[int]) -> str:
+    """[0, 1, 2, 3, 8, 10, 11] -> '0-3,8,10-11'"""
+    out, run = [], []
+    for c in sorted(set(cpus)):
+        if run and c == run[-1] + 1:
+            run.append(c)
+            continue
+        if run:
+            out.append(f"{run[0]}-{run[-1]}" if len(run) > 1 else str(run[0]))
+        run = [c]
+    if run:
+        out.append(f"{run[0]}-{run[-1]}" if len(run) > 1 else str(run[0]))
+    return ",".join(out)
+
+
+def pci_numa_cpus(bdf: str, sysfs_root: str = "/sys"):
+    """(numa node, CPUs local to it) of the PCI function ``bdf`` ('0000:c1:00.0'), read from sysfs: ``numa_node`` +
+    ``local_cpulist`` of the device, else the node's own ``cpulist``; (None, []) when the platform does not say (node -1)"""
+    base = os.path.join(sysfs_root, "bus", "pci", "devices", bdf.lower())
+    try:
+        node = int(open(os.path.join(base, "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return None, []
+    if node < 0:
+        return None, []
+    cpus: List[int] = []
+    for path in (os.path.join(base, "local_cpulist"), os.path.join(sysfs_root, "devices", "system", "node", f"node{node}", "cpulist")):
+        try:
+            cpus = parse_cpulist(open(path).read())
+        except (OSError, ValueError):
+            cpus = []
+        if cpus:
+            break
+    return node, cpus
+
+
+def gpu_pci_address(device_index: int) -> str:
+    """PCI address 'dddd:bb:dd.0' of HIP device ``device_index`` (after HIP_/ROCR_VISIBLE_DEVICES re-mapping)"""
+    p = torch.cuda.get_device_properties(device_index)
+    return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+
+
+def bind_to_gpu_numa(device_index: int, sysfs_root: str = "/sys", bdf: str = None, apply: bool = True):
+    """Restrict this process to the CPUs of the NUMA node of its GPU (``os.sched_setaffinity``), intersected with the mask it
+    already has (a container's cpuset stays in force).  Returns what bench.py prints in ``config.cpu_affinity``:
+    {"gpu": bdf, "numa_node": n, "cpus": "0-31,128-159", "n_cpus": k, "bound": bool}, ``bound`` False (mask untouched) when
+    sysfs gives no node, the intersection is empty, or ITERMVS_NO_AFFINITY=1."""
+    global _ORIGINAL_AFFINITY
+    if bdf is None:
+        bdf = gpu_pci_address(device_index)
+    node, cpus = pci_numa_cpus(bdf, sysfs_root)
+    have = sorted(os.sched_getaffinity(0))
+    if _ORIGINAL_AFFINITY is None:
+        _ORIGINAL_AFFINITY = set(have)
+    want = [c for c in cpus if c in set(have)]
+    info = {"gpu": bdf, "numa_node": node, "cpus": format_cpulist(want or have), "n_cpus": len(want or have), "bound": False}
+    if node is None or not want or os.environ.get("ITERMVS_NO_AFFINITY") == "1":
+        return info
+    if apply:
+        os.sched_setaffinity(0, want)
+        # (threads torch already started keep their masks; ranks bind right after init_distributed, before any pool exists)
+    info["bound"] = bool(apply)
+    return info
+
+
+def original_affinity():
+    """the CPU mask this process had before ``bind_to_gpu_numa`` narrowed it (None if it never did): the CPU-baseline leg of
+    bench.py runs on the whole host, not on one NUMA node"""
+    return None if _ORIGINAL_AFFINITY is None else set(_ORIGINAL_AFFINITY)
+
+
+def restore_affinity() -> bool:
+    """give EVERY thread of this process (OpenMP / torch pool threads inherit the mask they were created under) the mask the
+    process had before ``bind_to_gpu_numa``; True if something was restored"""
+    full = original_affinity()
+    if not full:
+        return False
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(tid), full)
+        except (OSError, ValueError):
+            pass
+    return True
+
+
 def barrier(device_sync: bool = True) -> None:
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

@@ -363,3 +363,56 @@ def test_build_rejects_unknown_and_knockout_switches():
         if f.endswith((".hip", ".hpp")) and f != "common.hpp":
             text = open(os.path.join(csrc, f)).read()
             assert "_KO" not in text, f"knock-out code in product source {f}"
+
+
+def test_rank_binds_to_the_cpus_of_its_gpus_numa_node(tmp_path):
+    """shard.bind_to_gpu_numa: PCI address -> sysfs numa_node / local_cpulist -> sched_setaffinity,
+    intersected with the mask the process already has; no node / empty intersection / ITERMVS_NO_AFFINITY leave it alone."""
+    import os, subprocess, sys, textwrap
+    from itermvs_amd import shard
+    assert shard.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert shard.format_cpulist([11, 0, 1, 2, 3, 8, 10]) == "0-3,8,10-11" and shard.format_cpulist([5]) == "5"
+    have = sorted(os.sched_getaffinity(0))
+    root = tmp_path / "sys"
+    dev = root / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    local = have[: max(1, len(have) // 2)]
+    (dev / "local_cpulist").write_text(shard.format_cpulist(local + [4093, 4094]) + "\n")        # two CPUs this process may not use
+    node, cpus = shard.pci_numa_cpus("0000:C1:00.0", str(root))
+    assert node == 1 and cpus == sorted(local + [4093, 4094])
+    info = shard.bind_to_gpu_numa(0, str(root), bdf="0000:c1:00.0", apply=False)
+    assert info == {"gpu": "0000:c1:00.0", "numa_node": 1, "cpus": shard.format_cpulist(local), "n_cpus": len(local), "bound": False}
+    # node -1 (platform says nothing), unknown device, cpulist from the node directory
+    dev2 = root / "bus" / "pci" / "devices" / "0000:05:00.0"
+    dev2.mkdir(parents=True)
+    (dev2 / "numa_node").write_text("-1\n")
+    assert shard.pci_numa_cpus("0000:05:00.0", str(root)) == (None, [])
+    assert shard.bind_to_gpu_numa(0, str(root), bdf="0000:05:00.0")["bound"] is False
+    assert shard.bind_to_gpu_numa(0, str(root), bdf="0000:99:00.0")["bound"] is False
+    dev3 = root / "bus" / "pci" / "devices" / "0000:06:00.0"
+    dev3.mkdir(parents=True)
+    (dev3 / "numa_node").write_text("0\n")
+    nd = root / "devices" / "system" / "node" / "node0"
+    nd.mkdir(parents=True)
+    (nd / "cpulist").write_text(shard.format_cpulist(have[-1:]))
+    assert shard.pci_numa_cpus("0000:06:00.0", str(root)) == (0, have[-1:])
+    # the real thing, in a child (the mask of the test process stays as it is): bound, every later thread inherits it, and
+    # restore_affinity widens all threads again
+    code = textwrap.dedent(f"""
+        import os, sys, threading
+        sys.path.insert(0, {str(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))!r})
+        from itermvs_amd import shard
+        before = sorted(os.sched_getaffinity(0))
+        info = shard.bind_to_gpu_numa(0, {str(root)!r}, bdf="0000:c1:00.0")
+        assert info["bound"] and sorted(os.sched_getaffinity(0)) == {local!r}, (info, os.sched_getaffinity(0))
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(sorted(os.sched_getaffinity(0)))); t.start(); t.join()
+        assert seen[0] == {local!r}
+        assert shard.restore_affinity() and sorted(os.sched_getaffinity(0)) == before
+        os.environ["ITERMVS_NO_AFFINITY"] = "1"
+        assert shard.bind_to_gpu_numa(0, {str(root)!r}, bdf="0000:c1:00.0")["bound"] is False
+        print("child ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stderr[-800:]

@@ -20,3 +20,5 @@ for k in ("staged_inputs", "pipelined", "with_transfers", "roofline_conv", "cpu_
             extra = f"  with transfers {v['with_transfers']['value']:.1f} ({v['with_transfers']['depth_maps_in_flight']} in flight)"
         print(f"{k}: {v.get('value', v.get('achieved')):.2f} {v.get('unit', '')} {('ms/step %.3f' % v['ms_per_step']) if 'ms_per_step' in v else ''}{extra}")
 print("workload:", d["config"]["workload"])
+if d.get("box"):
+    print("box:", {k: round(v, 2) for k, v in d["box"].items()}, " normalised:", d.get("value_normalised"), " affinity:", d["config"].get("cpu_affinity"))

@@ -1,23 +1,49 @@
-"""Time itermvs_corrnet at the cfg-1 shape (the 10 maps of one GRU iteration, 128 x 160): python tools/corrnet_bench.py [reps]"""
+"""Time itermvs_corrnet at the cfg-1 shape (the 10 maps of one GRU iteration, 128 x 160), 20 launches per hipGraph replay:
+    python tools/corrnet_bench.py [reps] [--lib <other libitermvs_hip.so>]
+Two arms on the same box: x 16-byte aligned (float4 tile staging) and x offset by one float (dword row staging)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from itermvs_amd import _lib
+if "--lib" in sys.argv:
+    _i = sys.argv.index("--lib")
+    _lib.LIB_PATH = os.path.abspath(sys.argv[_i + 1])
+    del sys.argv[_i:_i + 2]
 from itermvs_amd import ops
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(1)
-x = torch.randn((10, 8, 128, 160), generator=g).to(dev)
+shape = (10, 8, 128, 160)
+n = 10 * 8 * 128 * 160
+buf = torch.randn((n + 4,), generator=g).to(dev)
 packs = [(torch.randn((ops.CORRNET_WEIGHT_FLOATS,), generator=g) * 0.1).to(dev) for _ in range(3)]
-out = torch.empty((10, 1, 128, 160), device=dev)
-run = lambda: ops.corrnet(x, packs, (4, 8), out=out)
-for _ in range(10):
-    run()
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(reps):
-    run()
-e1.record()
-torch.cuda.synchronize()
-print(f"corrnet mode={os.environ.get('CN_MODE', '0')}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us per launch")
+outs = {}
+for name, off in (("aligned (float4 staging)", 0), ("offset by 4 bytes (dword staging)", 1)):
+    x = buf[off:off + n].view(shape)
+    if off:
+        x.copy_(buf[:n].clone().view(shape))
+    out = torch.empty((10, 1, 128, 160), device=dev)
+    run = lambda: ops.corrnet(x, packs, (4, 8), out=out)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        gr.capture_begin()
+        for _ in range(20):
+            run()
+        gr.capture_end()
+        best = 1e9
+        for _ in range(max(3, reps // 20)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gr.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 20 * 1e3)
+    outs[name] = out.clone()
+    print(f"corrnet, x {name}: {best:.1f} us per launch")
+a, b = outs.values()
+print("arms bit-identical:", bool(torch.equal(a, b)))
