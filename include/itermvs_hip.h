@@ -146,6 +146,11 @@ int itermvs_copy_multi(const void* const* src, void* const* dst, const int64_t* 
  * -> the sustained shader clock of THIS chip under matrix load.  The companion bandwidth probe is itermvs_copy_multi on a
  * 256 MB buffer.  Timed by the caller with events on `stream`. */
 int itermvs_box_probe(float* sink, int32_t blocks, int32_t iters, uint64_t* clocks, void* stream);
+/* itermvs_box_chase -- the latency probe of the same calibration: ONE lane follows i -> ring[i] from `start` for `steps` dependent
+ * loads (ring: device uint32 indices forming one cycle, built by the caller; its size selects L2 / memory-side cache / HBM);
+ * out[0] = the final index (start of the next call: untouched lines), clocks[0] = elapsed 100 MHz ticks (s_memrealtime),
+ * clocks[1] = elapsed shader-clock ticks (the clock of a nearly idle chip). */
+int itermvs_box_chase(const uint32_t* ring, uint32_t start, int32_t steps, uint32_t* out, uint64_t* clocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * itermvs_corr_iter -- models/itermvs.py:84-120 (Evaluation.forward, iteration branch, up to
@@ -306,6 +311,27 @@ int itermvs_head_regress(const float* x, int64_t x_sb, int32_t B, int32_t P, con
 int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W,
                        const float* w0_tile, const float* w1_packed, const float* w2_packed, const float* bias2,
                        float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream);
+/* itermvs_head_fused_conf -- itermvs_head_fused and, in the SAME launch on the same staged tile of `hidden`, the confidence
+ * head (models/itermvs.py:147-151 with the sigmoid of :198, run on the last GRU iteration :197-199): wc_tile = its dilated
+ * 3x3 layer 32 -> 32 in weight_format 2 ([9][2][4][32][4], 16-byte aligned), conf_dot = the 32 weights of its 1x1 layer + bias,
+ * conf [B,1,H,W] planes at batch stride conf_sb receives sigmoid(conv1x1(relu(conv3x3(hidden)))). */
+int itermvs_head_fused_conf(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W,
+                            const float* w0_tile, const float* w1_packed, const float* w2_packed, const float* bias2,
+                            float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best,
+                            const float* wc_tile, const float* conf_dot, float* conf, int64_t conf_sb, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * itermvs_conv3x3_conv1x1 -- conv3x3 (pad 1) 32 -> 64 + ReLU followed by conv1x1 64 -> NO (+ bias1) in one launch, the
+ * 64-channel tensor never stored: IterMVS.upsample (models/itermvs.py:243-247, applied at :262-263; NO = 144, no bias) and
+ * Update.hidden_init_head (models/itermvs.py:153-157, applied at :159-160; NO = 32, bias).
+ *   x [B,32,H,W] planes (batch stride x_sb); w0_tile = the 3x3 weight in itermvs_conv2d's weight_format 2 = [9][2][4][64][4];
+ *   w1_packed [NOB][4][4][16][4] (NOB = ceil(NO/16), zero padded) with element (ob,m,q,i,r) = W1[ob*16+i][m*16+q*4+r];
+ *   bias1 [NOB*16] or NULL; out [B,NO,H,W] planes (batch stride out_sb).  All weight pointers 16-byte aligned; NO <= 192.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_conv3x3_conv1x1(const float* x, int64_t x_sb, int32_t B, int32_t H, int32_t W, const float* w0_tile,
+                            const float* w1_packed, const float* bias1, int32_t NO, float* out, int64_t out_sb, void* stream);
+
+
 
 /* ------------------------------------------------------------------------------------------
  * ConvGRU gates -- models/module.py:59-66 (element-wise form for the traced / training path; in the inference
@@ -454,6 +480,14 @@ int itermvs_corrnet(const float* x, int64_t x_sn, const float* const* weights, c
  * ------------------------------------------------------------------------------------------ */
 int itermvs_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
                  float* y, float* sc, int64_t out_sn, void* stream);
+/* itermvs_stem_compose -- itermvs_stem and, in the SAME launch (its first workgroup), itermvs_compose_proj with its arguments
+ * (mats .. inv_max; Bd = batch size of the depth range; module.py:77-90, itermvs.py:267-268): the composition depends on the
+ * cameras only, so its ~10 us fp64 chain hides behind the first, longest launch of FeatureNet. */
+int itermvs_stem_compose(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
+                         float* y, float* sc, int64_t out_sn, const float* mats, int32_t n_sets, int32_t V, float* proj_out,
+                         int32_t* nan_flag, const float* depth_min, const float* depth_max, int32_t Bd, float* inv_min,
+                         float* inv_max, void* stream);
+
 
 
 /* ------------------------------------------------------------------------------------------

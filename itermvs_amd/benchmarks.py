@@ -27,7 +27,10 @@ def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int, e: int = 4
 
 # Pool reference of the box probe: medians over the fresh MI355X boxes this repository was measured on (profiles/r06_box_probe.md
 # lists every box).  `value_normalised` = value x (POOL_MEDIAN / this box), one figure per probe -- `value` itself is never touched.
-POOL_MEDIAN = {"mfma_f32_tflops": None, "copy_GBps": None, "sclk_MHz": None}
+POOL_MEDIAN = {"mfma_f32_tflops": None, "copy_GBps": None, "sclk_MHz": None, "graph_node_us": None, "l2_latency_ns": None,
+               "hbm_latency_ns": None, "sclk_idle_MHz": None}
+# probes where a SMALLER figure means a faster box (value_normalised multiplies by box / pool instead of pool / box)
+LOWER_IS_FASTER = {"graph_node_us", "l2_latency_ns", "hbm_latency_ns"}
 
 
 def box_probe(dev, repeats: int = 5) -> Dict[str, float]:
@@ -63,6 +66,39 @@ def box_probe(dev, repeats: int = 5) -> Dict[str, float]:
     flops = 2.0 * 16 * 16 * 4 * 4 * iters * blocks * 4
     out = {"mfma_f32_tflops": flops / (best_m * 1e-3) / 1e12, "copy_GBps": 2.0 * src.numel() * 4 / (best_c * 1e-3) / 1e9,
            "sclk_MHz": mhz}
+    # (3) what a kernel boundary costs inside a hipGraph: 200 dependent one-workgroup launches per replay (a depth map is ~50
+    # nodes); (4) the latency of a dependent load, ring of 1 MB (L2) and of 512 MB (HBM): the gather kernels wait on these
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        ops.box_probe(sink, 1, 1)
+        torch.cuda.synchronize(dev)
+        gr = torch.cuda.CUDAGraph()
+        gr.capture_begin()
+        for _ in range(200):
+            ops.box_probe(sink, 1, 1)
+        gr.capture_end()
+        best_g = None
+        for _ in range(repeats):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gr.replay()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            best_g = e0.elapsed_time(e1) if best_g is None else min(best_g, e0.elapsed_time(e1))
+    out["graph_node_us"] = best_g / 200 * 1e3
+    del gr
+    for name, n_lines in (("l2_latency_ns", 8192), ("hbm_latency_ns", 3 * 1024 * 1024)):
+        order = torch.randperm(n_lines, device=dev)
+        ring = torch.zeros((n_lines * 32,), dtype=torch.int32, device=dev)            # one index per 128-byte line
+        ring[order * 32] = (order.roll(-1) * 32).to(torch.int32)
+        _, _, at = ops.box_chase(ring, 2000)
+        best = None
+        for _ in range(3):                      # every walk continues where the last one ended: lines not touched before
+            ns, mhz_idle, at = ops.box_chase(ring, 4000, at)
+            best = ns if best is None else min(best, ns)
+        out[name] = best
+        out["sclk_idle_MHz"] = mhz_idle
+        del ring
     del sink, src, dst
     torch.cuda.empty_cache()
     return out
@@ -73,7 +109,7 @@ def normalised(value: float, box: Dict[str, float]) -> Optional[Dict[str, float]
     out = {}
     for k, ref in POOL_MEDIAN.items():
         if ref and box.get(k):
-            out["by_" + k] = value * ref / box[k]
+            out["by_" + k] = value * (box[k] / ref if k in LOWER_IS_FASTER else ref / box[k])
     return out or None
 
 

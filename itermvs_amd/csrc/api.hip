@@ -247,6 +247,29 @@ __global__ void __launch_bounds__(256) box_probe_kernel(float* __restrict__ sink
 }
 }  // namespace itermvs
 
+namespace itermvs {
+// one lane follows ring[i] -> ring[ring[i]] ...: the latency of a dependent load (L2 / memory-side cache / HBM by the ring's size)
+__global__ void __launch_bounds__(64) box_chase_kernel(const uint32_t* __restrict__ ring, uint32_t start, int steps,
+                                                       uint32_t* __restrict__ out, unsigned long long* __restrict__ clocks) {
+    if (threadIdx.x != 0) return;
+    uint32_t i = start;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int s = 0; s < steps; ++s) i = __builtin_nontemporal_load(ring + i);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = i;                      // where the walk ended: the next call starts there (lines not touched before)
+    clocks[0] = r1 - r0;
+    clocks[1] = c1 - c0;             // shader-clock ticks of a nearly idle chip over the same interval
+}
+}  // namespace itermvs
+
+extern "C" int itermvs_box_chase(const uint32_t* ring, uint32_t start, int32_t steps, uint32_t* out, uint64_t* clocks, void* stream) {
+    ITERMVS_RETURN_IF(!ring || !out || !clocks, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(steps < 1, ITERMVS_ERR_DIMS);
+    hipLaunchKernelGGL(itermvs::box_chase_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ring, start, steps, out,
+                       reinterpret_cast<unsigned long long*>(clocks));
+    return itermvs_launch_status();
+}
+
 extern "C" int itermvs_box_probe(float* sink, int32_t blocks, int32_t iters, uint64_t* clocks, void* stream) {
     ITERMVS_RETURN_IF(!sink, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(blocks < 1 || iters < 1, ITERMVS_ERR_DIMS);

@@ -42,7 +42,7 @@ __device__ __forceinline__ void corr_iter_level(const IterArgs& a, const IterLev
     // (vector-L1 hits) instead of being fetched again by whichever workgroup owns the next row strip
     constexpr int TW = kIterTW, TH = TILE / kIterTW;
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-    const int tile = xcd_tile(tiles_x * tiles_y);
+    const int tile = a.band > 0 ? xcd_tile_chunked(a.band) : xcd_tile(tiles_x * tiles_y);
     if (tile >= tiles_x * tiles_y) return;          // padding blocks of the XCD-aligned grid (uniform per block)
     const int tile_ty = tile / tiles_x, tile_tx = tile - tile_ty * tiles_x;
     const int x0 = tile_tx * TW, y0 = tile_ty * TH;
@@ -536,6 +536,17 @@ extern "C" int itermvs_pvw_tail(const float* x, const float* w, const float* bia
     return itermvs_launch_status();
 }
 
+// Tile order of the iteration kernel (see xcd_tile_chunked): tiles per XCD band, 0 = one contiguous band per XCD.
+// A TUNING build takes ITERMVS_ITER_BAND_ROWS (tile rows per band; 0 = contiguous, -1 = plain interleaving) from the environment.
+static int iter_band_tiles(int tiles_x, int tiles, const itermvs_corr_iter_params* p) {
+    if (const char* e = itermvs_tuning_env("ITERMVS_ITER_BAND_ROWS")) {
+        const int rows = atoi(e);
+        return rows < 0 ? 1 : rows * tiles_x;
+    }
+    (void)tiles; (void)p;
+    return 0;
+}
+
 extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream) {
     ITERMVS_RETURN_IF(!p, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->B < 1 || p->H < 1 || p->W < 1, ITERMVS_ERR_DIMS);
@@ -565,6 +576,7 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
     a.ref_q = p->ref_q; a.proj = p->proj; a.view_w = p->view_w; a.nd = p->norm_depth; a.nd_sb = p->norm_depth_sb;
     a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max;
     a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.CQ = coff;
+    a.band = 0;
     if (p->view_w_sb == 0 && p->view_w_ss == 0 && p->view_w_sp == 0) {      // default: planar [B,S,H,W]
         a.vw_sp = 1; a.vw_ss = (int64_t)p->H * p->W; a.vw_sb = a.vw_ss * p->S;
     } else {
@@ -579,8 +591,10 @@ extern "C" int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream
     itermvs_profile_begin(1, (hipStream_t)stream);
     {
         constexpr int TILE = 32;
-        const int tiles = ((p->W + kIterTW - 1) / kIterTW) * ((p->H + TILE / kIterTW - 1) / (TILE / kIterTW));
-        const dim3 grid(((tiles + 7) / 8) * 8, 3, p->B);
+        const int tiles_x = (p->W + kIterTW - 1) / kIterTW;
+        const int tiles = tiles_x * ((p->H + TILE / kIterTW - 1) / (TILE / kIterTW));
+        a.band = iter_band_tiles(tiles_x, tiles, p);
+        const dim3 grid(a.band > 0 ? xcd_chunked_grid(tiles, a.band) : (unsigned)(((tiles + 7) / 8) * 8), 3, p->B);
         switch (dtype) {
             case ITERMVS_F16: hipLaunchKernelGGL((corr_iter_kernel<TILE, ITERMVS_F16>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;
             case ITERMVS_BF16: hipLaunchKernelGGL((corr_iter_kernel<TILE, ITERMVS_BF16>), grid, dim3(kThreads), 0, (hipStream_t)stream, a); break;

@@ -1,82 +1,8 @@
 // Camera composition, the plain (un-fused) warp seam and reference-feature resampling.
 #include "corr_common.hpp"
+#include "compose.hpp"
 
 namespace itermvs {
-
-// ---------------------------------------------------------------------------------------------
-// compose_proj: out[set, s-1, 0:12] = rows of (src_s @ inverse(ref))[:3, :4]   (module.py:77-90)
-// One thread per (set, source view); 4x4 Gauss-Jordan with partial pivoting in fp64.
-// ---------------------------------------------------------------------------------------------
-struct ComposeArgs {
-    const float* mats;
-    float* out;
-    int* nan_flag;
-    const float* depth_min;
-    const float* depth_max;
-    float* inv_min;
-    float* inv_max;
-    int n_sets, V, B;
-};
-
-__device__ __forceinline__ void compose_proj_body(const ComposeArgs& c, int t) {
-    const float* __restrict__ mats = c.mats;
-    float* __restrict__ out = c.out;
-    int* __restrict__ nan_flag = c.nan_flag;
-    const float* __restrict__ depth_min = c.depth_min;
-    const float* __restrict__ depth_max = c.depth_max;
-    float* __restrict__ inv_min = c.inv_min;
-    float* __restrict__ inv_max = c.inv_max;
-    const int n_sets = c.n_sets, V = c.V, B = c.B;
-    const int S = V - 1;
-    // inverse depth range of the batch (1 / depth_min, 1 / depth_max: itermvs.py:240-241), IEEE division
-    if (inv_min && t < B) {
-        inv_min[t] = 1.0f / depth_min[t];
-        inv_max[t] = 1.0f / depth_max[t];
-    }
-    if (t >= n_sets * S) return;
-    const int set = t / S, s = t - set * S + 1;
-    const float* ref = mats + (size_t)set * V * 16;
-    const float* src = ref + (size_t)s * 16;
-    double a[4][8];
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            a[i][j] = (double)ref[i * 4 + j];
-            a[i][4 + j] = (i == j) ? 1.0 : 0.0;
-        }
-    for (int c = 0; c < 4; ++c) {
-        int piv = c;
-        double best = fabs(a[c][c]);
-        for (int r = c + 1; r < 4; ++r)
-            if (fabs(a[r][c]) > best) {
-                best = fabs(a[r][c]);
-                piv = r;
-            }
-        if (piv != c)
-            for (int j = 0; j < 8; ++j) {
-                double tmp = a[c][j];
-                a[c][j] = a[piv][j];
-                a[piv][j] = tmp;
-            }
-        const double inv = 1.0 / a[c][c];
-        for (int j = 0; j < 8; ++j) a[c][j] *= inv;
-        for (int r = 0; r < 4; ++r)
-            if (r != c) {
-                const double f = a[r][c];
-                for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
-            }
-    }
-    bool bad = false;
-    float* o = out + (size_t)t * 12;
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 4; ++j) {
-            double acc = 0.0;
-            for (int k = 0; k < 4; ++k) acc += (double)src[i * 4 + k] * a[k][4 + j];
-            const float v = (float)acc;
-            bad |= (v != v);
-            o[i * 4 + j] = v;
-        }
-    if (bad && nan_flag) atomicOr(nan_flag, 1);
-}
 
 __global__ void compose_proj_kernel(ComposeArgs c) { compose_proj_body(c, blockIdx.x * blockDim.x + threadIdx.x); }
 
@@ -174,33 +100,30 @@ __device__ __forceinline__ void ld4(const itermvs_fmap& f, int b, int c, int y, 
     }
 }
 
-// The first n_comp blocks (itermvs_ref_quarter_compose; otherwise 0) evaluate compose_proj -- an independent piece of work
-// of a few threads that would otherwise cost a launch of its own; its fp64 elimination is a long dependent chain, so it is
-// dispatched FIRST and runs beside the blocks that resample the reference features.
+// grid = (x chunks, B * H rows, 3 parts [+ 1]): blockIdx.z selects the pyramid level a block resamples, so a wave runs ONE of the
+// three forms (the first version took a thread per (pixel, channel quad) of all 96 channels: every wave executed the x0.5, the
+// copy and the x2 branch one after the other and spent most of its instructions on three runtime integer divisions -- 11.7 us
+// for 17 MB at cfg 1); the row and the batch item come from blockIdx.y, the only division left is by the part's constant number
+// of channel quads.  Same arithmetic per element as before (bit-identical results).
+// z == 3 (itermvs_ref_quarter_compose only): compose_proj, an independent piece of work of a few threads.
 template <int FT>
-__global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fmap r3, int B, float* __restrict__ out, int n_comp,
-                                   ComposeArgs comp) {
-    if ((int)blockIdx.x < n_comp) {
-        compose_proj_body(comp, (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x);
+__global__ void __launch_bounds__(256) ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fmap r3, int B, float* __restrict__ out,
+                                                          ComposeArgs comp) {
+    const int part = blockIdx.z;
+    if (part == 3) {
+        if (blockIdx.y == 0) compose_proj_body(comp, (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x);
         return;
     }
     const int H = r2.H, W = r2.W;
     const int CQ = r1.C + r2.C + r3.C;
-    const int quads = CQ / 4;
-    // 32-bit index arithmetic (the launcher guarantees total < 2^31): the three 64-bit divisions of the first form were most of
-    // this kernel's instructions -- 14 us for 8 MB of output
-    const uint32_t total = (uint32_t)B * (uint32_t)H * (uint32_t)W * (uint32_t)quads;
-    const uint32_t t = ((uint32_t)blockIdx.x - (uint32_t)n_comp) * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const uint32_t px = t / (uint32_t)quads;
-    const int q = (int)(t - px * (uint32_t)quads);
-    const uint32_t row = px / (uint32_t)W;
-    const int x = (int)(px - row * (uint32_t)W);
-    const int b = (int)(row / (uint32_t)H);
-    const int y = (int)(row - (uint32_t)b * (uint32_t)H);
-    int c = q * 4;
+    const int b = (int)blockIdx.y / H, y = (int)blockIdx.y - b * H;
+    const int t = (int)blockIdx.x * 256 + (int)threadIdx.x;
     float v[4];
-    if (c < r1.C) {
+    int x, c, coff;
+    if (part == 0) {
+        const int quads = r1.C >> 2;
+        x = t / quads; c = (t - x * quads) * 4; coff = 0;
+        if (x >= W) return;
         // x0.5 bilinear == weights 0.5/0.5 on rows 2y,2y+1 and columns 2x,2x+1
         float a00[4], a01[4], a10[4], a11[4];
         ld4<FT>(r1, b, c, 2 * y, 2 * x, a00); ld4<FT>(r1, b, c, 2 * y, 2 * x + 1, a01);
@@ -211,11 +134,15 @@ __global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fma
             const float bot = a10[k] * 0.5f + a11[k] * 0.5f;
             v[k] = top * 0.5f + bot * 0.5f;
         }
-    } else if (c < r1.C + r2.C) {
-        c -= r1.C;
+    } else if (part == 1) {
+        const int quads = r2.C >> 2;
+        x = t / quads; c = (t - x * quads) * 4; coff = r1.C;
+        if (x >= W) return;
         ld4<FT>(r2, b, c, y, x, v);
     } else {
-        c -= r1.C + r2.C;
+        const int quads = r3.C >> 2;
+        x = t / quads; c = (t - x * quads) * 4; coff = r1.C + r2.C;
+        if (x >= W) return;
         int y0, y1, x0, x1;
         float hy0, hy1, hx0, hx1;
         up2_axis(y, r3.H, y0, y1, hy0, hy1);
@@ -230,7 +157,7 @@ __global__ void ref_quarter_kernel(itermvs_fmap r1, itermvs_fmap r2, itermvs_fma
             v[k] = top * hy0 + bot * hy1;
         }
     }
-    reinterpret_cast<float4*>(out)[t] = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(out + ((size_t)((size_t)b * H + y) * W + x) * CQ + coff + c) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 }  // namespace itermvs
@@ -291,22 +218,27 @@ static int launch_ref_quarter(const itermvs_fmap* r1, const itermvs_fmap* r2, co
                           ITERMVS_ERR_DIMS);
     }
     const int64_t total = (int64_t)B * r2->H * r2->W * ((r1->C + r2->C + r3->C) / 4);
-    ITERMVS_RETURN_IF(total >= ((int64_t)1 << 31) - 512, ITERMVS_ERR_DIMS);        // 32-bit thread index in the kernel
+    ITERMVS_RETURN_IF(total >= ((int64_t)1 << 31) - 512, ITERMVS_ERR_DIMS);        // 32-bit offsets in the kernel
+    ITERMVS_RETURN_IF((int64_t)B * r2->H > 65535, ITERMVS_ERR_DIMS);               // grid.y = B * H rows
     ITERMVS_RETURN_IF(r1->dtype != r2->dtype || r1->dtype != r3->dtype, ITERMVS_ERR_DTYPE);
-    const int n_ref = (int)((total + 255) / 256);
+    int cmax = r1->C > r2->C ? r1->C : r2->C;
+    cmax = cmax > r3->C ? cmax : r3->C;
+    int gx = (r2->W * (cmax / 4) + 255) / 256;
     ComposeArgs c{};
-    int extra = 0;
+    int parts = 3;
     if (comp) {
         c = *comp;
         int ct = c.n_sets * (c.V - 1);
         if (c.inv_min && c.B > ct) ct = c.B;
-        extra = (ct + 255) / 256;
+        const int need = (ct + 255) / 256;
+        gx = gx > need ? gx : need;
+        parts = 4;
     }
-    const dim3 grid((unsigned)(n_ref + extra));
+    const dim3 grid((unsigned)gx, (unsigned)(B * r2->H), (unsigned)parts);
     switch (r1->dtype) {
-        case ITERMVS_F32: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F32>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, extra, c); break;
-        case ITERMVS_F16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, extra, c); break;
-        case ITERMVS_BF16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_BF16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, extra, c); break;
+        case ITERMVS_F32: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F32>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, c); break;
+        case ITERMVS_F16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_F16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, c); break;
+        case ITERMVS_BF16: hipLaunchKernelGGL(ref_quarter_kernel<ITERMVS_BF16>, grid, dim3(256), 0, (hipStream_t)stream, *r1, *r2, *r3, B, out, c); break;
         default: return ITERMVS_ERR_DTYPE;
     }
     return itermvs_launch_status();

@@ -233,6 +233,12 @@ struct FusedArgs {
     const float* bias2;
     HeadOut out;
     int H, W, tiles_x;
+    // confidence head riding in the same launch (head_coop_kernel<true>, itermvs.py:147-151,197-199): its dilated 3x3 layer reads
+    // the same staged tile of `hidden`
+    const float* wct;        // 3x3 weights 32 -> 32, tile format like w0t
+    const float* cdot;       // 1x1 layer: 32 weights + bias
+    float* conf;             // [B,1,H,W]
+    int64_t conf_sb;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -259,12 +265,21 @@ constexpr int kCoP = 2 * 2 * 4 * 16 * 4;   // conv partials: [chunk][mb0][q][l16
 constexpr int kCoY = 4 * 4 * 16 * 4;       // hidden layer: [mb1][q][l16][r]
 constexpr int kCoLgStride = 256 + 4;       // logits [16 pixels][256 bins], rows padded against bank conflicts
 constexpr int kCoLds = 2 * kCoT + kCoP + kCoY + 16 * kCoLgStride;
+constexpr int kCoWc = 9 * 2 * 4 * 32 * 4;  // the confidence head's 3x3 weights (CONF form): [tap][chunk][q][co 32][s]
+static_assert(kCoP <= 16 * kCoLgStride, "the confidence partials alias the logits buffer");
 
-__global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const int tiles_total) {
-    __shared__ __attribute__((aligned(16))) float smem[kCoLds];
+// CONF: the confidence head (dilated 3x3 32 -> 32, ReLU, 1x1 -> 1, sigmoid: itermvs.py:147-151,198) evaluated on the same staged
+// tile -- the last GRU iteration's launch carries it instead of a launch of its own (11.5 us at cfg 1).  Its 3x3 weights sit in
+// LDS (37 KB; the depth head's fill the wave's registers), its two chunk partials use the logits buffer, which is idle until the
+// 64 -> 256 layer is done; wave 0 folds ReLU, the 1x1 layer and the sigmoid into the phase of the depth head's first 1x1 layer.
+template <bool CONF>
+__global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, const int tiles_total) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* __restrict__ Pp = smem + 2 * kCoT;       // (two tile buffers in front: the next tile is stashed while this one computes)
     float* __restrict__ Y = Pp + kCoP;
     float* __restrict__ LG = Y + kCoY;
+    float* __restrict__ PC = LG;                    // CONF: conv partials of the confidence head
+    float* __restrict__ WC = smem + kCoLds;         // CONF: its 3x3 weights
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l16 = lane & 15;
@@ -286,6 +301,14 @@ __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const
     f32x4 bias[4];
 #pragma unroll
     for (int mbl = 0; mbl < 4; ++mbl) bias[mbl] = *reinterpret_cast<const f32x4*>(a.bias2 + (wave * 4 + mbl) * 16 + q * 4);
+    if constexpr (CONF) {
+        f32x4 t[kCoWc / 4 / 256];
+#pragma unroll
+        for (int i = 0; i < kCoWc / 4 / 256; ++i) t[i] = reinterpret_cast<const f32x4*>(a.wct)[tid + i * 256];
+#pragma unroll
+        for (int i = 0; i < kCoWc / 4 / 256; ++i) reinterpret_cast<f32x4*>(WC)[tid + i * 256] = t[i];
+        if (tid < 33) WC[kCoWc + tid] = a.cdot[tid];      // the 1x1 layer {w[32], bias} behind the 3x3 weights
+    }
 
     // staging: 1920 floats per tile = [32 channels][3 rows][20 columns]; thread t moves items t, t+256, ...  Which (channel,
     // row, column) an item is does not depend on the tile: its plane offset, row / column displacement and LDS slot are
@@ -346,6 +369,18 @@ __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const
             for (int s2 = 0; s2 < 4; ++s2) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[tap][s2], bv[s2], acc0, 0, 0, 0);
         }
         *reinterpret_cast<f32x4*>(Pp + (((ch * 2 + mb0) * 4 + q) * 16 + l16) * 4) = acc0;
+        if constexpr (CONF) {
+            f32x4 accc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(tb + ky * 80 + kx * 8);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(WC + ((((tap * 2 + ch) * 4 + q) * 32) + mb0 * 16 + l16) * 4);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) accc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s2], bv[s2], accc, 0, 0, 0);
+            }
+            *reinterpret_cast<f32x4*>(PC + (((ch * 2 + mb0) * 4 + q) * 16 + l16) * 4) = accc;
+        }
         // the next tile's halo (fetched one iteration ago) goes to the other buffer, the one after it into registers
         if (tile + (int)gridDim.x < tiles_total) {
             stash(smem + (buf ^ 1) * kCoT);
@@ -366,6 +401,24 @@ __global__ void __launch_bounds__(256) head_coop_kernel(const FusedArgs a, const
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc1[r] = fmaxf(acc1[r], 0.0f);
         *reinterpret_cast<f32x4*>(Y + ((wave * 4 + q) * 16 + l16) * 4) = acc1;
+        if constexpr (CONF) {
+            if (wave == 0) {        // confidence = sigmoid(sum_c relu(conv)[c] w[c] + b): lane (q, l16) holds channels u*16 + q*4 + r
+                float sdot = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4 cwv = *reinterpret_cast<const f32x4*>(WC + kCoWc + u * 16 + q * 4);
+                    const f32x4 pa = *reinterpret_cast<const f32x4*>(PC + (((0 * 2 + u) * 4 + q) * 16 + l16) * 4);
+                    const f32x4 pb = *reinterpret_cast<const f32x4*>(PC + (((1 * 2 + u) * 4 + q) * 16 + l16) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sdot = fmaf(fmaxf(pa[r] + pb[r], 0.0f), cwv[r], sdot);
+                }
+                sdot += __shfl_xor(sdot, 16);
+                sdot += __shfl_xor(sdot, 32);
+                sdot += WC[kCoWc + 32];
+                const int pxc = x0 + l16;
+                if (q == 0 && pxc < a.W) a.conf[b * a.conf_sb + y * a.W + pxc] = sigmoidf_(sdot);
+            }
+        }
         __syncthreads();
 
         // ---- 1x1 layer 64 -> 256: bins 64*wave .. 64*wave + 63 ----
@@ -488,20 +541,47 @@ extern "C" int itermvs_head_regress(const float* x, int64_t x_sb, int32_t B, int
     return itermvs_launch_status();
 }
 
-extern "C" int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W,
-                                  const float* w0_tile, const float* w1_packed, const float* w2_packed, const float* bias2,
-                                  float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream) {
+static int launch_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W, const float* w0_tile,
+                             const float* w1_packed, const float* w2_packed, const float* bias2, float* nd_out0, int64_t nd_sb0,
+                             float* nd_out1, int64_t nd_sb1, int64_t* best, const float* wc_tile, const float* conf_dot, float* conf,
+                             int64_t conf_sb, void* stream) {
     ITERMVS_RETURN_IF(!hidden || !w0_tile || !w1_packed || !w2_packed || !bias2, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(B < 1 || H < 1 || W < 1, ITERMVS_ERR_DIMS);
     FusedArgs a;
     a.hidden = hidden; a.h_sb = hidden_sb; a.w0t = w0_tile; a.w1p = w1_packed; a.w2p = w2_packed; a.bias2 = bias2;
     a.out.nd0 = nd_out0; a.out.nd1 = nd_out1; a.out.nd_sb0 = nd_sb0; a.out.nd_sb1 = nd_sb1; a.out.best = best; a.out.P = H * W;
     a.H = H; a.W = W; a.tiles_x = (W + 15) / 16;
+    a.wct = wc_tile; a.cdot = conf_dot; a.conf = conf; a.conf_sb = conf_sb;
     // one tile shared by the four waves of a persistent workgroup, two workgroups per CU
     const int cus = itermvs_num_cus();
     const int tiles = a.tiles_x * H * B;
     static const int wgs_per_cu = [] { const char* e = itermvs_tuning_env("ITERMVS_HEAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
     const int grid = tiles < wgs_per_cu * cus ? tiles : wgs_per_cu * cus;
-    hipLaunchKernelGGL(head_coop_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles);
+    if (conf) {
+        constexpr int lds = (kCoLds + kCoWc + 36) * 4;      // 77 KB: two workgroups per CU still fit the 160 KB
+        static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(head_coop_kernel<true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        ITERMVS_RETURN_IF(!attr_ok, ITERMVS_ERR_LAUNCH);
+        hipLaunchKernelGGL(head_coop_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, tiles);
+    } else {
+        hipLaunchKernelGGL(head_coop_kernel<false>, dim3(grid), dim3(256), kCoLds * 4, (hipStream_t)stream, a, tiles);
+    }
     return itermvs_launch_status();
+}
+
+extern "C" int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W,
+                                  const float* w0_tile, const float* w1_packed, const float* w2_packed, const float* bias2,
+                                  float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream) {
+    return launch_head_fused(hidden, hidden_sb, B, H, W, w0_tile, w1_packed, w2_packed, bias2, nd_out0, nd_sb0, nd_out1, nd_sb1, best,
+                             nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int itermvs_head_fused_conf(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W,
+                                       const float* w0_tile, const float* w1_packed, const float* w2_packed, const float* bias2,
+                                       float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best,
+                                       const float* wc_tile, const float* conf_dot, float* conf, int64_t conf_sb, void* stream) {
+    ITERMVS_RETURN_IF(!wc_tile || !conf_dot || !conf, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF((((uintptr_t)wc_tile) & 15) != 0, ITERMVS_ERR_ALIGN);
+    return launch_head_fused(hidden, hidden_sb, B, H, W, w0_tile, w1_packed, w2_packed, bias2, nd_out0, nd_sb0, nd_out1, nd_sb1, best,
+                             wc_tile, conf_dot, conf, conf_sb, stream);
 }

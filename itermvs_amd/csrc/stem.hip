@@ -17,6 +17,7 @@
 // ALU's issue rate), ~21 us stride-2 layer incl. 4 us of stores (12 us of matrix-pipe time); they add up because fp32 MFMA and
 // vector instructions do not overlap on this chip: 43-45 us against 72 us for the two launches.
 #include "common.hpp"
+#include "compose.hpp"
 #include <cstdlib>
 
 namespace itermvs {
@@ -88,8 +89,17 @@ struct StemPatch {
     }
 };
 
+// The first n_comp workgroups (itermvs_stem_compose; otherwise 0) evaluate compose_proj instead of tiles: the fp64 elimination of
+// src @ inverse(ref) is a ~10 us dependent chain of a handful of threads that depends on the cameras only -- dispatched first, it
+// runs beside the 43 us of this launch instead of being the critical path of a later, shorter one (ref_quarter).
 template <int kStTH>
-__global__ __launch_bounds__(kStThreads) void stem_kernel(StemArgs a, int tiles) {
+__global__ __launch_bounds__(kStThreads) void stem_kernel(StemArgs a, int tiles, int n_comp, ComposeArgs comp) {
+    if ((int)blockIdx.x < n_comp) {
+        compose_proj_body(comp, (int)blockIdx.x * kStThreads + (int)threadIdx.x);
+        return;
+    }
+    const int wg = (int)blockIdx.x - n_comp, n_wg = (int)gridDim.x - n_comp;
+
     constexpr int kStIR = 2 * kStTH + 3, kStFR = 2 * kStTH + 1;      // image / f0 patch rows
     constexpr int kStFPL = kStFR * kStFP + 1;                        // odd plane stride (1123 / 595)
     static_assert(kStFPL % 2 == 1, "f0 plane stride must be odd");
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(kStThreads) void stem_kernel(StemArgs a, int tiles)
     const int q = lane >> 4, l16 = lane & 15;
 
     StemPatch<kStTH> patch;
-    patch.fetch(a, blockIdx.x, wave, lane);
+    patch.fetch(a, wg, wave, lane);
 
     // the stride-2 layer's A operands and biases (registers for the whole kernel)
     float aw[36];
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(kStThreads) void stem_kernel(StemArgs a, int tiles)
     const int oplane = a.H2 * a.W2;
 
 #pragma unroll 1
-    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (int tile = wg; tile < tiles; tile += n_wg) {
         int t = tile;
         const int tx = t % a.tiles_x; t /= a.tiles_x;
         const int ty = t % a.tiles_y;
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(kStThreads) void stem_kernel(StemArgs a, int tiles)
 
         patch.commit(IMG, wave, lane);
         __syncthreads();
-        if (tile + (int)gridDim.x < tiles) patch.fetch(a, tile + gridDim.x, wave, lane);    // lands while this tile computes
+        if (tile + n_wg < tiles) patch.fetch(a, tile + n_wg, wave, lane);    // lands while this tile computes
 
         // f0 = relu(conv0(x) + b) on the patch: work item = (row, column), a thread evaluates all 8 channels of a position,
         // two channels per packed FMA.  Items FR x 64 (wave w: rows w, w+4, ..; lane = column) and the 65th column
@@ -206,12 +216,20 @@ __global__ __launch_bounds__(kStThreads) void stem_kernel(StemArgs a, int tiles)
 
 }  // namespace itermvs
 
-extern "C" int itermvs_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
-                            float* y, float* sc, int64_t out_sn, void* stream) {
+static int launch_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
+                       float* y, float* sc, int64_t out_sn, const itermvs::ComposeArgs* comp, void* stream) {
     using namespace itermvs;
     if (!x || !w0 || !w1 || !y || !sc) return ITERMVS_ERR_NULL;
     if (M < 0 || H < 1 || W < 1) return ITERMVS_ERR_DIMS;
-    if (M == 0) return ITERMVS_OK;
+    ComposeArgs c{};
+    int n_comp = 0;
+    if (comp) {
+        c = *comp;
+        int ct = c.n_sets * (c.V - 1);
+        if (c.inv_min && c.B > ct) ct = c.B;
+        n_comp = (ct + kStThreads - 1) / kStThreads;
+    }
+    if (M == 0 && n_comp == 0) return ITERMVS_OK;
     StemArgs a;
     a.x = x; a.w0 = w0; a.w1 = w1; a.y = y; a.sc = sc;
     a.x_sn = x_sn; a.out_sn = out_sn;
@@ -224,8 +242,25 @@ extern "C" int itermvs_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, 
     // persistent workgroups, tiles round-robin: as many as stay resident (LDS 51 / 28 KB per workgroup)
     static const int wg_per_cu = [] { const char* e = itermvs_tuning_env("ITERMVS_STEM_WGS"); return e ? atoi(e) : 0; }();
     const int resident = itermvs_num_cus() * (wg_per_cu > 0 ? wg_per_cu : (th == 4 ? 4 : 3));
-    const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
-    if (th == 4) hipLaunchKernelGGL(stem_kernel<4>, dim3(grid), dim3(kStThreads), 0, (hipStream_t)stream, a, (int)tiles);
-    else hipLaunchKernelGGL(stem_kernel<8>, dim3(grid), dim3(kStThreads), 0, (hipStream_t)stream, a, (int)tiles);
+    const unsigned grid = (unsigned)(tiles < resident ? tiles : resident) + (unsigned)n_comp;
+    if (th == 4) hipLaunchKernelGGL(stem_kernel<4>, dim3(grid), dim3(kStThreads), 0, (hipStream_t)stream, a, (int)tiles, n_comp, c);
+    else hipLaunchKernelGGL(stem_kernel<8>, dim3(grid), dim3(kStThreads), 0, (hipStream_t)stream, a, (int)tiles, n_comp, c);
     return itermvs_launch_status();
+}
+
+extern "C" int itermvs_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
+                            float* y, float* sc, int64_t out_sn, void* stream) {
+    return launch_stem(x, x_sn, M, H, W, w0, w1, y, sc, out_sn, nullptr, stream);
+}
+
+extern "C" int itermvs_stem_compose(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
+                                    float* y, float* sc, int64_t out_sn, const float* mats, int32_t n_sets, int32_t V,
+                                    float* proj_out, int32_t* nan_flag, const float* depth_min, const float* depth_max, int32_t Bd,
+                                    float* inv_min, float* inv_max, void* stream) {
+    ITERMVS_RETURN_IF(!mats || !proj_out, ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(inv_min && (!depth_min || !depth_max || !inv_max || Bd < 1), ITERMVS_ERR_NULL);
+    ITERMVS_RETURN_IF(n_sets < 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(V < 2 || V - 1 > ITERMVS_MAX_SRC, ITERMVS_ERR_VIEWS);
+    const itermvs::ComposeArgs c{mats, proj_out, nan_flag, depth_min, depth_max, inv_min, inv_max, n_sets, V, Bd};
+    return launch_stem(x, x_sn, M, H, W, w0, w1, y, sc, out_sn, &c, stream);
 }

@@ -6,7 +6,7 @@ resident in HBM; ``K`` = one launch):
 
     feature_net      FeatureNet, BN folded, all B*V views in one batch, MFMA convs              net.py:36-65
                        -> channels-last pyramids f1 [BV,H/2,W/2,16], f2 [BV,H/4,W/4,32], f3 [BV,H/8,W/8,48]
-    K  compose_proj    src @ inv(ref) for 3 levels x S views (+ inverse depth range)             module.py:77-90
+       (the stem launch also composes src @ inv(ref) for 3 levels x S views + the inverse depth range: module.py:77-90)
     K  ref_quarter     reference features on the 1/4 grid, packed                                itermvs.py:95-98
     stage_init       K corr_init (per-view group correlation, 32 hypotheses)                     itermvs.py:48-51
                        PixelViewWeight: K conv 3x3 + K pvw_tail (1x1 + softmax + max), K bilinear_up   :333-350,56
@@ -146,6 +146,13 @@ class InferenceEngine:
         # (z / r gates, 43 -> 64 dilated at 1/4 resolution: the bf16x3 form measured 18.7 us against 18.2 us -- four channel
         #  blocks stage and split each tile four times; the q convolution, two blocks, gains: 11.1 vs 13.1 us)
         self.pk_zr = ops.MfmaWeight(self.w_zr, split3=False)
+        # the two conv3x3 32 -> 64 + ReLU + conv1x1 heads, one launch each (csrc/stack2.hip)
+        hi, up = "iter_mvs.update.hidden_init_head.", "iter_mvs.upsample."
+        self.pk_hi0, self.pk_up0 = ops.MfmaWeight(w[hi + "0.weight"], split3=False), ops.MfmaWeight(w[up + "0.weight"], split3=False)
+        self.hi1, self.hi1_bias = ops.pack_conv1x1_operand(w[hi + "2.weight"], w[hi + "2.bias"])
+        self.up1, _ = ops.pack_conv1x1_operand(w[up + "2.weight"])
+        # the confidence head's 3x3 layer in the fp32 tile format (it rides in the depth head's last launch, csrc/head.hip)
+        self.pk_conf = ops.MfmaWeight(w["iter_mvs.update.confidence_head.0.weight"], split3=False)
 
     def _conv(self, x: Tensor, name: str, bias: bool = False, **kw) -> Tensor:
         """one layer by state-dict name (``name`` + "weight"/"bias")"""
@@ -170,9 +177,10 @@ class InferenceEngine:
         y = ops.conv2d(x, wt, bias, stride=2, act="relu", split=(c, "none", sc))
         return self._cbr(y, name + "conv2.", 1, "relu", add=sc)
 
-    def feature_net(self, x: Tensor) -> Dict[int, Tensor]:
+    def feature_net(self, x: Tensor, compose=None) -> Dict[int, Tensor]:
         """net.py:36-65 with BN folded; x [M,3,H,W] -> channels-last pyramids {1,2,3} (the layout the correlation kernels
-        gather from); level 2 also keeps a planar copy (``o2_planar``) for the up-sampling head."""
+        gather from); level 2 also keeps a planar copy (``o2_planar``) for the up-sampling head.
+        ``compose`` (see ops.stem): the camera composition rides in the stem launch; its results land in ``self.composed``."""
         p = "feature_net."
         m, _, hh, ww = x.shape
         dev = x.device
@@ -180,7 +188,11 @@ class InferenceEngine:
                                       memory_format=torch.channels_last)
         o1, o2, o3 = cl(16, 2), cl(32, 4), cl(48, 8)
         self.o2_planar = torch.empty((m, 32, hh // 4, ww // 4), device=dev)
-        y, sc = ops.stem(x, *self.stem_w)     # conv1 + layer1[0].conv1 / .downsample in one launch, fea0 never leaves LDS
+        # conv1 + layer1[0].conv1 / .downsample in one launch, fea0 never leaves LDS (+ the camera composition, module.py:77-90)
+        if compose is not None:
+            y, sc, *self.composed = ops.stem(x, *self.stem_w, compose=compose)
+        else:
+            y, sc = ops.stem(x, *self.stem_w)
         f1 = self._res(self._cbr(y, "layer1.0.conv2.", 1, "relu", add=sc), "layer1.1.", 1)
         f2 = self._res(self._res(f1, "layer2.0.", 2), "layer2.1.", 1)
         f3 = self._res(self._res(f2, "layer3.0.", 2), "layer3.1.", 1)
@@ -213,8 +225,7 @@ class InferenceEngine:
 
     def upsample_logits(self, ref2_nchw: Tensor, ws: dict) -> Tensor:
         """itermvs.py:262-263 (the softmax over the 9 taps is part of convex_upsample)"""
-        u = "iter_mvs.upsample."
-        return self._conv(self._conv(ref2_nchw, u + "0.", act="relu", out=ws["up_mid"]), u + "2.", ksize=1, pad=0, out=ws["up_logits"])
+        return ops.conv3x3_conv1x1(ref2_nchw, self.pk_up0, self.up1, None, 144, out=ws["up_logits"])
 
     # -- workspace ------------------------------------------------------------------------------
     def _workspace(self, b: int, h: int, w: int) -> dict:
@@ -233,7 +244,6 @@ class InferenceEngine:
                 "hidden": torch.empty((b, HIDDEN, h, w), device=dev),
                 "agg_all": torch.empty((b * (nx - 1), 8, h, w), device=dev),   # the three levels' CorrNet inputs, back to back
                 "zbuf": torch.empty((b, HIDDEN, h, w), device=dev),
-                "up_mid": torch.empty((b, 64, h, w), device=dev),
                 "up_logits": torch.empty((b, 144, h, w), device=dev),
                 "conf": torch.empty((b, 1, h, w), device=dev),
             }
@@ -320,20 +330,24 @@ class InferenceEngine:
 
     def stage_hidden0(self, ws: dict, score0: Tensor) -> None:
         """itermvs.py:159-164: hidden-init head + x2 bilinear + tanh, written to ``hidden`` and ``hx[:, :32]`` in one launch"""
-        hi = "iter_mvs.update.hidden_init_head."
-        x = self._conv(self._conv(score0, hi + "0.", act="relu"), hi + "2.", bias=True, ksize=1, pad=0)
+        x = ops.conv3x3_conv1x1(score0, self.pk_hi0, self.hi1, self.hi1_bias, HIDDEN)
         ops.bilinear_up_into(x, 2, ws["hidden"], ws["hx"][:, :HIDDEN], act="tanh")
 
-    def stage_head(self, ws: dict, want_logits: bool = False, want_best: bool = False):
+    def stage_head(self, ws: dict, want_logits: bool = False, want_best: bool = False, with_conf: bool = False):
         """depth head + softmax regression (itermvs.py:139-145, 171-190 / 201-219) on ``hidden``; the normalised depth goes
         to channel 32 of both GRU input buffers.  Default: ONE launch (itermvs_head_fused), the 256-bin logits never reach
-        memory; ``want_logits`` evaluates the head layer by layer.  Returns (logits | None, arg-max bins | None)."""
+        memory; ``want_logits`` evaluates the head layer by layer.  ``with_conf`` (last GRU iteration, itermvs.py:197-199): the
+        confidence head reads the same hidden state -- it rides in the same launch and fills ``ws["conf"]``.
+        Returns (logits | None, arg-max bins | None)."""
         hidden, nd_out = ws["hidden"], [(ws["hx"], HIDDEN), (ws["hx2"], HIDDEN)]
         if not want_logits:
             p = "iter_mvs.update.depth_head."
+            conf = (self.pk_conf, self.conf_dot, ws["conf"]) if with_conf else None
             _, best = ops.head_fused(hidden, self.pk[p + "0.weight"], self.head_w1, self.head_w2, self.w[p + "4.bias"],
-                                     nd_out=nd_out, want_best=want_best)
+                                     nd_out=nd_out, want_best=want_best, conf=conf)
             return None, best
+        if with_conf:
+            self.confidence(hidden, ws["conf"])
         logits = self.depth_head(hidden)
         _, _, best = ops.prob_regress(logits, nd_out=nd_out, want_best=True)
         return logits, best
@@ -376,7 +390,11 @@ class InferenceEngine:
         ``composed``: the projections already composed ([3,B,S,12] on the device, ``compose_host``); ``projs`` is then unused."""
         b, v, _, hh, ww = imgs.shape
         s = v - 1
-        feats = self.feature_net(imgs.reshape(b * v, 3, hh, ww).contiguous())
+        # camera composition (+ inverse depth range): a few threads of the FIRST launch (it depends on the cameras only)
+        pstack = None if composed is not None else (projs if torch.is_tensor(projs) else torch.stack([projs[1], projs[2], projs[3]]))
+        in_stem = composed is None and self.projection != "host_fp32"
+        feats = self.feature_net(imgs.reshape(b * v, 3, hh, ww).contiguous(),
+                                 compose=(pstack.reshape(3 * b, v, 4, 4), self.nan_flag, (depth_min, depth_max)) if in_stem else None)
         per_view = {l: feats[l].view(b, v, *feats[l].shape[1:]) for l in (1, 2, 3)}
         src = {l: [per_view[l][:, i] for i in range(1, v)] for l in (1, 2, 3)}
         ref = {l: per_view[l][:, 0] for l in (1, 2, 3)}
@@ -387,8 +405,6 @@ class InferenceEngine:
         f2p = self.o2_planar
         ref2_nchw = f2p[:1] if b == 1 else f2p.view(b, v, *f2p.shape[1:])[:, 0].contiguous()
         up_logits = self.upsample_logits(ref2_nchw, ws)                 # only needed by the final convex up-sampling
-        # camera composition (+ inverse depth range) rides in the launch that packs the reference features
-        pstack = None if composed is not None else (projs if torch.is_tensor(projs) else torch.stack([projs[1], projs[2], projs[3]]))
         if composed is not None:
             proj = composed
             inv_min, inv_max = 1.0 / depth_min, 1.0 / depth_max                    # itermvs.py:267-268 (IEEE division, as on the host)
@@ -397,8 +413,8 @@ class InferenceEngine:
             proj, inv_min, inv_max = self.compose_on_host(pstack.reshape(3, b, v, 4, 4), depth_min, depth_max)
             ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
         else:
-            ref_q, proj, inv_min, inv_max = ops.ref_quarter_compose(ref[1], ref[2], ref[3], pstack.reshape(3 * b, v, 4, 4), self.nan_flag,
-                                                                    (depth_min, depth_max))
+            proj, inv_min, inv_max = self.composed
+            ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
         proj = proj.view(3, b, s, 12)
 
         view_w = self.stage_init(ws, src[3], ref[3], proj[2], inv_min, inv_max, trace)          # itermvs.py:270-276
@@ -416,9 +432,10 @@ class InferenceEngine:
             self.stage_corrnets(ws)
             score = hx[:, HIDDEN + 1:].clone() if trace is not None else None
             self.stage_gru(ws)
-            if it == self.iteration - 1:                                                         # itermvs.py:197-199
-                conf = self.confidence(ws["hidden"], ws["conf"])
-            logits, best = self.stage_head(ws, trace is not None)
+            last = it == self.iteration - 1                                                      # itermvs.py:197-199
+            logits, best = self.stage_head(ws, trace is not None, with_conf=last)
+            if last:
+                conf = ws["conf"]
             if trace is not None:
                 trace["iters"].append(dict(nd_in=nd_in, aggs=[a.clone() for a in aggs], score=score,
                                            hidden=ws["hidden"].clone(), logits=logits, best=best,

@@ -171,6 +171,18 @@ def box_probe(sink: Tensor, blocks: int, iters: int, clocks: Optional[Tensor] = 
     check(_lib.load().itermvs_box_probe(sink.data_ptr(), blocks, iters, _ptr(clocks), _stream()), "itermvs_box_probe")
 
 
+def box_chase(ring: Tensor, steps: int, start: int = 0):
+    """itermvs_box_chase: (nanoseconds per dependent load along ``ring`` -- an int32 device tensor of indices forming one cycle --,
+    shader clock in MHz during the walk, index where it ended)"""
+    if not ring.is_cuda or ring.dtype != torch.int32:
+        raise RuntimeError("box_chase: ring must be an int32 CUDA/ROCm tensor")
+    out = torch.zeros((1,), device=ring.device, dtype=torch.int32)
+    clocks = torch.zeros((2,), device=ring.device, dtype=torch.int64)
+    check(_lib.load().itermvs_box_chase(ring.data_ptr(), start, steps, out.data_ptr(), clocks.data_ptr(), _stream()), "itermvs_box_chase")
+    c = clocks.tolist()
+    return float(c[0]) * 10.0 / steps, float(c[1]) / max(c[0], 1) * 100.0, int(out.item())
+
+
 def ref_quarter_compose(ref1: Tensor, ref2: Tensor, ref3: Tensor, mats: Tensor, nan_flag: Optional[Tensor], depth_range):
     """ref_quarter and compose_proj (with the inverse depth range) in ONE launch -- two independent pieces of work that both
     precede the correlation kernels.  Returns (ref_q, proj, inv_min, inv_max)."""
@@ -645,6 +657,43 @@ def pack_head_weights(w1: Tensor, w2: Tensor) -> Tuple[Tensor, Tensor]:
     return a1, a2
 
 
+def pack_conv1x1_operand(w1: Tensor, bias: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """Conv2d(64, NO, 1) weight [NO,64,1,1] (+ bias [NO]) -> the matrix-core operand layout of itermvs_conv3x3_conv1x1:
+    [NOB][4][4][16][4] with element (ob,m,q,i,r) = W1[ob*16+i][m*16+q*4+r], NO zero-padded to NOB*16 (bias likewise)."""
+    no, ci = w1.shape[0], w1.shape[1]
+    if ci != 64 or w1.numel() != no * 64:
+        raise RuntimeError("pack_conv1x1_operand: expects a [NO,64,1,1] weight")
+    nob = (no + 15) // 16
+    full = torch.zeros((nob * 16, 64), device=w1.device, dtype=torch.float32)
+    full[:no] = w1.reshape(no, 64).float()
+    a = full.reshape(nob, 16, 4, 4, 4).permute(0, 2, 3, 1, 4).contiguous()     # [ob,i,m,q,r] -> [ob,m,q,i,r]
+    bp = None
+    if bias is not None:
+        bp = torch.zeros((nob * 16,), device=w1.device, dtype=torch.float32)
+        bp[:no] = bias.float()
+    return a, bp
+
+
+def conv3x3_conv1x1(x: Tensor, w0: "MfmaWeight", w1p: Tensor, bias_p: Optional[Tensor], no: int, out: Optional[Tensor] = None) -> Tensor:
+    """itermvs_conv3x3_conv1x1: conv3x3 32 -> 64 (``w0``: its MfmaWeight, fp32 tile format) + ReLU + conv1x1 64 -> ``no``
+    (``w1p`` / ``bias_p`` from pack_conv1x1_operand) in one launch; x [B,32,H,W] -> [B,no,H,W]."""
+    ptr, sb = _planes(x, "conv3x3_conv1x1 input")
+    b, c, h, w = x.shape
+    if c != 32 or w0.tile is None or w0.cin != 32 or w0.cout != 64 or w0.ksize != 3:
+        raise RuntimeError("conv3x3_conv1x1: expects a 32-channel input and the 32 -> 64 3x3 weight")
+    nob = (no + 15) // 16
+    if w1p.numel() != nob * 1024 or (bias_p is not None and bias_p.numel() != nob * 16):
+        raise RuntimeError("conv3x3_conv1x1: w1p / bias_p must come from pack_conv1x1_operand for this output width")
+    if out is None:
+        out = torch.empty((b, no, h, w), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (b, no, h, w):
+        raise RuntimeError(f"conv3x3_conv1x1: output has shape {tuple(out.shape)}, expected {(b, no, h, w)}")
+    po, so = _planes(out, "conv3x3_conv1x1 output")
+    check(_lib.load().itermvs_conv3x3_conv1x1(ptr, sb, b, h, w, w0.tile.data_ptr(), _dev(w1p, "w1p").data_ptr(), _ptr(bias_p), no,
+                                              po, so, _stream()), "itermvs_conv3x3_conv1x1")
+    return out
+
+
 def head_regress(x: Tensor, w1p: Tensor, w2p: Tensor, bias2: Tensor,
                  nd_out: Optional[Sequence[Tuple[Tensor, int]]] = None, want_best: bool = False):
     """itermvs_head_regress: x [B,32,H,W] (after depth_head[0:2]) -> normalised depth (and arg-max bin),
@@ -674,9 +723,11 @@ def head_regress(x: Tensor, w1p: Tensor, w2p: Tensor, bias2: Tensor,
 
 
 def head_fused(hidden: Tensor, w0: "MfmaWeight", w1p: Tensor, w2p: Tensor, bias2: Tensor,
-               nd_out: Optional[Sequence[Tuple[Tensor, int]]] = None, want_best: bool = False):
+               nd_out: Optional[Sequence[Tuple[Tensor, int]]] = None, want_best: bool = False, conf=None):
     """itermvs_head_fused: hidden [B,32,H,W] -> normalised depth (and arg-max bin); the dilated 3x3 layer (``w0``: its
-    MfmaWeight), both 1x1 layers and the regression in one launch.  Returns (nd | None, best | None)."""
+    MfmaWeight), both 1x1 layers and the regression in one launch.  Returns (nd | None, best | None).
+    ``conf`` = (MfmaWeight of confidence_head[0], its 1x1 layer as 33 floats {w, bias}, out [B,1,H,W]): itermvs_head_fused_conf,
+    the confidence head (itermvs.py:147-151,198) rides in the same launch and writes sigmoid(...) to ``out``."""
     _dev(hidden, "hidden")
     b, c, h, w = hidden.shape
     if c != 32 or w0.tile is None or w0.cin != 32 or w0.cout != 32:
@@ -695,6 +746,15 @@ def head_fused(hidden: Tensor, w0: "MfmaWeight", w1p: Tensor, w2p: Tensor, bias2
     while len(dests) < 2:
         dests.append((None, 0))
     best = torch.empty((b, 1, h, w), device=hidden.device, dtype=torch.int64) if want_best else None
+    if conf is not None:
+        wc, cdot, cout = conf
+        if wc.tile is None or wc.cin != 32 or wc.cout != 32 or cdot.numel() != 33 or tuple(cout.shape) != (b, 1, h, w) or not cout.is_contiguous():
+            raise RuntimeError("head_fused: conf = (32 -> 32 3x3 MfmaWeight in the fp32 tile format, 33 floats, contiguous [B,1,H,W] output)")
+        check(_lib.load().itermvs_head_fused_conf(ptr, sb, b, h, w, w0.tile.data_ptr(), _dev(w1p, "w1").data_ptr(),
+                                                  _dev(w2p, "w2").data_ptr(), _dev(bias2, "bias2").data_ptr(), dests[0][0], dests[0][1],
+                                                  dests[1][0], dests[1][1], _ptr(best), wc.tile.data_ptr(), _dev(cdot, "conf_dot").data_ptr(),
+                                                  _dev(cout, "conf").data_ptr(), p, _stream()), "itermvs_head_fused_conf")
+        return nd, best
     check(_lib.load().itermvs_head_fused(ptr, sb, b, h, w, w0.tile.data_ptr(), _dev(w1p, "w1").data_ptr(),
                                          _dev(w2p, "w2").data_ptr(), _dev(bias2, "bias2").data_ptr(), dests[0][0], dests[0][1],
                                          dests[1][0], dests[1][1], _ptr(best), _stream()), "itermvs_head_fused")
@@ -1095,9 +1155,11 @@ def pack_stem_weights(w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor, wd: Tensor
     return p0, p1
 
 
-def stem(x: Tensor, w0: Tensor, w1: Tensor) -> Tuple[Tensor, Tensor]:
+def stem(x: Tensor, w0: Tensor, w1: Tensor, compose=None):
     """itermvs_stem: x [M,3,H,W] -> (relu(layer1[0].conv1(f0)), layer1[0].downsample(f0)) with f0 = FeatureNet.conv1(x)
-    kept in LDS; both [M,16,H2,W2].  ``w0`` / ``w1`` from pack_stem_weights."""
+    kept in LDS; both [M,16,H2,W2].  ``w0`` / ``w1`` from pack_stem_weights.
+    ``compose`` = (mats [n,V,4,4], nan_flag | None, (depth_min, depth_max)): itermvs_stem_compose -- the camera composition
+    (compose_proj + inverse depth range) rides in the same launch; returns (y, sc, proj [n,V-1,12], inv_min, inv_max)."""
     ptr, x_sn = _planes(x, "stem input")
     m, c, h, w = x.shape
     if c != 3:
@@ -1107,6 +1169,18 @@ def stem(x: Tensor, w0: Tensor, w1: Tensor) -> Tuple[Tensor, Tensor]:
     h2, w2 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     y = torch.empty((m, 16, h2, w2), device=x.device, dtype=torch.float32)
     sc = torch.empty_like(y)
+    if compose is not None:
+        mats, nan_flag, depth_range = compose
+        mats = _dev(mats, "mats").contiguous()
+        n, v = mats.shape[0], mats.shape[1]
+        proj = torch.empty((n, v - 1, 12), device=mats.device, dtype=torch.float32)
+        dmin, dmax = (_dev(t, "depth range").contiguous() for t in depth_range)
+        imin, imax = torch.empty_like(dmin), torch.empty_like(dmax)
+        check(_lib.load().itermvs_stem_compose(ptr, x_sn, m, h, w, _dev(w0, "stem weights").data_ptr(), _dev(w1, "stem weights").data_ptr(),
+                                               y.data_ptr(), sc.data_ptr(), 16 * h2 * w2, mats.data_ptr(), n, v, proj.data_ptr(),
+                                               _ptr(nan_flag), dmin.data_ptr(), dmax.data_ptr(), dmin.numel(), imin.data_ptr(),
+                                               imax.data_ptr(), _stream()), "itermvs_stem_compose")
+        return y, sc, proj, imin, imax
     check(_lib.load().itermvs_stem(ptr, x_sn, m, h, w, _dev(w0, "stem weights").data_ptr(), _dev(w1, "stem weights").data_ptr(),
                              y.data_ptr(), sc.data_ptr(), 16 * h2 * w2, _stream()), "itermvs_stem")
     return y, sc

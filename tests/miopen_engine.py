@@ -24,8 +24,11 @@ class MiopenEngine(InferenceEngine):
             x = self._cbr_t(x, name + "downsample.", stride, False)
         return F.relu_(y.add_(x))
 
-    def feature_net(self, x):
+    def feature_net(self, x, compose=None):
         w, p = self.w, "feature_net."
+        if compose is not None:             # (the product composes the cameras in its stem launch: same kernel body, own launch here)
+            mats, flag, depth_range = compose
+            self.composed = list(ops.compose_proj(mats, flag, depth_range))
         f0 = self._cbr_t(x, "conv1.", 1, True)
         f1 = self._res_t(self._res_t(f0, "layer1.0.", 2), "layer1.1.", 1)
         f2 = self._res_t(self._res_t(f1, "layer2.0.", 2), "layer2.1.", 1)
@@ -97,7 +100,9 @@ class MiopenEngine(InferenceEngine):
         ws["hidden"].copy_(hidden0)
         ws["hx"][:, :HIDDEN].copy_(hidden0)
 
-    def stage_head(self, ws, want_logits=False, want_best=False):
+    def stage_head(self, ws, want_logits=False, want_best=False, with_conf=False):
+        if with_conf:
+            self.confidence(ws["hidden"], ws["conf"])
         logits = self.depth_head(ws["hidden"])
         _, _, best = ops.prob_regress(logits, nd_out=[(ws["hx"], HIDDEN), (ws["hx2"], HIDDEN)], want_best=True)
         return logits, best

@@ -521,6 +521,36 @@ def test_head_fused_equals_conv_plus_head_regress(size):
     assert torch.equal(nd2, nd) and torch.equal(best2, best)                   # deterministic
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(1, 16, 32), (2, 23, 37), (1, 128, 160)])
+def test_head_fused_with_confidence_head(size):
+    """itermvs_head_fused_conf: the confidence head (itermvs.py:147-151 + the sigmoid of :198) evaluated in the depth head's launch
+    on the same staged tile.  Depth outputs must be bit-identical to itermvs_head_fused; the confidence equals
+    sigmoid(conv1x1(relu(conv3x3 dil 2 (hidden)))) by torch to 2e-6 and the separate one-launch form (itermvs_conv2d act
+    relu_dot_sigmoid) to rounding (the two input-channel chunks are summed in another order)."""
+    import torch.nn.functional as F
+    b, h, w = size
+    wts = load_weights("dtu")
+    p, c = "iter_mvs.update.depth_head.", "iter_mvs.update.confidence_head."
+    w0, w1, w2, b2 = (cu(wts[p + k]) for k in ("0.weight", "2.weight", "4.weight", "4.bias"))
+    c0, c2w, c2b = (cu(wts[c + k]) for k in ("0.weight", "2.weight", "2.bias"))
+    gen = torch.Generator().manual_seed(h * w + 1)
+    hidden = torch.tanh(torch.randn((b, 32, h, w), generator=gen)).to(DEV)
+    pk0, pkc = ops().MfmaWeight(w0, split3=False), ops().MfmaWeight(c0, split3=False)
+    a1, a2 = ops().pack_head_weights(w1, w2)
+    cdot = torch.cat([c2w.reshape(-1), c2b.reshape(-1)]).contiguous()
+    nd_ref, best_ref = ops().head_fused(hidden, pk0, a1, a2, b2, want_best=True)
+    conf = torch.full((b, 1, h, w), -1.0, device=DEV)
+    nd, best = ops().head_fused(hidden, pk0, a1, a2, b2, want_best=True, conf=(pkc, cdot, conf))
+    assert torch.equal(nd, nd_ref) and torch.equal(best, best_ref)
+    want = torch.sigmoid(F.conv2d(F.relu(F.conv2d(hidden, c0, padding=2, dilation=2)), c2w, c2b))
+    assert maxdiff(conf, want) <= 2e-6, maxdiff(conf, want)
+    sep = ops().conv2d(hidden, pkc, None, pad=2, dilation=2, act="relu_dot_sigmoid", aux1=cdot)
+    assert maxdiff(conf, sep) <= 1e-6
+    with pytest.raises(RuntimeError):
+        ops().head_fused(hidden, pk0, a1, a2, b2, conf=(pkc, cdot[:5], conf))
+
+
 def test_head_regress_edges_and_ties():
     """window clamps at both ends and exact ties (first max): weights that route x straight to chosen bins"""
     h, wd = 2, 40
@@ -720,6 +750,21 @@ def test_launches_that_carry_a_second_piece_of_work_equal_the_separate_ones():
     ops().ref_quarter_compose(r1, r2, r3, bad, flag, (dmin, dmax))
     assert int(flag.item()) == 1
 
+    # the composition as the first workgroup of the stem launch (the engine's form): same bits, same flag, same stem results
+    from itermvs_amd.engine import fold_batchnorm
+    from conftest import load_weights
+    wts = {k: v.to(DEV) for k, v in load_weights("dtu").items() if k.startswith("feature_net.")}
+    sw = ops().pack_stem_weights(*[t for n in ("conv1.", "layer1.0.conv1.", "layer1.0.downsample.") for t in fold_batchnorm(wts, "feature_net." + n)])
+    for mm, hh, ww in ((b * v, 64, 96), (1, 17, 23)):
+        x = r(mm, 3, hh, ww)
+        flag.zero_()
+        y0, sc0 = ops().stem(x, *sw)
+        y1, sc1, proj3, imin3, imax3 = ops().stem(x, *sw, compose=(mats, flag, (dmin, dmax)))
+        assert torch.equal(y0, y1) and torch.equal(sc0, sc1)
+        assert torch.equal(proj, proj3) and torch.equal(imin, imin3) and torch.equal(imax, imax3) and int(flag.item()) == 0
+        ops().stem(x, *sw, compose=(bad, flag, (dmin, dmax)))
+        assert int(flag.item()) == 1
+
     s, n, h3, w3 = 3, 32, 12, 20
     corr, vw = r(b, s, n, 8, h3, w3), torch.rand((b, s, h3, w3), generator=gen).to(DEV)
     agg, up = ops().view_aggregate_up(corr, vw)
@@ -835,3 +880,34 @@ def test_fused_correlation_properties_at_full_size(cfg):
     assert torch.equal(ci, ops().corr_init(src[3], ref[3], cu(p12[2]), inv_min, inv_max, 32))
     assert torch.equal(ci, ops().corr_init([t * 2 for t in src[3]], ref[3] * 0.5, cu(p12[2]), inv_min, inv_max, 32))
     assert bool(torch.isfinite(ci).all()) and tuple(ci.shape) == (1, s, 32, 8) + sizes[3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("head", ["upsample", "hidden_init"])
+@pytest.mark.parametrize("size", [(1, 128, 160), (2, 17, 37), (1, 3, 5), (3, 64, 80)])
+def test_conv3x3_conv1x1_one_launch_matches_torch(head, size):
+    """itermvs_conv3x3_conv1x1 (csrc/stack2.hip) against the torch layer chain of the two heads it serves:
+    IterMVS.upsample (itermvs.py:243-247: conv3x3 32 -> 64, ReLU, conv1x1 64 -> 144, no bias) and Update.hidden_init_head
+    (:153-157: conv3x3 32 -> 64, ReLU, conv1x1 64 -> 32 + bias) -- exact fp32 MFMA, 2e-6 of the output range; ragged widths
+    (tiles past the right edge), maps smaller than a tile, more tiles than resident workgroups, writing into a wider buffer"""
+    import torch.nn.functional as F
+    b, h, w = size
+    wts = load_weights("dtu")
+    p = "iter_mvs.upsample." if head == "upsample" else "iter_mvs.update.hidden_init_head."
+    w0, w1 = cu(wts[p + "0.weight"]), cu(wts[p + "2.weight"])
+    b1 = cu(wts[p + "2.bias"]) if head == "hidden_init" else None
+    no = w1.shape[0]
+    gen = torch.Generator().manual_seed(h * w + no)
+    x = torch.randn((b, 32, h, w), generator=gen).to(DEV)
+    want = F.conv2d(F.relu(F.conv2d(x, w0, padding=1)), w1, b1)
+    pk0 = ops().MfmaWeight(w0, split3=False)
+    w1p, bp = ops().pack_conv1x1_operand(w1, b1)
+    got = ops().conv3x3_conv1x1(x, pk0, w1p, bp, no)
+    assert got.shape == want.shape
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err <= 2e-6, err
+    wide = torch.full((b, no + 3, h, w), 7.0, device=DEV)
+    ops().conv3x3_conv1x1(x, pk0, w1p, bp, no, out=wide[:, 2:2 + no])
+    assert torch.equal(wide[:, 2:2 + no], got) and float((wide[:, :2] - 7.0).abs().max()) == 0.0 and float((wide[:, 2 + no:] - 7.0).abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ops().conv3x3_conv1x1(x[:, :16], pk0, w1p, bp, no)
