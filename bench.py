@@ -267,11 +267,12 @@ def main() -> None:
     from itermvs_amd import benchmarks as _bm
     box = _bm.box_probe(dev) if rank == 0 else None
 
-    # graph mode, one stream: TWO runners replayed alternately on that stream -- while step i runs, the event pairs
-    # embedded in the graph of step i-1 (around its corr_iter / corr_init launches) are read, so every launch of the
-    # timed region is measured without ever draining the stream
-    # (four runners A, B, A, B: each is bound to one of the four resident samples, see `resident` below)
-    ab = 4 if (args.streams == 1 and not args.eager) else 1
+    # graph mode, one stream: EIGHT runners replayed round-robin on that stream, each bound to one of the four resident samples
+    # (see `resident` below).  Runners 0 and 1 carry event-record nodes around one / two of their fused correlation launches;
+    # while step i runs, the pairs of step i-1 are read, so the launches are measured inside the timed region without ever
+    # draining the stream.  A bracket costs ~5 us of graph time: with three brackets spread over eight runners the timing
+    # costs `value` ~1.9 us per step (it was 3.75 us with four runners in rounds 4-5).
+    ab = 8 if (args.streams == 1 and not args.eager) else 1
     models, streams = [], []
     for _ in range(args.streams * ab):
         m = Pipeline(iteration=args.iters, test=True)
@@ -318,7 +319,7 @@ def main() -> None:
         with torch.cuda.stream(streams[k]):
             out = models[k](imgs, projs, dmin, dmax)      # graph mode: one hipGraph replay on this stream
         sink[:] = [out["depths_upsampled"], out["confidence_upsampled"]]
-        if ab == 4 and i >= 1:
+        if ab > 1 and i >= 1:
             read_pairs(i - 1)
 
     # HIP-event pairs around the fused kernels' launches (on their launch stream).  Graph mode: external
@@ -330,7 +331,7 @@ def main() -> None:
     ops.profile_enable((total_steps + args.warmup) * per_step + 8 * per_step, mask=0x3)
     for k in range(n_models):                          # set-up, not a step: capture every runner's hipGraph
         with torch.cuda.stream(streams[k]):
-            if ab == 4:
+            if ab > 1:
                 # an event-record node costs ~5 us of graph time: runner A carries them on iterations 0, 2, ...,
                 # runner B on 1, 3, ... -- every iteration position is sampled in every second replay
                 from itermvs_amd.engine import InferenceEngine
@@ -342,7 +343,7 @@ def main() -> None:
                 models[k]._engine.profile_iterations = {0} if k == 0 else ({min(2, args.iters - 1)} if k == 1 else set())
                 models[k]._engine.profile_init = (k == 1)
             models[k](*samples[k % n_resident])
-            if ab == 4:
+            if ab > 1:
                 r = next(iter(models[k]._runners.values()))
                 cams = samples[k % n_resident][1] if args.projection == "host_fp32" else {f"level_{l}": r.projs[l] for l in (1, 2, 3)}
                 resident[k] = ({"level_0": r.imgs}, cams, r.depth_min, r.depth_max)
@@ -355,7 +356,7 @@ def main() -> None:
     # min < max across ranks in SCALE_r*.json
     own_ms = shard.median(shard.last_local_regions()) / args.steps * 1e3
     rank_ms = shard.gather_over_ranks(own_ms)
-    if ab == 4:
+    if ab > 1:
         read_pairs(args.warmup + total_steps - 1)
         prof = graph_prof
     else:
@@ -377,12 +378,12 @@ def main() -> None:
         roofline = {"bound": "hbm", "kernel": f"itermvs_corr_iter ({kernel_name})", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": b_iter, "avg_launch_ms": avg_ms, "launches_timed": len(t_iter),
-                    "iterations_sampled": sorted({0, min(2, args.iters - 1)}) if ab == 4 else list(range(args.iters)),
+                    "iterations_sampled": sorted({0, min(2, args.iters - 1)}) if ab > 1 else list(range(args.iters)),
                     # (graph mode: external hipEvent record nodes around the launch inside the replayed hipGraph, read for every replay of
                     #  the timed regions; runner 0 brackets the corr_iter launch of GRU iteration 0 -- hypotheses around the first, noisy
                     #  depth map --, runner 1 that of iteration 2 and the corr_init launch, runners 2 and 3 carry no timing nodes: a
                     #  bracket costs ~5 us of graph time, ~4 us per step on average, included in `value`)
-                    "timing": "hipEvent nodes inside the replayed graphs" if ab == 4 else "hipEvent pairs on the launch stream"}
+                    "timing": "hipEvent nodes inside the replayed graphs" if ab > 1 else "hipEvent pairs on the launch stream"}
         # HBM bytes per launch: rocprofv3 --pmc passes of THIS command (tools/pmc_kernels.sh -> tools/pmc_summary.py ->
         # profiles/<round>_pmc_kernels.json); taken only if the summary names the kernel that ran here and the same workload
         pmc_file = pmc_summary_file()
@@ -403,7 +404,7 @@ def main() -> None:
     # runner's static input, every step pays the ~20 MB device-to-device staging copy (one itermvs_copy_multi launch) in front
     # of the replay -- what a consumer that receives fresh device tensors per depth map sees.  Runners 2 and 3 (no timing nodes).
     staged = None
-    if ab == 4 and not args.minimal:
+    if ab > 1 and not args.minimal:
         def sstep(i: int) -> None:
             k = 2 + (i & 1)
             with torch.cuda.stream(streams[k]):
@@ -517,6 +518,10 @@ def main() -> None:
             torch.cuda.empty_cache()
 
     if rank == 0:
+        # the probe once more after everything timed above: the chip's clocks drift with its thermal state within a run
+        box_end = _bm.box_probe(dev)
+        box_start = box
+        box = {k: 0.5 * (box_start[k] + box_end[k]) for k in box_start}
         result = {
             "metric": f"depth-maps/sec (ref-views/s) at {args.views}-view {args.width}x{args.height}, {args.iters} iters",
             "value": value, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -543,7 +548,8 @@ def main() -> None:
                        "algorithmic_MB_per_depth_map": b_map / 1e6},
             "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms)},   # each rank's own median region (straggler check)
             # this box against the pool (benchmarks.POOL_MEDIAN): `value` x (pool median / this box), per probe
-            "box": box, "value_normalised": _bm.normalised(value, box), "box_pool_median": _bm.POOL_MEDIAN,
+            "box": box, "box_start_end": [box_start, box_end], "value_normalised": _bm.normalised(value, box),
+            "box_pool_median": _bm.POOL_MEDIAN,
             "roofline": roofline,
             "other_configs": other,
             "roofline_conv": conv_roofline,
