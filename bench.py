@@ -223,6 +223,8 @@ def main() -> None:
     ap.add_argument("--conv-arithmetic", default="bf16x3", choices=["bf16x3", "fp32"],
                     help="3x3 convolutions with more than 8 input channels: exact three-term bf16 split on the bf16 MFMA (default) or the "
                          "exact fp32 MFMA (A/B on one box)")
+    ap.add_argument("--side-branch", action="store_true",
+                    help="A/B: ref_quarter and the up-sampling-weight launch as a parallel graph branch (measured slower: profiles/r06)")
     ap.add_argument("--repeats", type=int, default=9,
                     help="the --steps long timed region (barrier + device synchronise on both sides) is run this many times back "
                          "to back; `value` / `ms_per_step` are the MEDIAN region, min / max are reported beside them")
@@ -281,6 +283,7 @@ def main() -> None:
         m.feature_dtype = args.feature_dtype
         m.projection = args.projection
         m.conv_arithmetic = args.conv_arithmetic
+        m.side_branch = args.side_branch
         models.append(m.to(dev).eval())
         streams.append(torch.cuda.Stream(device=dev) if args.streams > 1 else torch.cuda.current_stream(dev))
     model = models[0]
@@ -338,7 +341,7 @@ def main() -> None:
                 # runner 0 brackets the corr_iter launch of GRU iteration 0, runner 1 that of iteration 2 and the corr_init launch,
                 # runners 2 and 3 carry no timing nodes at all (a bracket costs ~5 us of graph time)
                 models[k]._engine = InferenceEngine(models[k].weights(), models[k].iteration, args.feature_dtype, args.projection,
-                                                    args.conv_arithmetic)
+                                                    args.conv_arithmetic, args.side_branch)
                 models[k]._engine_version = models[k]._weights_version()      # (the engine belongs to the current weights)
                 models[k]._engine.profile_iterations = {0} if k == 0 else ({min(2, args.iters - 1)} if k == 1 else set())
                 models[k]._engine.profile_init = (k == 1)
@@ -543,6 +546,7 @@ def main() -> None:
                        "launch": "eager" if args.eager else "one hipGraph per depth map",
                        "parallelism": f"ref-view sharding x{world}, no collective",
                        "projection": args.projection, "conv_arithmetic": args.conv_arithmetic,
+                       "side_branch": args.side_branch,
                        "process_group": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                        "cpu_affinity": affinity,
                        "algorithmic_MB_per_depth_map": b_map / 1e6},

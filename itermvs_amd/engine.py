@@ -62,7 +62,7 @@ class InferenceEngine:
     """Test-mode ``IterMVS.forward`` (itermvs.py:253-329) on hand-written HIP kernels."""
 
     def __init__(self, weights: Mapping[str, Tensor], iteration: int, feature_dtype: str = "fp32", projection: str = "device_fp64",
-                 conv_arithmetic: str = "bf16x3"):
+                 conv_arithmetic: str = "bf16x3", side_branch: bool = False):
         """``projection``: how ``src_proj @ inverse(ref_proj)`` (module.py:77-90) is composed.  "device_fp64" (default): on the
         GPU in fp64, rounded once, inside the launch that packs the reference features -- no host round trip, within 5e-5
         px of any fp32 evaluation.  "host_fp32": on the host with torch in fp32, operation for operation like the reference
@@ -113,6 +113,9 @@ class InferenceEngine:
         # OR-ed with 1 by itermvs_compose_proj when a composed projection is NaN (module.py:83,87 assert on the host);
         # read and cleared by check_projection_finite()
         self.nan_flag = torch.zeros((1,), device=dev, dtype=torch.int32)
+        # ref_quarter and the up-sampling weights on a second stream = a parallel branch of the captured graph (see run)
+        self.side_branch = side_branch
+        self._side = None
         self.profile_iterations = None   # set of iteration indices whose corr_iter launch carries timing events (None = all)
         self.profile_init = True         # whether the corr_init launch carries timing events (bench.py)
         self.pk: Dict[str, object] = {}
@@ -153,6 +156,11 @@ class InferenceEngine:
         self.up1, _ = ops.pack_conv1x1_operand(w[up + "2.weight"])
         # the confidence head's 3x3 layer in the fp32 tile format (it rides in the depth head's last launch, csrc/head.hip)
         self.pk_conf = ops.MfmaWeight(w["iter_mvs.update.confidence_head.0.weight"], split3=False)
+
+    def _side_stream(self) -> "torch.cuda.Stream":
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def _conv(self, x: Tensor, name: str, bias: bool = False, **kw) -> Tensor:
         """one layer by state-dict name (``name`` + "weight"/"bias")"""
@@ -404,21 +412,38 @@ class InferenceEngine:
 
         f2p = self.o2_planar
         ref2_nchw = f2p[:1] if b == 1 else f2p.view(b, v, *f2p.shape[1:])[:, 0].contiguous()
-        up_logits = self.upsample_logits(ref2_nchw, ws)                 # only needed by the final convex up-sampling
+        # Two launches depend on FeatureNet only and are needed late: the reference features on the 1/4 grid (first read by the first
+        # corr_iter launch) and the up-sampling weights (read by the final convex up-sampling).  ``side_branch`` (OFF by default): they
+        # go to a second stream -- a parallel branch of the captured hipGraph -- and run beside the initialisation stage instead of in
+        # front of it; the main stream joins them where their results are first read.  Measured +25..33 us per depth map: kernels that
+        # share the machine slow each other down by more than the overlap returns (profiles/r06/r06f_side_branch_ab.txt).
+        main = torch.cuda.current_stream(self.device)
+        side = self._side_stream() if self.side_branch else None
+        ev_rq = None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
+                ev_rq = torch.cuda.Event()
+                ev_rq.record(side)
+                up_logits = self.upsample_logits(ref2_nchw, ws)
+            ref_q.record_stream(main)
+        else:
+            up_logits = self.upsample_logits(ref2_nchw, ws)             # only needed by the final convex up-sampling
+            ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
         if composed is not None:
             proj = composed
             inv_min, inv_max = 1.0 / depth_min, 1.0 / depth_max                    # itermvs.py:267-268 (IEEE division, as on the host)
-            ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
         elif self.projection == "host_fp32":
             proj, inv_min, inv_max = self.compose_on_host(pstack.reshape(3, b, v, 4, 4), depth_min, depth_max)
-            ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
         else:
             proj, inv_min, inv_max = self.composed
-            ref_q = ops.ref_quarter(ref[1], ref[2], ref[3])
         proj = proj.view(3, b, s, 12)
 
         view_w = self.stage_init(ws, src[3], ref[3], proj[2], inv_min, inv_max, trace)          # itermvs.py:270-276
         logits, best = self.stage_head(ws, trace is not None)
+        if ev_rq is not None:
+            main.wait_event(ev_rq)                                      # the first corr_iter launch reads ref_q
         if trace is not None:
             trace.update(feats=feats, proj=proj, ref_q=ref_q, logits0=logits, nd0=hx[:, HIDDEN:HIDDEN + 1].clone(), best0=best,
                          up_logits=up_logits, iters=[])
@@ -441,6 +466,8 @@ class InferenceEngine:
                                            hidden=ws["hidden"].clone(), logits=logits, best=best,
                                            nd=hx[:, HIDDEN:HIDDEN + 1].clone(), conf=conf))
 
+        if side is not None:
+            main.wait_stream(side)                                      # the up-sampling weights
         # convex up-sampling of the depth and bilinear up-sampling of the confidence: one launch     itermvs.py:321-324
         return ops.final_upsample(up_logits, hx, inv_min, inv_max, conf, nd_channel=HIDDEN)
 

@@ -98,6 +98,9 @@ class Pipeline(nn.Module):
         # test mode: "bf16x3" (default; the 3x3 layers with more than 8 input channels on the bf16 matrix instructions with an
         # exact three-term split of both operands, fp32-rounding-class error) or "fp32" (exact fp32 MFMA); see InferenceEngine
         self.conv_arithmetic = "bf16x3"
+        # test mode: the two launches that depend on FeatureNet only (reference features on the 1/4 grid, up-sampling weights) as a
+        # parallel branch of the captured graph (InferenceEngine.side_branch; measured slower, off)
+        self.side_branch = False
         # "device_fp64" (default) or "host_fp32": see InferenceEngine -- the second reproduces the reference's fp32
         # `src @ inverse(ref)` on the host (tap indices identical to a reference run on this host; eager mode only)
         self.projection = "device_fp64"
@@ -182,7 +185,8 @@ class Pipeline(nn.Module):
             if self._engine is not None and self._engine_version != self._weights_version():
                 self.invalidate()                 # parameters were updated in place since the weights were packed
             if self._engine is None:
-                self._engine = InferenceEngine(self.weights(), self.iteration, self.feature_dtype, self.projection, self.conv_arithmetic)
+                self._engine = InferenceEngine(self.weights(), self.iteration, self.feature_dtype, self.projection, self.conv_arithmetic,
+                                               self.side_branch)
                 self._engine_version = self._weights_version()
             with torch.no_grad():
                 composed = None

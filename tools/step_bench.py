@@ -22,6 +22,7 @@ ap.add_argument("--iters", type=int, default=4)
 ap.add_argument("--feature-dtype", default="fp32")
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--conv-arithmetic", default="bf16x3")
+ap.add_argument("--side-branch", action="store_true")
 args = ap.parse_args()
 if args.lib:
     _lib.LIB_PATH = os.path.abspath(args.lib)
@@ -33,7 +34,7 @@ dev = torch.device("cuda")
 m = Pipeline(iteration=args.iters, test=True)
 m.load_state_dict(synthetic.random_state_dict(0))
 m = m.to(dev).eval()
-eng = InferenceEngine(m.weights(), args.iters, args.feature_dtype, conv_arithmetic=args.conv_arithmetic)
+eng = InferenceEngine(m.weights(), args.iters, args.feature_dtype, conv_arithmetic=args.conv_arithmetic, side_branch=args.side_branch)
 s = synthetic.make_sample(batch=1, num_views=args.views, height=args.height, width=args.width, seed=0)
 pj = {l: s["proj_matrices"][f"level_{l}"].float().to(dev) for l in (1, 2, 3)}
 r = GraphedRunner(eng, s["imgs"]["level_0"].float().to(dev), pj, s["depth_min"].float().to(dev), s["depth_max"].float().to(dev))
@@ -49,5 +50,5 @@ for rep in range(5):
     e1.record()
     torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / args.steps)
-print(f"library {_lib.LIB_PATH}\n{args.views} views {args.width}x{args.height} {args.iters} iters {args.feature_dtype} conv {args.conv_arithmetic}: "
+print(f"library {_lib.LIB_PATH}\n{args.views} views {args.width}x{args.height} {args.iters} iters {args.feature_dtype} conv {args.conv_arithmetic} side_branch {args.side_branch}: "
       f"{best:.4f} ms per depth map ({1e3 / best:.1f} depth-maps/s)")
