@@ -365,6 +365,18 @@ def main() -> None:
     else:
         prof = ops.profile_collect(max_samples=(total_steps + args.warmup) * per_step + 8 * per_step)[-total_steps * per_step:]
     ops.profile_enable(0)
+    # the shader clock this chip holds under the timed workload itself (20 more steps between two counter stamps, rank 0)
+    sclk_workload = None
+    if rank == 0:
+        counter = iter(range(10 ** 9))
+
+        def plain_step() -> None:                      # a step without the event read-back of the timed region
+            k = next(counter) % n_models
+            imgs, projs, dmin, dmax = resident.get(k) or samples[k % n_resident]
+            with torch.cuda.stream(streams[k]):
+                models[k](imgs, projs, dmin, dmax)
+        if args.streams == 1:
+            sclk_workload = _bm.workload_clock(dev, plain_step, 20)
     maps = world * args.steps * args.batch
     value = maps / elapsed
 
@@ -525,6 +537,7 @@ def main() -> None:
         box_end = _bm.box_probe(dev)
         box_start = box
         box = {k: 0.5 * (box_start[k] + box_end[k]) for k in box_start}
+        box["sclk_workload_MHz"] = sclk_workload
         result = {
             "metric": f"depth-maps/sec (ref-views/s) at {args.views}-view {args.width}x{args.height}, {args.iters} iters",
             "value": value, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

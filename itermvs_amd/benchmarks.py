@@ -28,7 +28,7 @@ def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int, e: int = 4
 # Pool reference of the box probe: medians over the fresh MI355X boxes this repository was measured on (profiles/r06_box_probe.md
 # lists every box).  `value_normalised` = value x (POOL_MEDIAN / this box), one figure per probe -- `value` itself is never touched.
 POOL_MEDIAN = {"mfma_f32_tflops": None, "copy_GBps": None, "sclk_MHz": None, "graph_node_us": None, "l2_latency_ns": None,
-               "hbm_latency_ns": None, "sclk_idle_MHz": None}
+               "hbm_latency_ns": None, "sclk_idle_MHz": None, "sclk_workload_MHz": None}
 # probes where a SMALLER figure means a faster box (value_normalised multiplies by box / pool instead of pool / box)
 LOWER_IS_FASTER = {"graph_node_us", "l2_latency_ns", "hbm_latency_ns"}
 
@@ -102,6 +102,25 @@ def box_probe(dev, repeats: int = 5) -> Dict[str, float]:
     del sink, src, dst
     torch.cuda.empty_cache()
     return out
+
+
+def workload_clock(dev, replay, n: int = 20) -> float:
+    """shader clock (MHz) the chip sustains while ``replay()`` -- one depth map's hipGraph -- runs ``n`` times: two one-lane
+    stamps of (100 MHz counter, shader-clock counter) bracket the replays on the stream.  The boxes of the pool differ by up to
+    6 % in depth-maps/s with equal matrix-pipe and copy rates under sustained load (profiles/r06_box_probe.md): the clock a chip
+    holds under THIS bursty, latency-bound workload is what differs."""
+    from . import ops
+    ring = torch.zeros((64,), dtype=torch.int32, device=dev)
+    a, b = torch.zeros((4,), device=dev, dtype=torch.int64), torch.zeros((4,), device=dev, dtype=torch.int64)
+    replay()
+    torch.cuda.synchronize(dev)
+    ops.clock_stamp(ring, a)
+    for _ in range(n):
+        replay()
+    ops.clock_stamp(ring, b)
+    torch.cuda.synchronize(dev)
+    a, b = a.tolist(), b.tolist()
+    return float(b[3] - a[3]) / max(b[2] - a[2], 1) * 100.0
 
 
 def normalised(value: float, box: Dict[str, float]) -> Optional[Dict[str, float]]:

@@ -259,6 +259,8 @@ __global__ void __launch_bounds__(64) box_chase_kernel(const uint32_t* __restric
     out[0] = i;                      // where the walk ended: the next call starts there (lines not touched before)
     clocks[0] = r1 - r0;
     clocks[1] = c1 - c0;             // shader-clock ticks of a nearly idle chip over the same interval
+    clocks[2] = r0;                  // the two counters themselves at entry: two calls bracket a stretch of other work on the
+    clocks[3] = c0;                  // stream (bench.py: the shader clock the chip sustains under the real workload)
 }
 }  // namespace itermvs
 

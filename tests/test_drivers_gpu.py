@@ -113,3 +113,21 @@ def test_library_loaded_before_torch_then_smoke():
             "g.smoke()")
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "smoke ok" in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
+
+
+@pytest.mark.gpu
+def test_box_probe_reports_plausible_figures():
+    """bench.py's box calibration (itermvs_box_probe / itermvs_box_chase + the copy probe): every figure in the range an MI355X can
+    deliver, the HBM ring slower than the L2 ring, the clock under a real workload between the loaded and the idle clock's bounds"""
+    import torch
+    from itermvs_amd import benchmarks, ops
+    dev = torch.device("cuda:0")
+    box = benchmarks.box_probe(dev, repeats=2)
+    assert 60.0 <= box["mfma_f32_tflops"] <= 160.0 and 2000.0 <= box["copy_GBps"] <= 8000.0
+    assert 1200.0 <= box["sclk_MHz"] <= 2500.0 and 1200.0 <= box["sclk_idle_MHz"] <= 2500.0
+    assert 0.5 <= box["graph_node_us"] <= 10.0
+    assert 20.0 <= box["l2_latency_ns"] < box["hbm_latency_ns"] <= 2000.0
+    x = torch.randn((64 * 1024 * 1024,), device=dev)
+    mhz = benchmarks.workload_clock(dev, lambda: x.mul_(1.0001), n=10)
+    assert 1000.0 <= mhz <= 2500.0, mhz
+    assert benchmarks.normalised(100.0, box) is None or all(v > 0 for v in benchmarks.normalised(100.0, box).values())
