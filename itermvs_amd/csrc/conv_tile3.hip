@@ -29,6 +29,11 @@
 //   weights [chunk][tap][plane h,m,l][16*MB rows][16 ch bf16]   32 B per output channel.
 // An MFMA lane (i = lane & 15, q = lane >> 4) holds K indices 8q .. 8q+7: half (q & 1) of the 16 channels of the first
 // (q < 2) or second (q >= 2) term -- a per-lane constant plane offset selects the term.
+// PAIR form (5 .. 8 input channels, stride 1, dilation 1: the 3x3 layer of PixelViewWeight, itermvs.py:337-341, 1.5 GFLOP of fp32
+// MFMAs at cfg 1): eight channels fill only half of a 16-channel term, so the K = 32 carries TWO TAPS: channel slots 0..7 hold
+// the 8 channels at tap 2v, slots 8..15 the same 8 channels at tap 2v + 1 (v = 0..4; the missing tenth tap has zero weights,
+// ops.MfmaWeight).  Only half 0 of the tile is staged; a lane of half 1 reads it at the second tap's displacement -- a per-lane
+// select between two immediates.  5 x 3 MFMAs of 16 cycles instead of 18 fp32 MFMAs of 32 per 16 x 16 outputs.
 // With 3*MB + 2*NB operand reads of 1 KB for 3*MB*NB MFMAs per tap, a wave needs MB*NB >= 4 accumulator tiles to stay
 // under one ds_read_b128 per MFMA, the rate the LDS sustains beside the matrix pipe (tools/ubench/mfma_bf16_rate.hip).
 #include <stdlib.h>
@@ -70,10 +75,14 @@ struct Tile3Geom {
 #define ITERMVS_TILE3_DBUF 1
 #endif
 
-template <int MB, int STRIDE, int DIL, int TH, int TWT, int CPS>
+template <int MB, int STRIDE, int DIL, int TH, int TWT, int CPS, int PAIR = 0>
 __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
     using G = Tile3Geom<STRIDE, DIL, TH, TWT>;
     constexpr int NB = G::NB;
+    constexpr int TAPS = PAIR ? 5 : 9;               // K-steps per chunk: taps, or tap pairs
+    constexpr int NIT = PAIR ? (G::IN_PX + 255) / 256 : G::ITEMS;      // staging items per thread (PAIR: half 0 only)
+    constexpr int NLIVE = PAIR ? G::IN_PX : 2 * G::IN_PX;
+    static_assert(!PAIR || (CPS == 1 && STRIDE == 1 && DIL == 1), "tap pairs: one chunk, stride 1, no dilation");
     constexpr int kDbuf = ITERMVS_TILE3_DBUF;
     constexpr int PLB = G::PLB;
     constexpr int CH_BYTES = 6 * PLB;                // one staged chunk: [plane][half][PLB]
@@ -91,7 +100,7 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
     auto fill_weights = [&](int seg) {
         constexpr int PPG = 32 * MB;                 // 16-byte pieces per (chunk, tap, plane)
         const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(a.weight[seg]);
-        const int total = a.nchunk * 27 * PPG;
+        const int total = a.nchunk * (TAPS * 3) * PPG;
         constexpr int kBatch = 6;                    // loads in flight before their LDS stores
         for (int p0 = tid; p0 < total; p0 += kBatch * 256) {
             u32x4 t[kBatch];
@@ -99,7 +108,7 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
             for (int i = 0; i < kBatch; ++i) {
                 const int pc = p0 + i * 256;
                 const int grp = pc / PPG, within = pc - grp * PPG;
-                const int cidx = grp / 27, rem = grp - cidx * 27;
+                const int cidx = grp / (TAPS * 3), rem = grp - cidx * (TAPS * 3);
                 const int tap = rem / 3, pl = rem - tap * 3;
                 const int64_t g = ((int64_t)((tap * a.nchunk + cidx) * 3 + pl) * a.CoutPad + m0) * 2 + within;
                 if (pc < total) t[i] = src[g];
@@ -126,20 +135,20 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
 
     // staging items of this thread: item = (half of the chunk's 16 channels, pixel of the input tile): 8 channels, one
     // dword load per channel plane, three 16-byte LDS stores (h, m, l)
-    int rel[G::ITEMS], loff[G::ITEMS];
-    uint32_t reloff[G::ITEMS];
+    int rel[NIT], loff[NIT];
+    uint32_t reloff[NIT];
 #pragma unroll
-    for (int j = 0; j < G::ITEMS; ++j) {
+    for (int j = 0; j < NIT; ++j) {
         const int item = tid + j * 256;
-        const int hf = item / G::IN_PX;
+        const int hf = PAIR ? 0 : item / G::IN_PX;
         const int px = item - hf * G::IN_PX;
         const int y = px / G::IN_W, x = px - y * G::IN_W;
-        const bool live = item < 2 * G::IN_PX;
+        const bool live = item < NLIVE;
         rel[j] = live ? (y << 12) | x : -1;
         reloff[j] = live ? ((uint32_t)(hf * 8) * plane + (uint32_t)(y * a.Win + x)) * 4u : kTileOob;
         loff[j] = hf * PLB + px * 16;
     }
-    uint32_t goff[G::ITEMS];
+    uint32_t goff[NIT];
     __amdgpu_buffer_rsrc_t ir;
     auto setup = [&](const Work& k) {
         ir = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (int64_t)k.n * a.in_sn), 0, (int)(a.Cin * plane * 4u), 0x00020000);
@@ -147,26 +156,26 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
         if (iy0 >= 0 && ix0 >= 0 && iy0 + G::IN_H <= a.Hin && ix0 + G::IN_W <= a.Win) {
             const uint32_t base = (uint32_t)(iy0 * a.Win + ix0) * 4u;
 #pragma unroll
-            for (int j = 0; j < G::ITEMS; ++j) goff[j] = reloff[j] + base;
+            for (int j = 0; j < NIT; ++j) goff[j] = reloff[j] + base;
         } else {
             const int base = (iy0 * a.Win + ix0) * 4;
 #pragma unroll
-            for (int j = 0; j < G::ITEMS; ++j) {
+            for (int j = 0; j < NIT; ++j) {
                 const int gy = iy0 + (rel[j] >> 12), gx = ix0 + (rel[j] & 0xfff);
                 const bool ok = rel[j] >= 0 && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
                 goff[j] = ok ? reloff[j] + (uint32_t)base : kTileOob;
             }
         }
     };
-    float stage[CPS][G::ITEMS][8];
+    float stage[CPS][NIT][8];
     const uint32_t chunk_b = 16u * plane * 4u;       // bytes between chunks in the input planes
-    constexpr int kLoads = CPS * G::ITEMS * 8;
-    constexpr int kParts = 9 * CPS;
+    constexpr int kLoads = CPS * NIT * 8;
+    constexpr int kParts = TAPS * CPS;
     auto fetch_part = [&](uint32_t soff, int part) {
 #pragma unroll
         for (int e = 0; e < kLoads; ++e)
             if (e * kParts / kLoads == part) {
-                const int c = e / (G::ITEMS * 8), j = (e / 8) % G::ITEMS, k = e % 8;
+                const int c = e / (NIT * 8), j = (e / 8) % NIT, k = e % 8;
                 stage[c][j][k] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(ir, goff[j], soff + c * chunk_b + k * plane * 4u, 0));
             }
@@ -180,8 +189,9 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
     const int row0 = seg0 / TWT, col0 = seg0 - row0 * TWT;
     const int half = q & 1, second = q >> 1;          // half of the 16 channels; first / second term of the K = 32
     const int pix0 = (row0 * STRIDE) * G::IN_W + (col0 * 16 + l16) * STRIDE;
-    const char* __restrict__ bbase1 = tile + (second ? 2 * PLB : 0) + half * PLB + pix0 * 16;     // B1 = [xh | xm]
-    const char* __restrict__ bbase3 = tile + (second ? 4 * PLB : 0) + half * PLB + pix0 * 16;     // B3 = [xh | xl]
+    // (PAIR: both halves read half 0's planes; the half selects the tap, see read_operands)
+    const char* __restrict__ bbase1 = tile + (second ? 2 * PLB : 0) + (PAIR ? 0 : half * PLB) + pix0 * 16;     // B1 = [xh | xm]
+    const char* __restrict__ bbase3 = tile + (second ? 4 * PLB : 0) + (PAIR ? 0 : half * PLB) + pix0 * 16;     // B3 = [xh | xl]
     const char* __restrict__ abase = wlds + l16 * 32 + half * 16;                                 // A1 = [wh | wh]; A2 = + WPL
     const char* __restrict__ abase3 = abase + (second ? 0 : 2 * WPL);                             // A3 = [wl | wh]
     const int P = a.Hout * a.Wout;
@@ -206,8 +216,8 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
 #pragma unroll
             for (int c = 0; c < CPS; ++c)
 #pragma unroll
-                for (int j = 0; j < G::ITEMS; ++j)
-                    if (j < G::ITEMS - 1 || tid + j * 256 < 2 * G::IN_PX) {
+                for (int j = 0; j < NIT; ++j)
+                    if (j < NIT - 1 || tid + j * 256 < NLIVE) {
                         u32x4 H, M, L;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -221,7 +231,7 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
                         *reinterpret_cast<u32x4*>(d + 4 * PLB) = L;
                     }
             __syncthreads();
-            const int wst = st * (CPS * 9 * WBLK);
+            const int wst = st * (CPS * TAPS * WBLK);
             __builtin_amdgcn_sched_barrier(0);
             bool prefetch = true;
             uint32_t pf_soff = 0;
@@ -237,11 +247,13 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
             // are so large that the second one costs a wave of occupancy (kDbuf)
             bf8 a1[kDbuf + 1][MB], a2[kDbuf + 1][MB], a3[kDbuf + 1][MB], b1[kDbuf + 1][NB], b3[kDbuf + 1][NB];
             auto read_operands = [&](int u, int set) {
-                const int c = u / 9, tap = u % 9;
-                const int ky = tap / 3, kx = tap - ky * 3;
+                const int c = u / TAPS, tap = u % TAPS;
+                // PAIR: K-step `tap` = taps 2 tap (half 0) and 2 tap + 1 (half 1; the tenth tap re-reads the ninth: zero weights)
+                const int ta = PAIR ? 2 * tap : tap, tb = PAIR ? (2 * tap + 1 < 9 ? 2 * tap + 1 : 8) : tap;
+                const int ky = ta / 3, kx = ta - ky * 3, kyb = tb / 3, kxb = tb - kyb * 3;
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    const int o = wst + (c * 9 + tap) * WBLK + mb * 16 * 32;
+                    const int o = wst + (c * TAPS + tap) * WBLK + mb * 16 * 32;
                     a1[set][mb] = *reinterpret_cast<const bf8*>(abase + o);
                     a2[set][mb] = *reinterpret_cast<const bf8*>(abase + o + WPL);
                     a3[set][mb] = *reinterpret_cast<const bf8*>(abase3 + o);
@@ -249,7 +261,9 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const int r = nb / TWT, cc = nb % TWT;
-                    const int o = c * CH_BYTES + ((r * STRIDE + ky * DIL) * G::IN_W + cc * 16 * STRIDE + kx * DIL) * 16;
+                    const int oa = c * CH_BYTES + ((r * STRIDE + ky * DIL) * G::IN_W + cc * 16 * STRIDE + kx * DIL) * 16;
+                    const int ob = c * CH_BYTES + ((r * STRIDE + kyb * DIL) * G::IN_W + cc * 16 * STRIDE + kxb * DIL) * 16;
+                    const int o = PAIR ? (half ? ob : oa) : oa;
                     b1[set][nb] = *reinterpret_cast<const bf8*>(bbase1 + o);
                     b3[set][nb] = *reinterpret_cast<const bf8*>(bbase3 + o);
                 }
@@ -330,8 +344,30 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
 constexpr int kLds3Budget = 80 * 1024;     // per workgroup: two workgroups fit the CU's 160 KB
 
 template <int MB, int STRIDE, int DIL, int TH, int TWT, int CPS>
-static constexpr int tile3_lds_bytes(int nchunk) {
-    return CPS * 6 * Tile3Geom<STRIDE, DIL, TH, TWT>::PLB + nchunk * 27 * 16 * MB * 32;
+static constexpr int tile3_lds_bytes(int nchunk, int taps = 9) {
+    return CPS * 6 * Tile3Geom<STRIDE, DIL, TH, TWT>::PLB + nchunk * taps * 3 * 16 * MB * 32;
+}
+
+// PAIR form: one instantiation per channel blocking (8 x 32 tiles, one chunk)
+template <int MB>
+static int launch_tile3_pair(TileArgs& a, int mt, hipStream_t stream) {
+    constexpr int TH = 8, TWT = 2, TW = 16 * TWT;
+    const int lds = tile3_lds_bytes<MB, 1, 1, TH, TWT, 1>(1, 5);
+    auto kern = conv_tile3_kernel<MB, 1, 1, TH, TWT, 1, 1>;
+    a.tiles_x = (a.Wout + TW - 1) / TW;
+    a.tiles_y = (a.Hout + TH - 1) / TH;
+    a.ncb = mt / MB;
+    a.nstage = 1;
+    a.total = a.N * a.tiles_y * a.tiles_x;
+    a.rcp_tiles_x = (uint32_t)((1ull << 32) / (uint32_t)a.tiles_x + 1);
+    a.rcp_tiles_y = (uint32_t)((1ull << 32) / (uint32_t)a.tiles_y + 1);
+    int fit = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kern, 256, lds) != hipSuccess || fit < 1) fit = 1;
+    int gx = itermvs_num_cus() * (4 < fit ? 4 : fit) / a.ncb;
+    if (gx > a.total) gx = a.total;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(kern, dim3(gx, a.ncb), dim3(256), lds, stream, a);
+    return 0;
 }
 
 template <int MB, int STRIDE, int DIL, int TH, int TWT, int CPS>
@@ -401,7 +437,8 @@ using namespace itermvs;
 
 // called from itermvs_conv2d (conv.hip) when weight_format == 3; returns 1 when the shape is not covered
 int itermvs_conv2d_tile3(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream) {
-    if (p->ksize != 3 || p->Cin <= 8) return 1;
+    if (p->ksize != 3 || p->Cin <= 4) return 1;
+    if (p->Cin <= 8 && !(p->stride == 1 && p->dilation == 1)) return 1;      // the tap-pair form: stride 1, no dilation
     const bool s1d1 = p->stride == 1 && p->dilation == 1, s2d1 = p->stride == 2 && p->dilation == 1;
     const bool s1d2 = p->stride == 1 && p->dilation == 2;
     if (!s1d1 && !s2d1 && !s1d2) return 1;
@@ -436,6 +473,16 @@ int itermvs_conv2d_tile3(const itermvs_conv_params* p, int hout, int wout, hipSt
     else if (a.nchunk >= 3 || mt == 1) { shape = p->stride == 1 ? 2 : 1; mb = 1; }
     else if (mt == 2 && mb_ok(2)) { shape = 0; mb = 2; }
     else { shape = 0; mb = 1; }
+    if (p->Cin <= 8) {            // PAIR form (weights packed as five tap pairs: ops.MfmaWeight)
+        if (p->split_cout) return 1;
+        const bool dotp = p->act == 6 || p->act == 7;
+        int rcp = 1;
+        if (mt == 1) rcp = launch_tile3_pair<1>(a, mt, stream);
+        else if (mt == 2 && dotp) rcp = launch_tile3_pair<2>(a, mt, stream);
+        else if (!dotp) rcp = launch_tile3_pair<1>(a, mt, stream);
+        if (rcp != 0) return 1;
+        return itermvs_launch_status();
+    }
     const char* force = itermvs_tuning_env("ITERMVS_TILE3_FORCE");            // "shape,mb" (tools/conv_bench.py --sweep3)
     if (force) {
         shape = force[0] - '0';

@@ -961,6 +961,13 @@ class MfmaWeight:
             t[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(9, cin, cout)
             t = t.reshape(9, nch, 16, cout_p).permute(0, 1, 3, 2)                      # [9, chunks, Cout_pad, 16]
             self.tile3 = torch.stack(split_bf16x3(t), 2).contiguous()                  # [9, chunks, 3, Cout_pad, 16] bf16
+        # 5 .. 8 input channels: the TAP-PAIR form of conv_tile3.hip (stride 1, no dilation): K-step v = 0..4 carries the 8 channels
+        # at tap 2v in slots 0..7 and at tap 2v + 1 in slots 8..15 (the tenth tap: zeros) -> [5, 1, 3, Cout_pad, 16] bf16
+        elif k == 3 and 4 < cin <= 8 and not transposed and (MFMA_SPLIT3_DEFAULT if split3 is None else split3):
+            t = torch.zeros((10, 8, cout_p), device=w.device, dtype=torch.float32)
+            t[:9, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(9, cin, cout)
+            t = t.reshape(5, 2, 8, cout_p).permute(0, 3, 1, 2).reshape(5, 1, cout_p, 16)      # [pair, chunk, Cout_pad, (tap in pair, ch)]
+            self.tile3 = torch.stack(split_bf16x3(t), 2).contiguous()                  # [5, 1, 3, Cout_pad, 16] bf16
 
 
 _TILE_SHAPES = {(1, 1), (2, 1), (1, 2)}   # (stride, dilation) instantiated in conv_tile.hip
@@ -1006,7 +1013,8 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
         tiled = transposed or all(_use_tile(wt, stride, dilation) for wt in weights)
         # (stride-2 layers keep the fp32 form: their halo tiles leave no LDS for two resident workgroups in the split form, and
         #  the sweep measured no gain -- profiles/r05)
-        split3 = tiled and not transposed and stride == 1 and all(wt.tile3 is not None for wt in weights)
+        split3 = (tiled and not transposed and stride == 1 and all(wt.tile3 is not None for wt in weights)
+                  and (cin > 8 or dilation == 1))                    # (the tap-pair form of 5..8 channels: no dilation)
         weights = [(wt.tile3 if split3 else wt.tile) if tiled else wt.data for wt in weights]
     else:
         cout = weights[0].shape[3]

@@ -85,4 +85,10 @@ vw = torch.rand((1, 4, 64, 80), generator=g).to(dev)
 timed("softmax_max", lambda: ops.softmax_max(logit))
 timed("view_aggregate_up", lambda: ops.view_aggregate_up(corr_v, vw, interleaved=True))
 pv = "iter_mvs.evaluation.pixel_view_weight."
-timed("PixelViewWeight conv (relu_dot)", lambda: eng._conv(corr_v.view(128, 8, 64, 80), pv + "conv.0.conv.", act="relu_dot", aux1=eng.pvw_dot))
+wpv = eng.w[pv + "conv.0.conv.weight"]
+pk32, pk3 = ops.MfmaWeight(wpv, split3=False), ops.MfmaWeight(wpv, split3=True)
+xin = corr_v.view(128, 8, 64, 80)
+timed("PixelViewWeight conv (relu_dot), fp32 MFMA", lambda: ops.conv2d(xin, pk32, None, act="relu_dot", aux1=eng.pvw_dot))
+timed("PixelViewWeight conv (relu_dot), bf16x3 tap pairs", lambda: ops.conv2d(xin, pk3, None, act="relu_dot", aux1=eng.pvw_dot))
+a32, a3 = ops.conv2d(xin, pk32, None, act="relu_dot", aux1=eng.pvw_dot), ops.conv2d(xin, pk3, None, act="relu_dot", aux1=eng.pvw_dot)
+print("  max |fp32 - bf16x3| / max |fp32| =", float((a32 - a3).abs().max() / a32.abs().max()))
