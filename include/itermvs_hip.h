@@ -149,9 +149,12 @@ int itermvs_box_probe(float* sink, int32_t blocks, int32_t iters, uint64_t* cloc
 /* itermvs_box_chase -- the latency probe of the same calibration: ONE lane follows i -> ring[i] from `start` for `steps` dependent
  * loads (ring: device uint32 indices forming one cycle, built by the caller; its size selects L2 / memory-side cache / HBM);
  * out[0] = the final index (start of the next call: untouched lines), clocks[0] = elapsed 100 MHz ticks (s_memrealtime),
- * clocks[1] = elapsed shader-clock ticks (the clock of a nearly idle chip), clocks[2] / clocks[3] = the 100 MHz and the shader-clock
- * counter at entry (two calls bracketing other work on the stream give the clock sustained under THAT work).  clocks: 4 x uint64. */
+ * clocks[1] = elapsed shader-clock ticks (the clock of a nearly idle chip).  clocks: 2 x uint64. */
 int itermvs_box_chase(const uint32_t* ring, uint32_t start, int32_t steps, uint32_t* out, uint64_t* clocks, void* stream);
+/* itermvs_clock_stamp -- out (device, uint64[16][2], zeroed by the caller): every XCD writes { its 100 MHz counter, its shader-clock
+ * counter } to slot XCC_ID.  Two stamps around other work on the stream: per XCD, delta(shader) / delta(100 MHz) x 100 = the clock
+ * in MHz the chip sustained under THAT work (bench.py `box.sclk_workload_MHz`). */
+int itermvs_clock_stamp(uint64_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * itermvs_corr_iter -- models/itermvs.py:84-120 (Evaluation.forward, iteration branch, up to

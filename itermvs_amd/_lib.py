@@ -97,6 +97,7 @@ PROTOTYPES = {
                                          C.c_void_p]),
     "itermvs_copy_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p]),
     "itermvs_box_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "itermvs_clock_stamp": (C.c_int, [C.c_void_p, C.c_void_p]),
     "itermvs_box_chase": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "itermvs_corr_iter": (C.c_int, [C.POINTER(CorrIterParams), C.c_void_p]),
     "itermvs_corr_init": (C.c_int, [C.POINTER(CorrInitParams), C.c_void_p]),

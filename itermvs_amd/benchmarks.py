@@ -110,17 +110,18 @@ def workload_clock(dev, replay, n: int = 20) -> float:
     6 % in depth-maps/s with equal matrix-pipe and copy rates under sustained load (profiles/r06_box_probe.md): the clock a chip
     holds under THIS bursty, latency-bound workload is what differs."""
     from . import ops
-    ring = torch.zeros((64,), dtype=torch.int32, device=dev)
-    a, b = torch.zeros((4,), device=dev, dtype=torch.int64), torch.zeros((4,), device=dev, dtype=torch.int64)
+    a, b = torch.zeros((16, 2), device=dev, dtype=torch.int64), torch.zeros((16, 2), device=dev, dtype=torch.int64)
     replay()
     torch.cuda.synchronize(dev)
-    ops.clock_stamp(ring, a)
+    ops.clock_stamp(a)
     for _ in range(n):
         replay()
-    ops.clock_stamp(ring, b)
+    ops.clock_stamp(b)
     torch.cuda.synchronize(dev)
     a, b = a.tolist(), b.tolist()
-    return float(b[3] - a[3]) / max(b[2] - a[2], 1) * 100.0
+    # per XCD (the counters of different XCDs are not aligned): slots both stamps filled
+    mhz = sorted(float(b[i][1] - a[i][1]) / (b[i][0] - a[i][0]) * 100.0 for i in range(16) if a[i][0] and b[i][0] > a[i][0])
+    return mhz[len(mhz) // 2] if mhz else 0.0
 
 
 def normalised(value: float, box: Dict[str, float]) -> Optional[Dict[str, float]]:

@@ -259,8 +259,16 @@ __global__ void __launch_bounds__(64) box_chase_kernel(const uint32_t* __restric
     out[0] = i;                      // where the walk ended: the next call starts there (lines not touched before)
     clocks[0] = r1 - r0;
     clocks[1] = c1 - c0;             // shader-clock ticks of a nearly idle chip over the same interval
-    clocks[2] = r0;                  // the two counters themselves at entry: two calls bracket a stretch of other work on the
-    clocks[3] = c0;                  // stream (bench.py: the shader clock the chip sustains under the real workload)
+}
+
+// The 100 MHz counter and the shader-clock counter of every XCD (the counters are per XCD and not aligned with each other): 64
+// one-wave workgroups, each writes { s_memrealtime, s_memtime } to slot XCC_ID of `out` (uint64[16][2]).  Two launches bracket a
+// stretch of other work on the stream; per XCD, delta(shader ticks) / delta(100 MHz ticks) = the clock sustained under that work.
+__global__ void __launch_bounds__(64) clock_stamp_kernel(unsigned long long* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;        // HW_REG_XCC_ID[3:0]
+    out[2 * xcc] = __builtin_amdgcn_s_memrealtime();
+    out[2 * xcc + 1] = __builtin_amdgcn_s_memtime();
 }
 }  // namespace itermvs
 
@@ -269,6 +277,12 @@ extern "C" int itermvs_box_chase(const uint32_t* ring, uint32_t start, int32_t s
     ITERMVS_RETURN_IF(steps < 1, ITERMVS_ERR_DIMS);
     hipLaunchKernelGGL(itermvs::box_chase_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ring, start, steps, out,
                        reinterpret_cast<unsigned long long*>(clocks));
+    return itermvs_launch_status();
+}
+
+extern "C" int itermvs_clock_stamp(uint64_t* out, void* stream) {
+    ITERMVS_RETURN_IF(!out, ITERMVS_ERR_NULL);
+    hipLaunchKernelGGL(itermvs::clock_stamp_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(out));
     return itermvs_launch_status();
 }
 

@@ -177,17 +177,17 @@ def box_chase(ring: Tensor, steps: int, start: int = 0):
     if not ring.is_cuda or ring.dtype != torch.int32:
         raise RuntimeError("box_chase: ring must be an int32 CUDA/ROCm tensor")
     out = torch.zeros((1,), device=ring.device, dtype=torch.int32)
-    clocks = torch.zeros((4,), device=ring.device, dtype=torch.int64)
+    clocks = torch.zeros((2,), device=ring.device, dtype=torch.int64)
     check(_lib.load().itermvs_box_chase(ring.data_ptr(), start, steps, out.data_ptr(), clocks.data_ptr(), _stream()), "itermvs_box_chase")
     c = clocks.tolist()
     return float(c[0]) * 10.0 / steps, float(c[1]) / max(c[0], 1) * 100.0, int(out.item())
 
 
-def clock_stamp(ring: Tensor, clocks: Tensor) -> None:
-    """enqueue a one-lane launch that writes the 100 MHz counter and the shader-clock counter to clocks[2], clocks[3] (int64[4]):
-    two stamps around other work on the stream -> the shader clock sustained under that work (benchmarks.workload_clock)"""
-    out = torch.zeros((1,), device=ring.device, dtype=torch.int32)
-    check(_lib.load().itermvs_box_chase(ring.data_ptr(), 0, 1, out.data_ptr(), clocks.data_ptr(), _stream()), "itermvs_box_chase")
+def clock_stamp(out: Tensor) -> None:
+    """itermvs_clock_stamp: every XCD writes {100 MHz counter, shader-clock counter} to out[XCC_ID] (int64[16, 2], zeroed)"""
+    if not out.is_cuda or out.dtype != torch.int64 or out.numel() != 32:
+        raise RuntimeError("clock_stamp: out must be an int64 CUDA/ROCm tensor [16, 2]")
+    check(_lib.load().itermvs_clock_stamp(out.data_ptr(), _stream()), "itermvs_clock_stamp")
 
 
 def ref_quarter_compose(ref1: Tensor, ref2: Tensor, ref3: Tensor, mats: Tensor, nan_flag: Optional[Tensor], depth_range):
