@@ -565,7 +565,7 @@ def main() -> None:
                        "algorithmic_MB_per_depth_map": b_map / 1e6},
             "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms)},   # each rank's own median region (straggler check)
             # this box against the pool (benchmarks.POOL_MEDIAN): `value` x (pool median / this box), per probe
-            "box": box, "box_start_end": [box_start, box_end], "value_normalised": _bm.normalised(value, box),
+            "box": box, "box_start_end": [box_start, box_end], "value_normalised": _bm.normalised(value, box, roofline["avg_launch_ms"] if roofline and (args.views, args.height, args.width, args.iters, args.feature_dtype, args.batch) == (5, 512, 640, 4, "fp32", 1) else None),
             "box_pool_median": _bm.POOL_MEDIAN,
             "roofline": roofline,
             "other_configs": other,

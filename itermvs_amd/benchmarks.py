@@ -29,6 +29,11 @@ def algorithmic_bytes(s: int, h: int, w: int, batch: int, iters: int, e: int = 4
 # lists every box).  `value_normalised` = value x (POOL_MEDIAN / this box), one figure per probe -- `value` itself is never touched.
 POOL_MEDIAN = {"mfma_f32_tflops": None, "copy_GBps": None, "sclk_MHz": None, "graph_node_us": None, "l2_latency_ns": None,
                "hbm_latency_ns": None, "sclk_idle_MHz": None, "sclk_workload_MHz": None}
+# The yardstick that DOES track a box's speed (profiles/r06_box_probe.md): the event-bracketed launch time of itermvs_corr_iter inside
+# the timed region (`roofline.avg_launch_ms`).  That kernel's code has not changed since round 4, every kernel of a depth map scales
+# with it from box to box, and value x launch time is constant within 0.5 % over boxes that differ by 6 % in value.  Median over
+# the ten boxes of round 6, cfg 1, fp32 feature storage:
+POOL_MEDIAN_CORR_ITER_MS = 0.0262
 # probes where a SMALLER figure means a faster box (value_normalised multiplies by box / pool instead of pool / box)
 LOWER_IS_FASTER = {"graph_node_us", "l2_latency_ns", "hbm_latency_ns"}
 
@@ -124,9 +129,12 @@ def workload_clock(dev, replay, n: int = 20) -> float:
     return mhz[len(mhz) // 2] if mhz else 0.0
 
 
-def normalised(value: float, box: Dict[str, float]) -> Optional[Dict[str, float]]:
-    """``value`` scaled to the pool-median box, per probe (None until POOL_MEDIAN is filled in)"""
+def normalised(value: float, box: Dict[str, float], corr_iter_ms: Optional[float] = None) -> Optional[Dict[str, float]]:
+    """``value`` scaled to the pool-median box: by the launch time of the unchanged corr_iter kernel (cfg 1 / fp32 only), and per
+    probe where a pool median is filled in"""
     out = {}
+    if corr_iter_ms:
+        out["by_corr_iter_launch"] = value * corr_iter_ms / POOL_MEDIAN_CORR_ITER_MS
     for k, ref in POOL_MEDIAN.items():
         if ref and box.get(k):
             out["by_" + k] = value * (box[k] / ref if k in LOWER_IS_FASTER else ref / box[k])
