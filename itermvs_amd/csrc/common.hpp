@@ -38,6 +38,23 @@ static inline const char* itermvs_tuning_env(const char* name) {
 #endif
 }
 
+// ---- the exact three-term bf16 split of fp32 operands (conv_tile3.hip, corrnet.hip) ----
+namespace itermvs {
+using bf8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+// two fp32 values -> their (h, m, l) bf16 terms, packed [value 0 | value 1 << 16]
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& H, uint32_t& M, uint32_t& L) {
+    const uint32_t b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+    const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);   // exact
+    const uint32_t c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+    const float t0 = r0 - __uint_as_float(c0 & 0xffff0000u), t1 = r1 - __uint_as_float(c1 & 0xffff0000u);   // exact, <= 8 bits
+    H = __builtin_amdgcn_perm(b1, b0, 0x07060302u);      // (b0 >> 16) | (b1 & 0xffff0000)
+    M = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+    L = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
+}
+
+}  // namespace itermvs
+
 // compute units of the current device (grid size of persistent kernels)
 static inline int itermvs_num_cus() {
     static const int cus = [] {

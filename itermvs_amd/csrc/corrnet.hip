@@ -57,6 +57,14 @@ constexpr int kW4 = kW3 + 9 * 8 * 4 * 16;      // conv4 (transposed): 9 x 4 x 4 
 constexpr int kW5 = kW4 + 9 * 4 * 4 * 16;      // conv5: [ci 8][tap 9], then the bias
 constexpr int kWBias = kW5 + 72;
 constexpr int kCnWeightFloats = kWBias + 8;
+// bf16x3 form (corrnet_kernel<true>): conv0's weights as bf16 A operands of v_mfma_f32_16x16x32_bf16 -- [18 MFMAs][64 lanes][8 bf16]
+// = 4608 floats -- in front of the same layers 1..5 (ops.pack_corrnet_weights(split3=True))
+constexpr int kW0Split = 18 * 64 * 4;
+constexpr int kSplitShift = kW0Split - (kW1 - kW0);        // every later offset moves by this much
+static_assert(kW0Split <= kSzW, "conv0's split weights must fit the weight buffer");
+constexpr int kXPlaneB = XS * XP * 16;                     // bytes of one bf16 plane of the x tile: [row 45][col 46][8 channels]
+static_assert(2 * kXPlaneB <= kSzX * 4 && kXPlaneB <= kSzC0 * 4, "planes h, m of x must fit the x region, plane l the c0 region");
+static_assert(kCnWeightFloats + kSplitShift == 17360, "packed set of the bf16x3 form (include/itermvs_hip.h)");
 
 struct CorrNetArgs {
     const float* x;
@@ -171,6 +179,91 @@ __device__ __forceinline__ void conv0_layer(const float* __restrict__ In, float*
     }
 }
 
+// ---- conv0 on the bf16 matrix instruction (corrnet_kernel<true>) ----
+// x has 8 channels: one 16-byte LDS entry per position and term (h, m, l of the exact split, common.hpp).  The K = 32 of
+// v_mfma_f32_16x16x32_bf16 carries TWO positions of the 4 x 3 window (the two-rows-per-tile form of conv0_layer: 12 window
+// positions, rows 0..7 of the tile = output row 2p, rows 8..15 = output row 2p + 1) times TWO terms:
+//     lanes q = 0, 1: window positions 2v, 2v + 1, first term;   q = 2, 3: the same positions, second term
+//     B1 = [xh xh | xm xm]   B3 = [xh xh | xl xl]        A1 = wh   A2 = wm   A3 = [wl wl | wh wh]
+//     acc += A1 B1 (wh xh + wh xm) + A2 B1 (wm xh + wm xm) + A3 B3 (wl xh + wh xl)          -- the six largest of nine products
+// 18 MFMAs of 16 cycles per 32 output positions instead of 24 of 40.  Planes h and m of x (2 x 33 KB) fill the x region; the l
+// plane lies in the c0 region, which is empty until conv0's results are stored: the accumulators of a wave's groups stay in
+// registers until every wave is done reading (one barrier), then c0 overwrites the l plane.
+template <int INR, int INP, int OUTS, int OUTPL, int OUTP>
+struct Conv0Split {
+    static constexpr int PAIRS = (OUTS + 1) / 2, NPOS = PAIRS * OUTS, GROUPS = (NPOS + 15) / 16;
+    static constexpr int PER = (GROUPS + kCnWaves - 1) / kCnWaves;
+    f32x4 acc[PER];
+    // the B-operand byte offset of window-position pair v for this lane at group position (rp, ox)
+    static __device__ __forceinline__ int boff(int v, int sel, int rp, int ox) {
+        const int wp = 2 * v + sel, wr = wp / 3, kx = wp - wr * 3;
+        const int row = 2 * rp + wr < INR ? 2 * rp + wr : INR - 1;       // window row 3 of the last pair: re-read the last row (zero weights)
+        return (row * INP + ox + kx) * 16;
+    }
+    // Xb: planes h, m (kXPlaneB apart); Lb: plane l; Wb: the 18 A operands
+    __device__ __forceinline__ void run(const char* __restrict__ Xb, const char* __restrict__ Lb, const char* __restrict__ Wb, int wave, int lane) {
+        const int q = lane >> 4, l16 = lane & 15;
+        const int sel = q & 1, second = q >> 1;
+        const char* __restrict__ x1 = Xb + second * kXPlaneB;            // B1: h (q = 0, 1) / m (q = 2, 3)
+        const char* __restrict__ x3 = second ? Lb : Xb;                  // B3: h / l
+        bf8 aw[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) aw[i] = *reinterpret_cast<const bf8*>(Wb + (i * 64 + lane) * 16);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int g = wave + k * kCnWaves;
+            f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (g < GROUPS) {                    // wave-uniform
+                const int pos = g * 16 + l16;
+                const int pc = pos < NPOS ? pos : NPOS - 1;
+                const int rp = pc / OUTS, ox = pc - rp * OUTS;
+#pragma unroll
+                for (int v = 0; v < 6; ++v) {
+                    const int o = boff(v, sel, rp, ox);
+                    const bf8 b1 = *reinterpret_cast<const bf8*>(x1 + o);
+                    const bf8 b3 = *reinterpret_cast<const bf8*>(x3 + o);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[12 + v], b3, c, 0, 0, 0);         // A3 B3 (smaller terms first)
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[2 * v + 1], b1, c, 0, 0, 0);      // A2 B1
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[2 * v], b1, c, 0, 0, 0);          // A1 B1
+                }
+            }
+            acc[k] = c;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ Out, int gy0, int gx0, int imgH, int imgW, int wave, int lane) const {
+        const int q = lane >> 4, l16 = lane & 15;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int g = wave + k * kCnWaves;
+            const int pos = g * 16 + l16;
+            if (g < GROUPS && pos < NPOS) {
+                const int rp = pos / OUTS, ox = pos - rp * OUTS;
+                const int oy = 2 * rp + (q >> 1);
+                const int gy = gy0 + oy, gx = gx0 + ox;
+                const bool inside = gy >= 0 && gy < imgH && gx >= 0 && gx < imgW;
+                if (oy < OUTS) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Out[((q & 1) * 4 + r) * OUTPL + oy * OUTP + ox] = inside ? fmaxf(acc[k][r], 0.0f) : 0.0f;
+                }
+            }
+        }
+    }
+};
+
+// 8 channels of one position of the x tile -> its three 16-byte bf16 entries (planes h, m at Xb, plane l at Lb)
+__device__ __forceinline__ void x_split_put(char* __restrict__ Xb, char* __restrict__ Lb, int p, const float (&v)[8]) {
+    u32x4 Hh, Mm, Ll;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t h, m, l;
+        split_pair(v[2 * k], v[2 * k + 1], h, m, l);
+        Hh[k] = h; Mm[k] = m; Ll[k] = l;
+    }
+    *reinterpret_cast<u32x4*>(Xb + p * 16) = Hh;
+    *reinterpret_cast<u32x4*>(Xb + kXPlaneB + p * 16) = Mm;
+    *reinterpret_cast<u32x4*>(Lb + p * 16) = Ll;
+}
+
 // ConvTranspose2d(3, stride 2, pad 1, out_pad 1) + skip, LDS -> LDS in place: out[o] = sum_i in[i] w[o - 2i + 1].
 // The output region's origin is an ODD coordinate, so output (2a + py, 2b + px) of the region takes
 //   py = 0: rows a+1 (ky 0) and a (ky 2);  py = 1: row a+1 (ky 1)           -- same for columns --
@@ -230,7 +323,9 @@ __device__ __forceinline__ void deconv_layer(const float* __restrict__ In, float
     }
 }
 
+template <bool S3>
 __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a) {
+    constexpr int SH = S3 ? kSplitShift : 0;          // offset of layers 1..5 in the packed weight set
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* __restrict__ X = lds;
     float* __restrict__ C0 = lds + kOffC0;
@@ -245,81 +340,117 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
     const float* __restrict__ wt = a.w[m < a.seg_end[0] ? 0 : (m < a.seg_end[1] ? 1 : 2)];
     const int H = a.H, W = a.W, H2 = H >> 1, W2 = W >> 1, H4 = H >> 2, W4 = W >> 2;
 
-    // ---- x tile (+8 / +12 halo) and conv0's weights -> LDS; zeros outside the image and in the pad column ----
-    {
+    if constexpr (S3) {
+        // ---- x tile -> two bf16 planes (h, m) + conv0's split weights -> LDS; conv0 in two passes (see Conv0Split) ----
         const float* __restrict__ xm = a.x + (int64_t)m * a.x_sn;
-        // all of a wave's row loads (and conv0's weights) are issued before the first LDS write: one HBM round trip instead
-        // of one per batch
-        WeightStage<kW1 - kW0> w0s;
-        w0s.fetch(wt + kW0, tid);
-        if (a.vec4) {
-            // 16-byte loads: the region starts at column X0 - 8 (a multiple of 4, like W), so a row is 12 aligned float4 that
-            // lie entirely inside or outside the image; item = (channel, row, float4) -- 4 320 items, 5 per thread, instead of
-            // 23 dword row loads per wave (dword loads of unaligned tile rows stream at ~2.5 TB/s, aligned 16-byte ones at
-            // ~7.6: tools/ubench/tile_read.hip)
-            constexpr int ITEMS = 8 * XS * 12, PER4 = (ITEMS + kCnThreads - 1) / kCnThreads;
-            f32x4 v4[PER4];
+        char* __restrict__ Xb = reinterpret_cast<char*>(X);
+        WeightStage<kW0Split> w0s;
+        w0s.fetch(wt, tid);
+        char* __restrict__ Lb = reinterpret_cast<char*>(C0);
+        // item = one position, 8 dword loads (lanes = consecutive columns of one plane row); 45 x 46 positions (the pad column as
+        // zeros), up to 3 per thread.  (A form with aligned 16-byte loads -- 540 threads x 8 planes x float4, four positions
+        // split per thread -- measured 25.2 us per launch against 23.9 us: the split arithmetic of a position is the
+        // long pole of this phase and spreads better over all 1024 threads.)
+        float v[3][8];
 #pragma unroll
-            for (int i = 0; i < PER4; ++i) {
-                const int id = min(tid + i * kCnThreads, ITEMS - 1);
-                const int r = id / 12, j = id - r * 12;
-                const int ci = r / XS, ry = r - ci * XS;
-                const int gy = Y0 - 8 + ry, gx = X0 - 8 + 4 * j;
-                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                v4[i] = ok ? *reinterpret_cast<const f32x4*>(xm + (int64_t)ci * H * W + gy * W + gx) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            }
+        for (int k = 0; k < 3; ++k) {
+            const int p = tid + k * kCnThreads;
+            const int ry = p / XP, rx = p - ry * XP;
+            const int gy = Y0 - 8 + ry, gx = X0 - 8 + rx;
+            const bool ok = p < XS * XP && rx < XS && gy >= 0 && gy < H && gx >= 0 && gx < W;
 #pragma unroll
-            for (int i = 0; i < PER4; ++i) {
-                const int id = tid + i * kCnThreads;
-                if (id < ITEMS) {
+            for (int ci = 0; ci < 8; ++ci) v[k][ci] = ok ? xm[(int64_t)ci * H * W + gy * W + gx] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (tid + k * kCnThreads < XS * XP) x_split_put(Xb, Lb, tid + k * kCnThreads, v[k]);
+        w0s.commit(WL, tid);
+        __syncthreads();
+        Conv0Split<XS, XP, C0S, C0PL, C0P> c0;
+        WeightStage<kW2 - kW1> nw;
+        nw.fetch(wt + kW1 + SH, tid);
+        c0.run(Xb, Lb, reinterpret_cast<const char*>(WL), wave, lane);
+        __syncthreads();                                   // every wave is done with the l plane (c0 region) and conv0's weights
+        c0.store(C0, Y0 - 7, X0 - 7, H, W, wave, lane);
+        nw.commit(WL, tid);
+        __syncthreads();
+    } else {
+        // ---- x tile (+8 / +12 halo) and conv0's weights -> LDS; zeros outside the image and in the pad column ----
+        {
+            const float* __restrict__ xm = a.x + (int64_t)m * a.x_sn;
+            // all of a wave's row loads (and conv0's weights) are issued before the first LDS write: one HBM round trip instead
+            // of one per batch
+            WeightStage<kW1 - kW0> w0s;
+            w0s.fetch(wt + kW0, tid);
+            if (a.vec4) {
+                // 16-byte loads: the region starts at column X0 - 8 (a multiple of 4, like W), so a row is 12 aligned float4 that
+                // lie entirely inside or outside the image; item = (channel, row, float4) -- 4 320 items, 5 per thread, instead of
+                // 23 dword row loads per wave (dword loads of unaligned tile rows stream at ~2.5 TB/s, aligned 16-byte ones at
+                // ~7.6: tools/ubench/tile_read.hip)
+                constexpr int ITEMS = 8 * XS * 12, PER4 = (ITEMS + kCnThreads - 1) / kCnThreads;
+                f32x4 v4[PER4];
+    #pragma unroll
+                for (int i = 0; i < PER4; ++i) {
+                    const int id = min(tid + i * kCnThreads, ITEMS - 1);
                     const int r = id / 12, j = id - r * 12;
                     const int ci = r / XS, ry = r - ci * XS;
-                    float* __restrict__ d = X + ci * XPL + ry * XP + 4 * j;       // even offset: two 8-byte stores
-                    if (j < 11) {
-                        *reinterpret_cast<float2*>(d) = float2{v4[i][0], v4[i][1]};
-                        *reinterpret_cast<float2*>(d + 2) = float2{v4[i][2], v4[i][3]};
-                    } else {
-                        *reinterpret_cast<float2*>(d) = float2{v4[i][0], 0.0f};    // column 44 and the pad column; 46, 47 are the next row's
+                    const int gy = Y0 - 8 + ry, gx = X0 - 8 + 4 * j;
+                    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                    v4[i] = ok ? *reinterpret_cast<const f32x4*>(xm + (int64_t)ci * H * W + gy * W + gx) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+    #pragma unroll
+                for (int i = 0; i < PER4; ++i) {
+                    const int id = tid + i * kCnThreads;
+                    if (id < ITEMS) {
+                        const int r = id / 12, j = id - r * 12;
+                        const int ci = r / XS, ry = r - ci * XS;
+                        float* __restrict__ d = X + ci * XPL + ry * XP + 4 * j;       // even offset: two 8-byte stores
+                        if (j < 11) {
+                            *reinterpret_cast<float2*>(d) = float2{v4[i][0], v4[i][1]};
+                            *reinterpret_cast<float2*>(d + 2) = float2{v4[i][2], v4[i][3]};
+                        } else {
+                            *reinterpret_cast<float2*>(d) = float2{v4[i][0], 0.0f};    // column 44 and the pad column; 46, 47 are the next row's
+                        }
+                    }
+                }
+            } else {
+                // one (channel, row) of the region per wave iteration, lanes = columns (any alignment of x)
+                const int gx = X0 - 8 + lane;
+                const bool okx = lane < XS && gx >= 0 && gx < W;
+                constexpr int PER = (8 * XS + kCnWaves - 1) / kCnWaves;
+                float v[PER];
+    #pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int r = min(wave + i * kCnWaves, 8 * XS - 1);
+                    const int ci = r / XS, ry = r - ci * XS;             // wave-uniform
+                    const int gy = Y0 - 8 + ry;
+                    const bool ok = okx && gy >= 0 && gy < H;
+                    v[i] = ok ? xm[(int64_t)ci * H * W + gy * W + gx] : 0.0f;
+                }
+    #pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int r = wave + i * kCnWaves;
+                    if (r < 8 * XS && lane < XP) {
+                        const int ci = r / XS, ry = r - ci * XS;
+                        X[ci * XPL + ry * XP + lane] = v[i];
                     }
                 }
             }
-        } else {
-            // one (channel, row) of the region per wave iteration, lanes = columns (any alignment of x)
-            const int gx = X0 - 8 + lane;
-            const bool okx = lane < XS && gx >= 0 && gx < W;
-            constexpr int PER = (8 * XS + kCnWaves - 1) / kCnWaves;
-            float v[PER];
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int r = min(wave + i * kCnWaves, 8 * XS - 1);
-                const int ci = r / XS, ry = r - ci * XS;             // wave-uniform
-                const int gy = Y0 - 8 + ry;
-                const bool ok = okx && gy >= 0 && gy < H;
-                v[i] = ok ? xm[(int64_t)ci * H * W + gy * W + gx] : 0.0f;
-            }
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int r = wave + i * kCnWaves;
-                if (r < 8 * XS && lane < XP) {
-                    const int ci = r / XS, ry = r - ci * XS;
-                    X[ci * XPL + ry * XP + lane] = v[i];
-                }
-            }
+            w0s.commit(WL, tid);
         }
-        w0s.commit(WL, tid);
-    }
-    __syncthreads();
-    {   // c0 = relu(conv(x)): 43 x 43
-        WeightStage<kW2 - kW1> nw;
-        nw.fetch(wt + kW1, tid);
-        conv0_layer<XPL, XS, XP, C0S, C0PL, C0P>(X, C0, WL, Y0 - 7, X0 - 7, H, W, wave, lane);
         __syncthreads();
-        nw.commit(WL, tid);
+        {   // c0 = relu(conv(x)): 43 x 43
+            WeightStage<kW2 - kW1> nw;
+            nw.fetch(wt + kW1, tid);
+            conv0_layer<XPL, XS, XP, C0S, C0PL, C0P>(X, C0, WL, Y0 - 7, X0 - 7, H, W, wave, lane);
+            __syncthreads();
+            nw.commit(WL, tid);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     {   // c1 = relu(conv s2 (c0)): 21 x 21 at half resolution (over the x region)
         WeightStage<kW3 - kW2> nw;
-        nw.fetch(wt + kW2, tid);
+        nw.fetch(wt + kW2 + SH, tid);
         conv_layer<8, 16, 1, 2, C0PL, C0P, C1S, C1PL, C1P>(C0, C1, WL, (Y0 >> 1) - 3, (X0 >> 1) - 3, H2, W2, wave, lane);
         __syncthreads();
         nw.commit(WL, tid);
@@ -327,7 +458,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
     __syncthreads();
     {   // c2 = relu(conv s2 (c1)): 10 x 10 at quarter resolution
         WeightStage<kW4 - kW3> nw;
-        nw.fetch(wt + kW3, tid);
+        nw.fetch(wt + kW3 + SH, tid);
         conv_layer<16, 32, 2, 2, C1PL, C1P, C2S, C2PL, C2P>(C1, C2, WL, (Y0 >> 2) - 1, (X0 >> 2) - 1, H4, W4, wave, lane);
         __syncthreads();
         nw.commit(WL, tid);
@@ -335,7 +466,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
     __syncthreads();
     {   // u1 = c1 + deconv(c2): 18 x 18 = c1 rows / columns 2 .. 19, in place
         WeightStage<kW5 - kW4> nw;
-        nw.fetch(wt + kW4, tid);
+        nw.fetch(wt + kW4 + SH, tid);
         deconv_layer<32, 16, 9, 0, C2PL, C2P, 2, C1PL, C1P>(C2, C1, WL, (Y0 >> 1) - 1, (X0 >> 1) - 1, H2, W2, wave, lane);
         __syncthreads();
         nw.commit(WL, tid);
@@ -349,7 +480,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
     //      wave-uniform (scalar loads) ----
     if (tid < 512) {
         const int oy = tid >> 4, ox = (tid & 15) * 2;
-        float y0 = wt[kWBias], y1 = y0;
+        float y0 = wt[kWBias + SH], y1 = y0;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
@@ -358,7 +489,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
                 const float in[4] = {row[0], row[1], row[2], row[3]};
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const float wv = wt[kW5 + ci * 9 + ky * 3 + kx];
+                    const float wv = wt[kW5 + SH + ci * 9 + ky * 3 + kx];
                     y0 = fmaf(wv, in[kx], y0);
                     y1 = fmaf(wv, in[kx + 1], y1);
                 }
@@ -381,9 +512,9 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
 
 using namespace itermvs;
 
-extern "C" int itermvs_corrnet(const float* x, int64_t x_sn, const float* const* weights, const int32_t* seg_end, int32_t n_seg,
-                               int32_t M, int32_t H, int32_t W, float* out, int64_t out_sn, float* out2, int64_t out2_sn,
-                               void* stream) {
+static int launch_corrnet(const float* x, int64_t x_sn, const float* const* weights, const int32_t* seg_end, int32_t n_seg,
+                          int32_t M, int32_t H, int32_t W, float* out, int64_t out_sn, float* out2, int64_t out2_sn, bool split3,
+                          void* stream) {
     ITERMVS_RETURN_IF(!x || !weights || !out, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(M < 1 || H < 4 || W < 4 || (H & 3) || (W & 3) || n_seg < 1 || n_seg > 3, ITERMVS_ERR_DIMS);
     CorrNetArgs a;
@@ -398,10 +529,25 @@ extern "C" int itermvs_corrnet(const float* x, int64_t x_sn, const float* const*
     a.out = out; a.out2 = out2; a.out_sn = out_sn; a.out2_sn = out2_sn;
     a.vec4 = (((uintptr_t)x) % 16 == 0 && x_sn % 4 == 0) ? 1 : 0;
     a.M = M; a.H = H; a.W = W; a.tiles_x = (W + kCnTile - 1) / kCnTile;
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(corrnet_kernel),
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(corrnet_kernel<false>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kCnLdsFloats * 4) == hipSuccess &&
+                                hipFuncSetAttribute(reinterpret_cast<const void*>(corrnet_kernel<true>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kCnLdsFloats * 4) == hipSuccess;
     ITERMVS_RETURN_IF(!attr_ok, ITERMVS_ERR_LAUNCH);
     const dim3 grid(a.tiles_x * ((H + kCnTile - 1) / kCnTile), M);
-    hipLaunchKernelGGL(corrnet_kernel, grid, dim3(kCnThreads), kCnLdsFloats * 4, (hipStream_t)stream, a);
+    if (split3) hipLaunchKernelGGL(corrnet_kernel<true>, grid, dim3(kCnThreads), kCnLdsFloats * 4, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(corrnet_kernel<false>, grid, dim3(kCnThreads), kCnLdsFloats * 4, (hipStream_t)stream, a);
     return itermvs_launch_status();
+}
+
+extern "C" int itermvs_corrnet(const float* x, int64_t x_sn, const float* const* weights, const int32_t* seg_end, int32_t n_seg,
+                               int32_t M, int32_t H, int32_t W, float* out, int64_t out_sn, float* out2, int64_t out2_sn,
+                               void* stream) {
+    return launch_corrnet(x, x_sn, weights, seg_end, n_seg, M, H, W, out, out_sn, out2, out2_sn, false, stream);
+}
+
+extern "C" int itermvs_corrnet_bf16x3(const float* x, int64_t x_sn, const float* const* weights, const int32_t* seg_end, int32_t n_seg,
+                                      int32_t M, int32_t H, int32_t W, float* out, int64_t out_sn, float* out2, int64_t out2_sn,
+                                      void* stream) {
+    return launch_corrnet(x, x_sn, weights, seg_end, n_seg, M, H, W, out, out_sn, out2, out2_sn, true, stream);
 }

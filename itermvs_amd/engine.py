@@ -143,7 +143,7 @@ class InferenceEngine:
         self.conf_dot = torch.cat([w[cf + "weight"].reshape(-1), w[cf + "bias"].reshape(-1)]).float().contiguous()
         self.pvw_dot = torch.cat([w[pv + "weight"].reshape(-1), w[pv + "bias"].reshape(-1)]).float().contiguous()
         self.stem_w = ops.pack_stem_weights(*self.cbr["conv1."], *self.cbr["layer1.0.conv1."], *self.cbr["layer1.0.downsample."])
-        self.corrnet_w = {l: ops.pack_corrnet_weights(w, f"iter_mvs.evaluation.corr_conv1.{l - 1}.") for l in (1, 2, 3)}
+        self.corrnet_w = {l: ops.pack_corrnet_weights(w, f"iter_mvs.evaluation.corr_conv1.{l - 1}.", split3=self.split3) for l in (1, 2, 3)}
         dh = "iter_mvs.update.depth_head."
         self.head_w1, self.head_w2 = ops.pack_head_weights(w[dh + "2.weight"], w[dh + "4.weight"])
         # (z / r gates, 43 -> 64 dilated at 1/4 resolution: the bf16x3 form measured 18.7 us against 18.2 us -- four channel

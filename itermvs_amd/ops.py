@@ -1122,6 +1122,7 @@ def fuse_depth(depth_ref: Tensor, conf_ref: Tensor, depth_src: Sequence[Tensor],
 
 
 CORRNET_WEIGHT_FLOATS = 14288
+CORRNET_WEIGHT_FLOATS_SPLIT3 = 14288 - 1536 + 4608          # conv0 as bf16x3 operands (itermvs_corrnet_bf16x3)
 
 
 def _mfma_operand_order(w_tap_ci_co: Tensor, co_pad: int) -> Tensor:
@@ -1132,10 +1133,11 @@ def _mfma_operand_order(w_tap_ci_co: Tensor, co_pad: int) -> Tensor:
     return out.reshape(-1)
 
 
-def pack_corrnet_weights(w: Dict[str, Tensor], prefix: str) -> Tensor:
+def pack_corrnet_weights(w: Dict[str, Tensor], prefix: str, split3: bool = False) -> Tensor:
     """the six layers of one CorrNet (state-dict names ``prefix`` + conv0.conv.weight ... conv5.bias) in the layout of
     itermvs_corrnet (include/itermvs_hip.h): the five matrix-core layers in operand order [tap][k-step][q][co], conv5 as
-    [ci][tap], the bias, padding"""
+    [ci][tap], the bias, padding.  ``split3``: the set of itermvs_corrnet_bf16x3 -- conv0 as the bf16 A operands of its 18
+    v_mfma_f32_16x16x32_bf16 ([mfma][q][row m][8 channels], three-term split of the fp32 weights), layers 1..5 unchanged."""
     conv = lambda name, pad: _mfma_operand_order(w[prefix + name].float().permute(2, 3, 1, 0).reshape(9, w[prefix + name].shape[1], -1), pad)
     # ConvTranspose2d weights are [ci, co, ky, kx]
     dconv = lambda name, pad: _mfma_operand_order(w[prefix + name].float().permute(2, 3, 0, 1).reshape(9, w[prefix + name].shape[0], -1), pad)
@@ -1145,11 +1147,24 @@ def pack_corrnet_weights(w: Dict[str, Tensor], prefix: str) -> Tensor:
     two = torch.zeros((4, 3, 8, 16), device=w0.device, dtype=torch.float32)
     two[0:3, :, :, 0:8] = w0.permute(2, 3, 1, 0)
     two[1:4, :, :, 8:16] = w0.permute(2, 3, 1, 0)
-    parts = [_mfma_operand_order(two.reshape(12, 8, 16), 16), conv("conv1.conv.weight", 16), conv("conv2.conv.weight", 32),
+    if split3:
+        wh, wm, wl = split_bf16x3(two)                                              # each [4, 3, 8 ci, 16 rows] bf16
+        wp = lambda t: t.reshape(12, 8, 16).permute(0, 2, 1)                        # [window position 12, row m 16, ci 8]
+        h, m_, l = wp(wh), wp(wm), wp(wl)
+        ops_a = []
+        for v in range(6):                  # MFMA 2v = [h h | h h], 2v + 1 = [m m | m m]: lanes q = 0..3 -> window position 2v + (q & 1)
+            for term in (h, m_):
+                ops_a.append(torch.stack([term[2 * v], term[2 * v + 1], term[2 * v], term[2 * v + 1]]))       # [q 4, m 16, ci 8]
+        for v in range(6):                  # MFMA 12 + v = [l l | h h]
+            ops_a.append(torch.stack([l[2 * v], l[2 * v + 1], h[2 * v], h[2 * v + 1]]))
+        first = torch.stack(ops_a).contiguous().view(torch.int16).reshape(-1).view(torch.float32)              # 18 x 64 x 8 bf16 = 4608 floats
+    else:
+        first = _mfma_operand_order(two.reshape(12, 8, 16), 16)
+    parts = [first, conv("conv1.conv.weight", 16), conv("conv2.conv.weight", 32),
              dconv("conv3.weight", 16), dconv("conv4.weight", 16),
              w[prefix + "conv5.weight"].float().permute(1, 2, 3, 0).reshape(-1), w[prefix + "conv5.bias"].float().reshape(-1)]
     flat = torch.cat(parts + [torch.zeros(7, device=parts[0].device)])
-    assert flat.numel() == CORRNET_WEIGHT_FLOATS
+    assert flat.numel() == (CORRNET_WEIGHT_FLOATS_SPLIT3 if split3 else CORRNET_WEIGHT_FLOATS)
     return flat.contiguous()
 
 
@@ -1218,6 +1233,13 @@ def corrnet(x: Tensor, weight_sets: Sequence[Tensor], seg_end: Sequence[int] = (
             raise RuntimeError(f"corrnet: output has shape {tuple(t.shape)}, expected {(m, 1, h, w)}")
     wp = (C.c_void_p * len(weight_sets))(*[_dev(t, "corrnet weights").data_ptr() for t in weight_sets])
     se = (C.c_int32 * 3)(*(list(seg_end) + [m] * (3 - len(seg_end))))
+    sizes = {t.numel() for t in weight_sets}
+    if sizes == {CORRNET_WEIGHT_FLOATS_SPLIT3}:
+        check(_lib.load().itermvs_corrnet_bf16x3(ptr, x_sn, wp, se, len(weight_sets), m, h, w, po, o_sn, p2, o2_sn, _stream()),
+              "itermvs_corrnet_bf16x3")
+        return out
+    if sizes != {CORRNET_WEIGHT_FLOATS}:
+        raise RuntimeError("corrnet: weight sets must all come from pack_corrnet_weights (one arithmetic)")
     check(_lib.load().itermvs_corrnet(ptr, x_sn, wp, se, len(weight_sets), m, h, w, po, o_sn, p2, o2_sn, _stream()), "itermvs_corrnet")
     return out
 

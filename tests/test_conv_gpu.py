@@ -260,9 +260,18 @@ def test_corrnet_one_launch_matches_torch(case):
         u0 = c0 + F.conv_transpose2d(u1, wts[p + "conv4.weight"], stride=2, padding=1, output_padding=1)
         want.append(F.conv2d(u0, wts[p + "conv5.weight"], wts[p + "conv5.bias"], padding=1))
     want = torch.cat(want)
-    packs = [ops().pack_corrnet_weights(wts, f"iter_mvs.evaluation.corr_conv1.{l - 1}.") for l in levels]
+    # (the file's fixture runs this test twice: conv0 on the bf16 matrix instruction with the exact three-term split, and in fp32)
+    split3 = ops().MFMA_SPLIT3_DEFAULT
+    packs = [ops().pack_corrnet_weights(wts, f"iter_mvs.evaluation.corr_conv1.{l - 1}.", split3=split3) for l in levels]
     got = ops().corrnet(x, packs, seg_end)
     assert got.shape == want.shape and rel_err(got, want) <= 3e-6, rel_err(got, want)
+    if split3:                                # any alignment of the input: same bits
+        buf = torch.zeros((x.numel() + 4,), device=DEV)
+        xo = buf[1:1 + x.numel()].view(x.shape)
+        xo.copy_(x)
+        assert torch.equal(ops().corrnet(xo, packs, seg_end), got)
+        with pytest.raises(RuntimeError):     # one arithmetic per launch
+            ops().corrnet(x, [packs[0], ops().pack_corrnet_weights(wts, "iter_mvs.evaluation.corr_conv1.0.", split3=False)][:max(2, len(packs))], (1,))
     if m == 10:                               # the GRU input buffers take the ten score planes in place
         wide = torch.zeros((1, 43, h, w), device=DEV)
         wide2 = torch.zeros((1, 43, h, w), device=DEV)

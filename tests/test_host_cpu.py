@@ -164,6 +164,20 @@ def test_weight_packings_of_the_fused_kernels():
     w = {"p." + k: torch.randn(v, generator=g) for k, v in names.items()}
     pk = ops.pack_corrnet_weights(w, "p.")
     assert pk.numel() == ops.CORRNET_WEIGHT_FLOATS
+    pk3 = ops.pack_corrnet_weights(w, "p.", split3=True)
+    assert pk3.numel() == ops.CORRNET_WEIGHT_FLOATS_SPLIT3 and torch.equal(pk3[4608:], pk[1536:])    # layers 1..5 unchanged
+    # conv0's bf16 operands: MFMA 2v / 2v+1 / 12+v of window-position pair v hold terms [h h|h h] / [m m|m m] / [l l|h h]; their sum over
+    # the three terms of a position is the fp32 weight exactly
+    a = pk3[:4608].view(torch.int16).view(torch.bfloat16).reshape(18, 4, 16, 8).float()
+    w0c = w["p.conv0.conv.weight"].float()
+    two = torch.zeros((4, 3, 8, 16))
+    two[0:3, :, :, 0:8] = w0c.permute(2, 3, 1, 0)
+    two[1:4, :, :, 8:16] = w0c.permute(2, 3, 1, 0)
+    full = two.reshape(12, 8, 16).permute(0, 2, 1)                                   # [window position, row, ci]
+    for v in range(6):
+        for sel in (0, 1):
+            assert torch.equal(a[2 * v, sel] + a[2 * v + 1, sel] + a[12 + v, sel], full[2 * v + sel])
+            assert torch.equal(a[2 * v, sel], a[2 * v, 2 + sel]) and torch.equal(a[12 + v, 2 + sel], a[2 * v, sel])
     c0 = w["p.conv0.conv.weight"]
     wr, kx, ks, q, co = 2, 1, 1, 2, 3                    # window row 2: tap row 2 of the first output row, tap row 1 of the second
     idx = (((wr * 3 + kx) * 2 + ks) * 4 + q) * 16

@@ -16,13 +16,18 @@ dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(1)
 shape = (10, 8, 128, 160)
 n = 10 * 8 * 128 * 160
-buf = torch.randn((n + 4,), generator=g).to(dev)
-packs = [(torch.randn((ops.CORRNET_WEIGHT_FLOATS,), generator=g) * 0.1).to(dev) for _ in range(3)]
+buf = torch.zeros((n + 4,), device=dev)
+data = torch.randn(shape, generator=g).to(dev)
+names = {"conv0.conv.weight": (8, 8, 3, 3), "conv1.conv.weight": (16, 8, 3, 3), "conv2.conv.weight": (32, 16, 3, 3),
+         "conv3.weight": (32, 16, 3, 3), "conv4.weight": (16, 8, 3, 3), "conv5.weight": (1, 8, 3, 3), "conv5.bias": (1,)}
+wts = {f"p{l}." + k: (torch.randn(v, generator=g) * 0.2).to(dev) for l in range(3) for k, v in names.items()}
+packs_by = {s3: [ops.pack_corrnet_weights(wts, f"p{l}.", split3=s3) for l in range(3)] for s3 in (False, True)}
 outs = {}
-for name, off in (("aligned (float4 staging)", 0), ("offset by 4 bytes (dword staging)", 1)):
+for name, off, s3 in (("aligned (float4 staging), fp32 MFMA", 0, False), ("offset by 4 bytes (dword staging), fp32 MFMA", 1, False),
+                      ("aligned, conv0 bf16x3", 0, True), ("offset by 4 bytes, conv0 bf16x3", 1, True)):
+    packs = packs_by[s3]
     x = buf[off:off + n].view(shape)
-    if off:
-        x.copy_(buf[:n].clone().view(shape))
+    x.copy_(data)
     out = torch.empty((10, 1, 128, 160), device=dev)
     run = lambda: ops.corrnet(x, packs, (4, 8), out=out)
     st = torch.cuda.Stream()
@@ -45,5 +50,6 @@ for name, off in (("aligned (float4 staging)", 0), ("offset by 4 bytes (dword st
             best = min(best, e0.elapsed_time(e1) / 20 * 1e3)
     outs[name] = out.clone()
     print(f"corrnet, x {name}: {best:.1f} us per launch")
-a, b = outs.values()
-print("arms bit-identical:", bool(torch.equal(a, b)))
+a, b, c, d = outs.values()
+print("fp32 arms bit-identical:", bool(torch.equal(a, b)), " bf16x3 arms bit-identical:", bool(torch.equal(c, d)))
+print("max |fp32 - bf16x3| / max |fp32| =", float((a - c).abs().max() / a.abs().max()))
