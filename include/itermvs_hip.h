@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define ITERMVS_ABI_VERSION 9
+#define ITERMVS_ABI_VERSION 10
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -335,6 +335,22 @@ int itermvs_head_fused_conf(const float* hidden, int64_t hidden_sb, int32_t B, i
 int itermvs_conv3x3_conv1x1(const float* x, int64_t x_sb, int32_t B, int32_t H, int32_t W, const float* w0_tile,
                             const float* w1_packed, const float* bias1, int32_t NO, float* out, int64_t out_sb, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * itermvs_res_chain16 -- the three 3x3 16 -> 16 convolutions that follow the stem in FeatureNet's half-resolution stage
+ * (models/net.py:13,40 `layer1` = two ResidualBlocks, models/module.py:33-50; BatchNorm folded) in ONE launch:
+ *     a = relu(conv(y1; W0) + b0 + shortcut)     layer1[0].conv2 + layer1[0].downsample's result
+ *     b = relu(conv(a;  W1) + b1)                layer1[1].conv1
+ *     out = relu(conv(b; W2) + b2 + a)           layer1[1].conv2 + skip
+ * a and b never leave LDS.  Arithmetic: the bf16x3 form of itermvs_conv2d's weight_format 3 (both operands split exactly
+ * into three bf16 terms, six cross products on v_mfma_f32_16x16x32_bf16, fp32 accumulation).
+ *   y1, shortcut [N,16,H,W] (image strides y1_sn / shortcut_sn, elements): itermvs_stem's two results, in_layout = the
+ *   out_layout they were written with (0 planes, 1 channel quads [N,4,H,W,4]: a quarter of the load instructions);
+ *   weights[3]: each layer's weight in weight_format 3 = bf16 [9][1][3][16][16] (itermvs_amd.ops.MfmaWeight(...).tile3), 16-byte
+ *   aligned; bias[3]: 16 floats each (NULL = none); out [N,16,H,W] planes.  H, W <= 4095.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_res_chain16(const float* y1, int64_t y1_sn, const float* shortcut, int64_t shortcut_sn, int32_t in_layout, int32_t N,
+                        int32_t H, int32_t W, const void* const* weights, const float* const* bias, float* out, int64_t out_sn, void* stream);
+
 
 
 /* ------------------------------------------------------------------------------------------
@@ -490,14 +506,16 @@ int itermvs_corrnet_bf16x3(const float* x, int64_t x_sn, const float* const* wei
  *   w0: 224 floats = conv1 weight as [ci][ky][kx][co 8] then its 8 biases;
  *   w1: 2336 floats = the two stride-2 layers' weights, output channels concatenated (conv1 branch first), in matrix-core
  *   operand order [tap = ky*3+kx][k-step = ci/4][q = ci%4][co 32], then the 32 biases (itermvs_amd.ops.pack_stem_weights).
+ *   out_layout: 0 = planes [M,16,H2,W2]; 1 = channel quads [M,4,H2,W2,4] (channel 4*cq + c of pixel p at ((cq*H2*W2 + p)*4 + c):
+ *   the layout itermvs_res_chain16 fetches with 16-byte loads; y, sc 16-byte aligned, out_sn a multiple of 4).
  * ------------------------------------------------------------------------------------------ */
 int itermvs_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
-                 float* y, float* sc, int64_t out_sn, void* stream);
+                 float* y, float* sc, int64_t out_sn, int32_t out_layout, void* stream);
 /* itermvs_stem_compose -- itermvs_stem and, in the SAME launch (its first workgroup), itermvs_compose_proj with its arguments
  * (mats .. inv_max; Bd = batch size of the depth range; module.py:77-90, itermvs.py:267-268): the composition depends on the
  * cameras only, so its ~10 us fp64 chain hides behind the first, longest launch of FeatureNet. */
 int itermvs_stem_compose(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
-                         float* y, float* sc, int64_t out_sn, const float* mats, int32_t n_sets, int32_t V, float* proj_out,
+                         float* y, float* sc, int64_t out_sn, int32_t out_layout, const float* mats, int32_t n_sets, int32_t V, float* proj_out,
                          int32_t* nan_flag, const float* depth_min, const float* depth_max, int32_t Bd, float* inv_min,
                          float* inv_max, void* stream);
 

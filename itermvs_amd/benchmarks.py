@@ -109,11 +109,13 @@ def box_probe(dev, repeats: int = 5) -> Dict[str, float]:
     return out
 
 
-def workload_clock(dev, replay, n: int = 20) -> float:
+def workload_clock(dev, replay, n: int = 20) -> Optional[float]:
     """shader clock (MHz) the chip sustains while ``replay()`` -- one depth map's hipGraph -- runs ``n`` times: two one-lane
     stamps of (100 MHz counter, shader-clock counter) bracket the replays on the stream.  The boxes of the pool differ by up to
     6 % in depth-maps/s with equal matrix-pipe and copy rates under sustained load (profiles/r06_box_probe.md): the clock a chip
-    holds under THIS bursty, latency-bound workload is what differs."""
+    holds under THIS bursty, latency-bound workload is what differs.
+    The ratio is only a clock when both counters ran through the bracket undisturbed: on some boxes of the pool it comes out at
+    3 400 or 10 000 "MHz" (above anything the chip can clock, profiles/r06_box_probe.md) -- such a figure is reported as None."""
     from . import ops
     a, b = torch.zeros((16, 2), device=dev, dtype=torch.int64), torch.zeros((16, 2), device=dev, dtype=torch.int64)
     replay()
@@ -126,7 +128,8 @@ def workload_clock(dev, replay, n: int = 20) -> float:
     a, b = a.tolist(), b.tolist()
     # per XCD (the counters of different XCDs are not aligned): slots both stamps filled
     mhz = sorted(float(b[i][1] - a[i][1]) / (b[i][0] - a[i][0]) * 100.0 for i in range(16) if a[i][0] and b[i][0] > a[i][0])
-    return mhz[len(mhz) // 2] if mhz else 0.0
+    med = mhz[len(mhz) // 2] if mhz else None
+    return med if med is not None and 500.0 <= med <= 2600.0 else None
 
 
 def normalised(value: float, box: Dict[str, float], corr_iter_ms: Optional[float] = None) -> Optional[Dict[str, float]]:

@@ -38,6 +38,7 @@ struct StemArgs {
     float* sc;
     int64_t x_sn, out_sn;
     int M, H, W, H2, W2, tiles_x, tiles_y;
+    int out_c4;      // results as [M][4][H2][W2][4] (a lane's four channels of a pixel are one 16-byte store) instead of planes
 };
 
 using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -200,13 +201,20 @@ __global__ __launch_bounds__(kStThreads) void stem_kernel(StemArgs a, int tiles,
             }
             const int gy = oy0 + oy, gx = ox0 + oxl;
             if (gy < a.H2 && gx < a.W2) {
-                const int64_t o = (int64_t)n * a.out_sn + (int64_t)(q * 4) * oplane + gy * a.W2 + gx;
-                float* __restrict__ yo = a.y + o;
-                float* __restrict__ so = a.sc + o;
+                if (a.out_c4) {
+                    const int64_t o = (int64_t)n * a.out_sn + ((int64_t)q * oplane + gy * a.W2 + gx) * 4;
+                    *reinterpret_cast<f32x4*>(a.y + o) =
+                        f32x4{fmaxf(acc[0][0], 0.0f), fmaxf(acc[0][1], 0.0f), fmaxf(acc[0][2], 0.0f), fmaxf(acc[0][3], 0.0f)};
+                    *reinterpret_cast<f32x4*>(a.sc + o) = acc[1];
+                } else {
+                    const int64_t o = (int64_t)n * a.out_sn + (int64_t)(q * 4) * oplane + gy * a.W2 + gx;
+                    float* __restrict__ yo = a.y + o;
+                    float* __restrict__ so = a.sc + o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    yo[r * oplane] = fmaxf(acc[0][r], 0.0f);
-                    so[r * oplane] = acc[1][r];
+                    for (int r = 0; r < 4; ++r) {
+                        yo[r * oplane] = fmaxf(acc[0][r], 0.0f);
+                        so[r * oplane] = acc[1][r];
+                    }
                 }
             }
         }
@@ -217,10 +225,12 @@ __global__ __launch_bounds__(kStThreads) void stem_kernel(StemArgs a, int tiles,
 }  // namespace itermvs
 
 static int launch_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
-                       float* y, float* sc, int64_t out_sn, const itermvs::ComposeArgs* comp, void* stream) {
+                       float* y, float* sc, int64_t out_sn, int32_t out_layout, const itermvs::ComposeArgs* comp, void* stream) {
     using namespace itermvs;
     if (!x || !w0 || !w1 || !y || !sc) return ITERMVS_ERR_NULL;
     if (M < 0 || H < 1 || W < 1) return ITERMVS_ERR_DIMS;
+    if (out_layout != 0 && out_layout != 1) return ITERMVS_ERR_LAYOUT;
+    if (out_layout == 1 && (((uintptr_t)y | (uintptr_t)sc) % 16 || out_sn % 4)) return ITERMVS_ERR_ALIGN;
     ComposeArgs c{};
     int n_comp = 0;
     if (comp) {
@@ -232,7 +242,7 @@ static int launch_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, int32
     if (M == 0 && n_comp == 0) return ITERMVS_OK;
     StemArgs a;
     a.x = x; a.w0 = w0; a.w1 = w1; a.y = y; a.sc = sc;
-    a.x_sn = x_sn; a.out_sn = out_sn;
+    a.x_sn = x_sn; a.out_sn = out_sn; a.out_c4 = out_layout;
     a.M = M; a.H = H; a.W = W;
     a.H2 = (H - 1) / 2 + 1; a.W2 = (W - 1) / 2 + 1;
     static const int th = [] { const char* e = itermvs_tuning_env("ITERMVS_STEM_TH"); return e && atoi(e) == 4 ? 4 : 8; }();
@@ -249,12 +259,12 @@ static int launch_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, int32
 }
 
 extern "C" int itermvs_stem(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
-                            float* y, float* sc, int64_t out_sn, void* stream) {
-    return launch_stem(x, x_sn, M, H, W, w0, w1, y, sc, out_sn, nullptr, stream);
+                            float* y, float* sc, int64_t out_sn, int32_t out_layout, void* stream) {
+    return launch_stem(x, x_sn, M, H, W, w0, w1, y, sc, out_sn, out_layout, nullptr, stream);
 }
 
 extern "C" int itermvs_stem_compose(const float* x, int64_t x_sn, int32_t M, int32_t H, int32_t W, const float* w0, const float* w1,
-                                    float* y, float* sc, int64_t out_sn, const float* mats, int32_t n_sets, int32_t V,
+                                    float* y, float* sc, int64_t out_sn, int32_t out_layout, const float* mats, int32_t n_sets, int32_t V,
                                     float* proj_out, int32_t* nan_flag, const float* depth_min, const float* depth_max, int32_t Bd,
                                     float* inv_min, float* inv_max, void* stream) {
     ITERMVS_RETURN_IF(!mats || !proj_out, ITERMVS_ERR_NULL);
@@ -262,5 +272,5 @@ extern "C" int itermvs_stem_compose(const float* x, int64_t x_sn, int32_t M, int
     ITERMVS_RETURN_IF(n_sets < 1, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(V < 2 || V - 1 > ITERMVS_MAX_SRC, ITERMVS_ERR_VIEWS);
     const itermvs::ComposeArgs c{mats, proj_out, nan_flag, depth_min, depth_max, inv_min, inv_max, n_sets, V, Bd};
-    return launch_stem(x, x_sn, M, H, W, w0, w1, y, sc, out_sn, &c, stream);
+    return launch_stem(x, x_sn, M, H, W, w0, w1, y, sc, out_sn, out_layout, &c, stream);
 }

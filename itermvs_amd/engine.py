@@ -197,11 +197,17 @@ class InferenceEngine:
         o1, o2, o3 = cl(16, 2), cl(32, 4), cl(48, 8)
         self.o2_planar = torch.empty((m, 32, hh // 4, ww // 4), device=dev)
         # conv1 + layer1[0].conv1 / .downsample in one launch, fea0 never leaves LDS (+ the camera composition, module.py:77-90)
+        # (bf16x3 arithmetic: the stem's two results go to the chain kernel as channel quads -- 16-byte stores and loads)
         if compose is not None:
-            y, sc, *self.composed = ops.stem(x, *self.stem_w, compose=compose)
+            y, sc, *self.composed = ops.stem(x, *self.stem_w, compose=compose, quads=self.split3)
         else:
-            y, sc = ops.stem(x, *self.stem_w)
-        f1 = self._res(self._cbr(y, "layer1.0.conv2.", 1, "relu", add=sc), "layer1.1.", 1)
+            y, sc = ops.stem(x, *self.stem_w, quads=self.split3)
+        if self.split3:
+            # layer1[0].conv2 (+ shortcut) and both layers of layer1[1] in one launch, the two intermediate maps in LDS (res_chain.hip)
+            names = ("layer1.0.conv2.", "layer1.1.conv1.", "layer1.1.conv2.")
+            f1 = ops.res_chain16(y, sc, [self.pk[p + k] for k in names], [self.cbr[k][1] for k in names], quads=True)
+        else:
+            f1 = self._res(self._cbr(y, "layer1.0.conv2.", 1, "relu", add=sc), "layer1.1.", 1)
         f2 = self._res(self._res(f1, "layer2.0.", 2), "layer2.1.", 1)
         f3 = self._res(self._res(f2, "layer3.0.", 2), "layer3.1.", 1)
         self._conv(f3, p + "output3.", bias=True, channels_last_out=True, out=o3)
@@ -564,7 +570,10 @@ class GraphedRunner:
                 gc_was_on = gc.isenabled()
                 gc.disable()
                 try:
-                    self.graph.capture_begin()
+                    # thread_local: calls other host threads make meanwhile (scan_dataset.Prefetcher's decoder pins the next
+                    # sample = hipHostMalloc) are legal and leave this capture alone; in the default global mode such a call
+                    # invalidated the capture now and then ("operation not permitted when stream is capturing")
+                    self.graph.capture_begin(capture_error_mode="thread_local")
                     self.out = engine.run(self.imgs, self.proj_stack, self.depth_min, self.depth_max, composed=self.composed)
                     self.graph.capture_end()
                 finally:

@@ -1185,11 +1185,13 @@ def pack_stem_weights(w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor, wd: Tensor
     return p0, p1
 
 
-def stem(x: Tensor, w0: Tensor, w1: Tensor, compose=None):
+def stem(x: Tensor, w0: Tensor, w1: Tensor, compose=None, quads: bool = False):
     """itermvs_stem: x [M,3,H,W] -> (relu(layer1[0].conv1(f0)), layer1[0].downsample(f0)) with f0 = FeatureNet.conv1(x)
     kept in LDS; both [M,16,H2,W2].  ``w0`` / ``w1`` from pack_stem_weights.
     ``compose`` = (mats [n,V,4,4], nan_flag | None, (depth_min, depth_max)): itermvs_stem_compose -- the camera composition
-    (compose_proj + inverse depth range) rides in the same launch; returns (y, sc, proj [n,V-1,12], inv_min, inv_max)."""
+    (compose_proj + inverse depth range) rides in the same launch; returns (y, sc, proj [n,V-1,12], inv_min, inv_max).
+    ``quads``: y and sc are written as channel quads -- tensors of shape [M,4,H2,W2,4] holding channel 4*cq + c at [m,cq,y,x,c] --
+    the layout res_chain16(..., quads=True) fetches with 16-byte loads."""
     ptr, x_sn = _planes(x, "stem input")
     m, c, h, w = x.shape
     if c != 3:
@@ -1197,7 +1199,7 @@ def stem(x: Tensor, w0: Tensor, w1: Tensor, compose=None):
     if w0.numel() != STEM_W0_FLOATS or w1.numel() != STEM_W1_FLOATS:
         raise RuntimeError("stem: weights must come from pack_stem_weights")
     h2, w2 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    y = torch.empty((m, 16, h2, w2), device=x.device, dtype=torch.float32)
+    y = torch.empty((m, 4, h2, w2, 4) if quads else (m, 16, h2, w2), device=x.device, dtype=torch.float32)
     sc = torch.empty_like(y)
     if compose is not None:
         mats, nan_flag, depth_range = compose
@@ -1207,13 +1209,53 @@ def stem(x: Tensor, w0: Tensor, w1: Tensor, compose=None):
         dmin, dmax = (_dev(t, "depth range").contiguous() for t in depth_range)
         imin, imax = torch.empty_like(dmin), torch.empty_like(dmax)
         check(_lib.load().itermvs_stem_compose(ptr, x_sn, m, h, w, _dev(w0, "stem weights").data_ptr(), _dev(w1, "stem weights").data_ptr(),
-                                               y.data_ptr(), sc.data_ptr(), 16 * h2 * w2, mats.data_ptr(), n, v, proj.data_ptr(),
+                                               y.data_ptr(), sc.data_ptr(), 16 * h2 * w2, int(quads), mats.data_ptr(), n, v, proj.data_ptr(),
                                                _ptr(nan_flag), dmin.data_ptr(), dmax.data_ptr(), dmin.numel(), imin.data_ptr(),
                                                imax.data_ptr(), _stream()), "itermvs_stem_compose")
         return y, sc, proj, imin, imax
     check(_lib.load().itermvs_stem(ptr, x_sn, m, h, w, _dev(w0, "stem weights").data_ptr(), _dev(w1, "stem weights").data_ptr(),
-                             y.data_ptr(), sc.data_ptr(), 16 * h2 * w2, _stream()), "itermvs_stem")
+                             y.data_ptr(), sc.data_ptr(), 16 * h2 * w2, int(quads), _stream()), "itermvs_stem")
     return y, sc
+
+
+def res_chain16(y1: Tensor, shortcut: Tensor, weights: Sequence["MfmaWeight"], biases: Sequence[Optional[Tensor]],
+                out: Optional[Tensor] = None, quads: bool = False) -> Tensor:
+    """itermvs_res_chain16: FeatureNet.layer1 behind the stem in one launch -- a = relu(conv(y1; W0) + b0 + shortcut),
+    b = relu(conv(a; W1) + b1), out = relu(conv(b; W2) + b2 + a); ``y1`` / ``shortcut`` [N,16,H,W] (ops.stem's results) or,
+    with ``quads``, [N,4,H,W,4] (ops.stem(..., quads=True)); ``weights``: the three layers' MfmaWeight (bf16x3 form, 16 -> 16),
+    ``biases``: [16] each or None.  ``out`` [N,16,H,W] planes."""
+    if quads:
+        for t, name in ((y1, "res_chain16 input"), (shortcut, "res_chain16 shortcut")):
+            _dev(t, name)
+            if t.dim() != 5 or t.shape[1] != 4 or t.shape[4] != 4 or not t.is_contiguous():
+                raise RuntimeError(f"{name}: quads layout is a contiguous [N,4,H,W,4] tensor")
+        n, _, h, w, _ = y1.shape
+        if tuple(shortcut.shape) != tuple(y1.shape):
+            raise RuntimeError("res_chain16: input and shortcut differ in shape")
+        ptr, y_sn, sp, s_sn = y1.data_ptr(), 16 * h * w, shortcut.data_ptr(), 16 * h * w
+    else:
+        ptr, y_sn = _planes(y1, "res_chain16 input")
+        sp, s_sn = _planes(shortcut, "res_chain16 shortcut")
+        n, c, h, w = y1.shape
+        if c != 16 or tuple(shortcut.shape) != (n, c, h, w):
+            raise RuntimeError("res_chain16: expects two [N,16,H,W] tensors")
+    if len(weights) != 3 or len(biases) != 3:
+        raise RuntimeError("res_chain16: three layers")
+    for wt in weights:
+        if not isinstance(wt, MfmaWeight) or wt.tile3 is None or wt.cin != 16 or wt.cout != 16 or wt.ksize != 3:
+            raise RuntimeError("res_chain16: weights must be 3x3 16 -> 16 MfmaWeight built with split3=True")
+        if not wt.tile3.is_cuda or wt.tile3.dtype != torch.bfloat16:
+            raise RuntimeError("res_chain16 weights: expected bfloat16 ROCm tensors (MfmaWeight.tile3)")
+    if out is None:
+        out = torch.empty((n, 16, h, w), device=y1.device, dtype=torch.float32)
+    elif tuple(out.shape) != (n, 16, h, w):
+        raise RuntimeError(f"res_chain16: output has shape {tuple(out.shape)}, expected {(n, 16, h, w)}")
+    po, o_sn = _planes(out, "res_chain16 output")
+    wp = (C.c_void_p * 3)(*[wt.tile3.data_ptr() for wt in weights])
+    bl = [None if b is None else _dev(b, "res_chain16 bias").float().contiguous() for b in biases]
+    bp = (C.c_void_p * 3)(*[_ptr(b) for b in bl])
+    check(_lib.load().itermvs_res_chain16(ptr, y_sn, sp, s_sn, int(quads), n, h, w, wp, bp, po, o_sn, _stream()), "itermvs_res_chain16")
+    return out
 
 
 def corrnet(x: Tensor, weight_sets: Sequence[Tensor], seg_end: Sequence[int] = (), out: Optional[Tensor] = None,

@@ -97,7 +97,7 @@ class CapturedTrainStep:
             self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
                 self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph, stream=self.stream):
+                with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):   # data-loader threads may pin memory meanwhile
                     self.out = self._step(self.static)
             cur.wait_stream(self.stream)
         else:

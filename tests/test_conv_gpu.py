@@ -321,5 +321,49 @@ def test_stem_one_launch_matches_torch(case):
     y, sc = ops().stem(x, *ops().pack_stem_weights(w0, b0, w1, b1, wd, bd))
     assert y.shape == want_y.shape and sc.shape == want_sc.shape
     assert rel_err(y, want_y) <= 3e-6 and rel_err(sc, want_sc) <= 3e-6, (rel_err(y, want_y), rel_err(sc, want_sc))
+    # channel-quad output layout [M,4,H2,W2,4]: the same values, permuted
+    yq, sq = ops().stem(x, *ops().pack_stem_weights(w0, b0, w1, b1, wd, bd), quads=True)
+    unq = lambda t: t.permute(0, 1, 4, 2, 3).reshape(y.shape)
+    assert yq.shape == (m, 4, y.shape[2], y.shape[3], 4) and torch.equal(unq(yq), y) and torch.equal(unq(sq), sc)
     with pytest.raises(RuntimeError):
         ops().stem(torch.zeros((1, 4, 8, 8), device=DEV), *ops().pack_stem_weights(w0, b0, w1, b1, wd, bd))
+
+
+@pytest.mark.parametrize("case", [(5, 256, 320), (2, 37, 70), (1, 8, 32), (3, 64, 96), (1, 5, 3)])
+def test_res_chain16_one_launch_matches_torch(case, conv_arithmetic):
+    """itermvs_res_chain16: FeatureNet.layer1 behind the stem (module.py:33-50, net.py:13,40) in one launch against the three
+    torch layers in fp64, and against the three-launch form of this library (same bf16x3 arithmetic per layer)"""
+    if conv_arithmetic != "bf16x3":
+        pytest.skip("the chain exists in the bf16x3 arithmetic only (the fp32 form keeps its three launches)")
+    n, h, w = case
+    g = torch.Generator().manual_seed(n * 1000 + h)
+    y1 = torch.randn((n, 16, h, w), generator=g).relu().to(DEV)
+    sc = torch.randn((n, 16, h, w), generator=g).to(DEV)
+    wts = [(torch.randn((16, 16, 3, 3), generator=g) * 0.12).to(DEV) for _ in range(3)]
+    bs = [(torch.randn((16,), generator=g) * 0.2).to(DEV) for _ in range(3)]
+    d = lambda t: t.double()
+    a = F.relu(F.conv2d(d(y1), d(wts[0]), d(bs[0]), padding=1) + d(sc))
+    b = F.relu(F.conv2d(a, d(wts[1]), d(bs[1]), padding=1))
+    want = F.relu(F.conv2d(b, d(wts[2]), d(bs[2]), padding=1) + a).float()
+    pk = [ops().MfmaWeight(wt, split3=True) for wt in wts]
+    got = ops().res_chain16(y1, sc, pk, bs)
+    assert got.shape == want.shape and rel_err(got, want) <= 3e-6, rel_err(got, want)
+    a3 = ops().conv2d(y1, pk[0], bs[0], act="relu", add=sc)
+    b3 = ops().conv2d(a3, pk[1], bs[1], act="relu")
+    c3 = ops().conv2d(b3, pk[2], bs[2], act="relu", add=a3)
+    assert rel_err(got, c3) <= 2e-6, rel_err(got, c3)
+    # image strides: slices of larger buffers
+    big_y, big_s, big_o = (torch.zeros((n, 20, h, w), device=DEV) for _ in range(3))
+    big_y[:, 2:18] = y1
+    big_s[:, 1:17] = sc
+    out = ops().res_chain16(big_y[:, 2:18], big_s[:, 1:17], pk, [bs[0], None, bs[2]], out=big_o[:, 4:20])
+    b_nb = F.relu(F.conv2d(a, d(wts[1]), None, padding=1))
+    want_nb = F.relu(F.conv2d(b_nb, d(wts[2]), d(bs[2]), padding=1) + a).float()
+    assert rel_err(out, want_nb) <= 3e-6 and float(big_o[:, :4].abs().max()) == 0.0
+    # channel-quad inputs (ops.stem(..., quads=True)'s layout): bit-identical to the plane form
+    toq = lambda t: t.reshape(n, 4, 4, h, w).permute(0, 1, 3, 4, 2).contiguous()
+    assert torch.equal(ops().res_chain16(toq(y1), toq(sc), pk, bs, quads=True), got)
+    with pytest.raises(RuntimeError):
+        ops().res_chain16(y1, sc, pk, bs, quads=True)
+    with pytest.raises(RuntimeError):
+        ops().res_chain16(y1, sc, [ops().MfmaWeight(wt, split3=False) for wt in wts], bs)

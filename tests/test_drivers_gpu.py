@@ -129,7 +129,7 @@ def test_box_probe_reports_plausible_figures():
     assert 20.0 <= box["l2_latency_ns"] < box["hbm_latency_ns"] <= 2000.0
     x = torch.randn((64 * 1024 * 1024,), device=dev)
     mhz = benchmarks.workload_clock(dev, lambda: x.mul_(1.0001), n=40)
-    # (a pure streaming workload: seen up to 2 818 "MHz" against the 100 MHz reference counter over a 1 ms bracket on one box of the
-    # pool -- the bound only rejects figures that cannot be a clock ratio at all)
-    assert 1000.0 <= mhz <= 3200.0, mhz
+    # (seen up to 10 470 "MHz" against the 100 MHz reference counter on one box of the pool: a ratio that cannot be a clock is
+    # reported as None, never as a number)
+    assert mhz is None or 500.0 <= mhz <= 2600.0, mhz
     assert benchmarks.normalised(100.0, box) is None or all(v > 0 for v in benchmarks.normalised(100.0, box).values())
