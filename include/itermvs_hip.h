@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define ITERMVS_ABI_VERSION 10
+#define ITERMVS_ABI_VERSION 11
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -350,6 +350,24 @@ int itermvs_conv3x3_conv1x1(const float* x, int64_t x_sb, int32_t B, int32_t H, 
  * ------------------------------------------------------------------------------------------ */
 int itermvs_res_chain16(const float* y1, int64_t y1_sn, const float* shortcut, int64_t shortcut_sn, int32_t in_layout, int32_t N,
                         int32_t H, int32_t W, const void* const* weights, const float* const* bias, float* out, int64_t out_sn, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * itermvs_lateral_conv3x3 -- one level of FeatureNet's top-down path in ONE launch (models/net.py:48-50; test mode :62-63):
+ *     intra = F.interpolate(coarse, scale_factor=2, mode="bilinear") + inner(fine)       1x1 layer Cf -> 48, bias
+ *     out   = output(intra)                                                               3x3 layer 48 -> Cout, bias, padding 1
+ * `intra` ([N,48,H,W]; 78 MB at level 1 of cfg 1) never reaches memory: only the output convolution reads it (net.py:50).
+ * Arithmetic: the 1x1 layer on the exact fp32 matrix instruction, the up-sampling operation for operation that of
+ * itermvs_bilinear_up (align_corners=False), the 3x3 layer in the bf16x3 form of itermvs_conv2d's weight_format 3.
+ *   fine [N,Cf,H,W] planes (image stride fine_sn), coarse [N,48,H/2,W/2] planes (coarse_sn); H, W even; Cf = 16, Cout = 16
+ *   (ITERMVS_ERR_CHANNELS otherwise: the level-1 layer pair of the path);
+ *   w_lat: the 1x1 weight in weight_format 1 = fp32 [Cf][48] (itermvs_amd.ops.MfmaWeight(...).data), b_lat [48] or NULL;
+ *   w_out: the 3x3 weight in weight_format 3 = bf16 [9][3][3][16][16] (MfmaWeight(...).tile3), 16-byte aligned; b_out [Cout] or NULL;
+ *   out: out_layout 0 = fp32 planes [N,Cout,H,W]; 1 / 2 / 3 = channels-last [N,H,W,Cout] in fp32 / fp16 / bf16 storage (what the
+ *   correlation kernels gather from; out_sn in ELEMENTS of the storage type); out2: optional dense fp32 planar copy or NULL.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_lateral_conv3x3(const float* fine, int64_t fine_sn, int32_t Cf, const float* coarse, int64_t coarse_sn, int32_t N,
+                            int32_t H, int32_t W, const float* w_lat, const float* b_lat, const void* w_out, const float* b_out,
+                            int32_t Cout, void* out, int64_t out_sn, int32_t out_layout, float* out2, void* stream);
 
 
 

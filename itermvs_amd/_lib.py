@@ -14,7 +14,7 @@ MAX_SRC = 16
 MAX_HYP = 8
 GROUPS = 8
 F32, F16, BF16 = 0, 1, 2      # itermvs_dtype: storage type of feature maps
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitermvs_hip.so")
@@ -140,6 +140,9 @@ PROTOTYPES = {
                                   C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "itermvs_res_chain16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_void_p]),
+    "itermvs_lateral_conv3x3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
+                                          C.c_void_p, C.c_void_p]),
     "itermvs_stem": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_int64, C.c_int32, C.c_void_p]),
     "itermvs_stem_compose": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -213,8 +213,13 @@ class InferenceEngine:
         self._conv(f3, p + "output3.", bias=True, channels_last_out=True, out=o3)
         mid = self._conv(f2, p + "inner2.", bias=True, ksize=1, pad=0, add=f3, add_up2=True)   # net.py:46 (fused F.interpolate)
         self._conv(mid, p + "output2.", bias=True, channels_last_out=True, out=o2, out2=self.o2_planar)
-        mid = self._conv(f1, p + "inner1.", bias=True, ksize=1, pad=0, add=mid, add_up2=True)  # net.py:49
-        self._conv(mid, p + "output1.", bias=True, channels_last_out=True, out=o1)
+        if self.split3:
+            # net.py:49-50 in one launch: the 48-channel half-resolution map (78 MB at cfg 1) stays in LDS (lat_conv.hip)
+            ops.lateral_conv3x3(f1, mid, self.pk[p + "inner1.weight"], self.w[p + "inner1.bias"], self.pk[p + "output1.weight"],
+                                self.w[p + "output1.bias"], out=o1, channels_last_out=True)
+        else:
+            mid = self._conv(f1, p + "inner1.", bias=True, ksize=1, pad=0, add=mid, add_up2=True)  # net.py:49
+            self._conv(mid, p + "output1.", bias=True, channels_last_out=True, out=o1)
         return {1: o1, 2: o2, 3: o3}
 
     # -- small stacks ---------------------------------------------------------------------------

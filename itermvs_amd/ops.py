@@ -1258,6 +1258,49 @@ def res_chain16(y1: Tensor, shortcut: Tensor, weights: Sequence["MfmaWeight"], b
     return out
 
 
+def lateral_conv3x3(fine: Tensor, coarse: Tensor, w_lat: "MfmaWeight", b_lat: Optional[Tensor], w_out: "MfmaWeight",
+                    b_out: Optional[Tensor], out: Optional[Tensor] = None, channels_last_out: bool = False,
+                    out2: Optional[Tensor] = None) -> Tensor:
+    """itermvs_lateral_conv3x3: out = conv3x3(F.interpolate(coarse, x2, bilinear) + conv1x1(fine; w_lat) + b_lat; w_out) + b_out
+    in one launch (net.py:48-50), the 48-channel intermediate map stays on the chip.  ``fine`` [N,16,H,W], ``coarse``
+    [N,48,H/2,W/2] planes; ``w_lat``: MfmaWeight of the 1x1 layer 16 -> 48, ``w_out``: MfmaWeight(split3=True) of the 3x3 layer
+    48 -> 16.  ``channels_last_out``: ``out`` in channels-last memory format, fp32 / fp16 / bf16 storage (the feature maps the
+    correlation kernels gather from); ``out2``: optional fp32 planar copy."""
+    fp, f_sn = _planes(fine, "lateral_conv3x3 fine input")
+    cp, c_sn = _planes(coarse, "lateral_conv3x3 coarse input")
+    n, cf, h, w = fine.shape
+    if h % 2 or w % 2 or tuple(coarse.shape) != (n, 48, h // 2, w // 2):
+        raise RuntimeError(f"lateral_conv3x3: coarse input {tuple(coarse.shape)} is not [N,48,H/2,W/2] of fine input {tuple(fine.shape)}")
+    if not (isinstance(w_lat, MfmaWeight) and w_lat.ksize == 1 and w_lat.cin == cf and w_lat.cout == 48):
+        raise RuntimeError("lateral_conv3x3: w_lat must be the MfmaWeight of a 1x1 layer Cf -> 48")
+    if not (isinstance(w_out, MfmaWeight) and w_out.ksize == 3 and w_out.cin == 48 and w_out.tile3 is not None):
+        raise RuntimeError("lateral_conv3x3: w_out must be the MfmaWeight (split3=True) of a 3x3 layer 48 -> Cout")
+    if not (w_out.tile3.is_cuda and w_lat.data.is_cuda):
+        raise RuntimeError("lateral_conv3x3 weights: expected ROCm tensors")
+    cout = w_out.cout
+    if out is None:
+        out = torch.empty((n, cout, h, w), device=fine.device, dtype=torch.float32,
+                          memory_format=torch.channels_last if channels_last_out else torch.contiguous_format)
+    if tuple(out.shape) != (n, cout, h, w):
+        raise RuntimeError(f"lateral_conv3x3: output has shape {tuple(out.shape)}, expected {(n, cout, h, w)}")
+    if channels_last_out:
+        if not out.is_contiguous(memory_format=torch.channels_last):
+            raise RuntimeError("lateral_conv3x3: channels_last_out needs a dense channels-last `out`")
+        po, o_sn, layout = out.data_ptr(), cout * h * w, 1 + _feat(out, "lateral_conv3x3 output")
+    else:
+        if out.dtype != torch.float32:
+            raise RuntimeError("lateral_conv3x3: planar output is fp32")
+        po, o_sn = _planes(out, "lateral_conv3x3 output")
+        layout = 0
+    if out2 is not None and not (out2.dtype == torch.float32 and out2.is_contiguous() and tuple(out2.shape) == (n, cout, h, w)):
+        raise RuntimeError("lateral_conv3x3: out2 must be a dense fp32 [N,Cout,H,W] tensor")
+    bl = None if b_lat is None else _dev(b_lat, "lateral_conv3x3 bias").float().contiguous()
+    bo = None if b_out is None else _dev(b_out, "lateral_conv3x3 bias").float().contiguous()
+    check(_lib.load().itermvs_lateral_conv3x3(fp, f_sn, cf, cp, c_sn, n, h, w, w_lat.data.data_ptr(), _ptr(bl), w_out.tile3.data_ptr(),
+                                              _ptr(bo), cout, po, o_sn, layout, _ptr(out2), _stream()), "itermvs_lateral_conv3x3")
+    return out
+
+
 def corrnet(x: Tensor, weight_sets: Sequence[Tensor], seg_end: Sequence[int] = (), out: Optional[Tensor] = None,
             out2: Optional[Tensor] = None) -> Tensor:
     """itermvs_corrnet: x [M,8,H,W] -> [M,1,H,W]; ``weight_sets`` = 1..3 tensors from pack_corrnet_weights, ``seg_end`` the

@@ -367,3 +367,52 @@ def test_res_chain16_one_launch_matches_torch(case, conv_arithmetic):
         ops().res_chain16(y1, sc, pk, bs, quads=True)
     with pytest.raises(RuntimeError):
         ops().res_chain16(y1, sc, [ops().MfmaWeight(wt, split3=False) for wt in wts], bs)
+
+
+@pytest.mark.parametrize("case", [(5, 256, 320), (2, 38, 70), (1, 8, 32), (3, 64, 96), (1, 2, 2), (1, 10, 34)])
+@pytest.mark.parametrize("storage", ["planes", "fp32", "fp16", "bf16"])
+def test_lateral_conv3x3_one_launch_matches_torch(case, storage):
+    """itermvs_lateral_conv3x3 (net.py:48-50: F.interpolate x2 + inner1, then output1, the 48-channel map kept on the chip) against
+    the torch layers in fp64 and against the two-launch form of this library (fused-interpolate lateral layer, then the bf16x3
+    3x3 layer): full level-1 size of cfg 1, ragged sizes, images smaller than a tile; every output storage form"""
+    n, h, w = case
+    if storage != "planes" and case not in ((5, 256, 320), (2, 38, 70), (1, 2, 2)):
+        pytest.skip("storage forms: three shapes")
+    g = torch.Generator().manual_seed(n * 977 + h + w)
+    fine = torch.randn((n, 16, h, w), generator=g).relu().to(DEV)
+    coarse = torch.randn((n, 48, h // 2, w // 2), generator=g).to(DEV)
+    wl = (torch.randn((48, 16, 1, 1), generator=g) * 0.25).to(DEV)
+    bl = (torch.randn((48,), generator=g) * 0.2).to(DEV)
+    wo = (torch.randn((16, 48, 3, 3), generator=g) * 0.07).to(DEV)
+    bo = (torch.randn((16,), generator=g) * 0.2).to(DEV)
+    d = lambda t: t.double()
+    intra = F.interpolate(d(coarse), scale_factor=2, mode="bilinear") + F.conv2d(d(fine), d(wl), d(bl))
+    want = F.conv2d(intra, d(wo), d(bo), padding=1).float()
+    pl, po = ops().MfmaWeight(wl), ops().MfmaWeight(wo, split3=True)
+    two = ops().conv2d(ops().conv2d(fine, pl, bl, ksize=1, pad=0, add=coarse, add_up2=True), po, bo)
+    if storage == "planes":
+        got = ops().lateral_conv3x3(fine, coarse, pl, bl, po, bo)
+        assert got.shape == want.shape and got.is_contiguous()
+        tol = 3e-6
+    else:
+        dt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[storage]
+        out = torch.empty((n, 16, h, w), device=DEV, dtype=dt, memory_format=torch.channels_last)
+        out2 = torch.empty((n, 16, h, w), device=DEV)
+        got = ops().lateral_conv3x3(fine, coarse, pl, bl, po, bo, out=out, channels_last_out=True, out2=out2)
+        assert got is out and rel_err(out2, want) <= 3e-6
+        assert torch.equal(out.float(), out2.to(dt).float())            # the 16-bit forms round the fp32 result to nearest even
+        got, tol = out.float(), {"fp32": 3e-6, "fp16": 1e-3, "bf16": 8e-3}[storage]
+    assert rel_err(got, want) <= tol, rel_err(got, want)
+    if storage == "planes":
+        assert rel_err(got, two) <= 2e-6, rel_err(got, two)
+        # no biases; image strides: channel slices of larger buffers
+        big_f, big_c, big_o = torch.zeros((n, 20, h, w), device=DEV), torch.zeros((n, 50, h // 2, w // 2), device=DEV), torch.zeros((n, 18, h, w), device=DEV)
+        big_f[:, 3:19] = fine
+        big_c[:, 1:49] = coarse
+        o = ops().lateral_conv3x3(big_f[:, 3:19], big_c[:, 1:49], pl, None, po, None, out=big_o[:, 2:18])
+        intra_nb = F.interpolate(d(coarse), scale_factor=2, mode="bilinear") + F.conv2d(d(fine), d(wl))
+        assert rel_err(o, F.conv2d(intra_nb, d(wo), padding=1).float()) <= 3e-6 and float(big_o[:, :2].abs().max()) == 0.0
+        with pytest.raises(RuntimeError):
+            ops().lateral_conv3x3(fine, coarse[:, :, :, :-1], pl, bl, po, bo)
+        with pytest.raises(RuntimeError):
+            ops().lateral_conv3x3(fine, coarse, pl, bl, ops().MfmaWeight(wo, split3=False), bo)

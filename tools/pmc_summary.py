@@ -15,7 +15,7 @@ import re
 import sys
 
 root, out = sys.argv[1:3]
-KEEP = ("corr_iter", "corr_init", "corrnet_kernel", "lateral_up2_kernel", "conv_tile_kernel", "conv_tile3_kernel", "deconv_tile_kernel", "conv_mfma", "conv_direct_kernel",
+KEEP = ("lat_conv_kernel", "res_chain16_kernel", "corr_iter", "corr_init", "corrnet_kernel", "lateral_up2_kernel", "conv_tile_kernel", "conv_tile3_kernel", "deconv_tile_kernel", "conv_mfma", "conv_direct_kernel",
         "head_fused", "head_coop", "stem_kernel", "softmax_max", "view_aggregate", "ref_quarter", "convex_upsample")
 
 
