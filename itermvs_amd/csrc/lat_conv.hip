@@ -50,7 +50,7 @@ struct LatConvArgs {
     float* out;
     float* out2;
     int64_t fine_sn, coarse_sn, out_sn;
-    int N, H, W, Cout, CoutPad, out_nhwc, tiles_x, tiles_y, total;
+    int N, H, W, Cout, CoutPad, out_nhwc, tiles_x, tiles_y, total, banded;
 };
 
 template <int KS, int MBO>
@@ -153,8 +153,21 @@ __global__ void __launch_bounds__(kLcThreads) lat_conv_kernel(const LatConvArgs 
     const char* __restrict__ wa = Wt + l16 * 32 + half * 16;             // A1 = [wh | wh]; A2 = + 512
     const char* __restrict__ wa3 = wa + (second ? 0 : 1024);             // A3 = [wl | wh]
 
-    int w = blockIdx.x;
-    if (w >= a.total) return;
+    // Tile order: workgroup b runs on XCD b % 8 (round-robin dispatch); the tiles of one XCD are a contiguous run of the tile list
+    // (whole image bands), so that tiles sharing halo rows / patch cache lines meet in the same 4 MB L2 instead of being fetched
+    // from the fabric by up to eight of them
+    int w, wstep, wend;
+    if (a.banded) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        w = (int)((int64_t)a.total * xcd / 8) + slot;
+        wend = (int)((int64_t)a.total * (xcd + 1) / 8);
+        wstep = gridDim.x >> 3;
+    } else {
+        w = blockIdx.x;
+        wend = a.total;
+        wstep = gridDim.x;
+    }
+    if (w >= wend) return;
     Work cur = decode(w);
     fetch(cur, 0);
     // split weights of the 3x3 layer -> LDS, once per workgroup (all loads in flight, then the stores; behind the first tile's fetch)
@@ -235,9 +248,9 @@ __global__ void __launch_bounds__(kLcThreads) lat_conv_kernel(const LatConvArgs 
         for (int g = 0; g < kLcGPW; ++g)
 #pragma unroll
             for (int s = 0; s < KS; ++s) fr[g][s] = Ft[((4 * s + q) * kLcMH + my[g]) * kLcFW + mx[g]];
-        const int wn = w + gridDim.x;
+        const int wn = w + wstep;
         Work nxt = cur;
-        if (wn < a.total) {
+        if (wn < wend) {
             nxt = decode(wn);
             fetch(nxt, set ^ 1);
         }
@@ -363,7 +376,7 @@ __global__ void __launch_bounds__(kLcThreads) lat_conv_kernel(const LatConvArgs 
         e.Cout = a.Cout; e.P = P; e.act = 0;
         e.add_mode = 0; e.Hout = a.H; e.Wout = a.W; e.out_nhwc = a.out_nhwc;
         conv_epilogue<MBO, NB>(e, acc, 0, q, pix_off, py, px);
-        if (wn >= a.total) return false;
+        if (wn >= wend) return false;
         w = wn;
         cur = nxt;
         return true;
@@ -381,6 +394,7 @@ static int launch_lat_conv(LatConvArgs& a, hipStream_t stream) {
     if (!attr_ok) return ITERMVS_ERR_LAUNCH;
     const int cus = itermvs_num_cus();
     const int grid = a.total < cus ? a.total : cus;
+    a.banded = grid % 8 == 0 && a.total >= 8 * grid ? 1 : 0;      // (few tiles: plain order keeps every workgroup busy)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kLcThreads), lds, stream, a);
     return itermvs_launch_status();
 }
