@@ -105,39 +105,70 @@ __global__ void __launch_bounds__(kLcThreads) lat_conv_kernel(const LatConvArgs 
         my[g] = pc / kLcMW;
         mx[g] = pc - my[g] * kLcMW;
     }
-    // Staging: every global access is a 16-byte load of four consecutive pixels of one plane (a wave-level load occupies the CU's
-    // address path for ~64 cycles whatever its width: with one dword per lane the 192 loads of a tile were the longest pole of
-    // this kernel, profiles/r06/r06k_*).  fine: (channel, tile row, piece of 4 columns) -> LDS [channel][row][36]; coarse:
-    // (channel, patch row, piece) -> LDS [position][channel].  The pieces start at column ox0 - 1 (cx0 = ox0/2 - 1 for the
-    // patch): dword-aligned only; in the first tile column the first piece is fetched one pixel to the right and shifted.
-    // Two register sets: the next tile's loads are issued at the START of a tile and have all of it to land.
+    // Staging: every global access is a 16-byte load of four consecutive pixels of one plane.  fine: (channel, tile row, piece of
+    // 4 columns) -> LDS [channel][row][36]; coarse: (channel, patch row, piece) -> LDS [position][channel].  The pieces start at
+    // column ox0 - 1 (cx0 = ox0/2 - 1 for the patch): dword-aligned only; in the first tile column the first piece is fetched one
+    // pixel to the right and shifted.
     constexpr int kFItems = 4 * KS * kLcMH * kLcFQ;
     constexpr int FIT = (kFItems + kLcThreads - 1) / kLcThreads;
-    u32x4 fv[2][FIT], pv[2][kLcPIT];
-    auto fetch = [&](const Work& k, int set) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t fr_ =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(a.fine + (int64_t)k.n * a.fine_sn), 0, (int)((uint32_t)(4 * KS) * plane * 4u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t cr_ =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(a.coarse + (int64_t)k.n * a.coarse_sn), 0, (int)(48u * cplane * 4u), 0x00020000);
-#pragma unroll
-        for (int j = 0; j < FIT; ++j) {
+    u32x4 fv[FIT], pv[kLcPIT];
+    // piece i of tile k's loads: i < FIT the fine items, then the coarse items.  The loads of the NEXT tile are issued one or
+    // two per phase: issued together (48 wave-level loads of 1 KB per workgroup) they filled the CU's address path and the
+    // issuing waves stood at the instruction for 3-7 k cycles while the others waited at the next barrier
+    // (profiles/r06/r06k_lat_conv_phase_stamps.txt)
+    auto fetch_part = [&](const Work& k, int i) __attribute__((always_inline)) {
+        if (i < FIT) {
+            const int j = i;
+            const __amdgpu_buffer_rsrc_t fr_ =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(a.fine + (int64_t)k.n * a.fine_sn), 0, (int)((uint32_t)(4 * KS) * plane * 4u), 0x00020000);
             const int item = tid + j * kLcThreads;
             const int ch = item / (kLcMH * kLcFQ), rem = item - ch * (kLcMH * kLcFQ);
             const int row = rem / kLcFQ, jq = rem - row * kLcFQ;
             const int gy = k.oy0 - 1 + row, gx0 = k.ox0 - 1 + 4 * jq;
             const bool ok = item < kFItems && gy >= 0 && gy < a.H && gx0 < a.W;
             const uint32_t go = ok ? ((uint32_t)ch * plane + (uint32_t)(gy * a.W + max(gx0, 0))) * 4u : kLcOob;
-            fv[set][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(fr_, go, 0, 0));
-        }
-        const int cy0 = (k.oy0 >> 1) - 1, cx0 = (k.ox0 >> 1) - 1;
-#pragma unroll
-        for (int j = 0; j < kLcPIT; ++j) {
+            fv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(fr_, go, 0, 0));
+        } else {
+            const int j = i - FIT;
+            const __amdgpu_buffer_rsrc_t cr_ =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(a.coarse + (int64_t)k.n * a.coarse_sn), 0, (int)(48u * cplane * 4u), 0x00020000);
+            const int cy0 = (k.oy0 >> 1) - 1, cx0 = (k.ox0 >> 1) - 1;
             const int item = tid + j * kLcThreads;                       // channel fastest: the LDS stores of a wave hit every bank once
             const int rem = item / 48, ch = item - rem * 48;
             const int pr = rem / kLcPQ, jq = rem - pr * kLcPQ;
             const int cy = min(max(cy0 + pr, 0), Hc - 1);                // rows: border-replicated here; columns: clamped when read
             const uint32_t go = item < kLcPItems ? ((uint32_t)ch * cplane + (uint32_t)(cy * Wc + max(cx0 + 4 * jq, 0))) * 4u : kLcOob;
-            pv[set][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(cr_, go, 0, 0));
+            pv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(cr_, go, 0, 0));
+        }
+    };
+    constexpr int kParts = FIT + kLcPIT;
+    static_assert(kParts == 6, "two loads per step");
+    // the fetched registers of tile k -> LDS
+    auto stage = [&](const Work& k) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < FIT; ++j) {
+            const int item = tid + j * kLcThreads;
+            if (j < FIT - 1 || item < kFItems) {
+                const int ch = item / (kLcMH * kLcFQ), rem = item - ch * (kLcMH * kLcFQ);
+                const int row = rem / kLcFQ, jq = rem - row * kLcFQ;
+                u32x4 v = fv[j];
+                if (k.ox0 == 0 && jq == 0) v = u32x4{0u, v[0], v[1], v[2]};             // fetched from column 0 instead of -1
+                *reinterpret_cast<u32x4*>(Ft + (ch * kLcMH + row) * kLcFW + 4 * jq) = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kLcPIT; ++j) {
+            const int item = tid + j * kLcThreads;
+            if (j < kLcPIT - 1 || item < kLcPItems) {
+                const int rem = item / 48, ch = item - rem * 48;
+                const int pr = rem / kLcPQ, jq = rem - pr * kLcPQ;
+                // element e is patch column 4 jq + e; in the first tile column piece 0 was fetched from image column 0 = patch column 1
+                const int pc0 = 4 * jq + (k.ox0 == 0 && jq == 0 ? 1 : 0);
+                float* __restrict__ d = Pt + (pr * kLcPW + pc0) * kLcPS + ch;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (pc0 + e < kLcPW) d[e * kLcPS] = __uint_as_float(pv[j][e]);
+            }
         }
     };
 
@@ -153,9 +184,150 @@ __global__ void __launch_bounds__(kLcThreads) lat_conv_kernel(const LatConvArgs 
     const char* __restrict__ wa = Wt + l16 * 32 + half * 16;             // A1 = [wh | wh]; A2 = + 512
     const char* __restrict__ wa3 = wa + (second ? 0 : 1024);             // A3 = [wl | wh]
 
+    // ---- per-tile state of the A phase: up-sampling weights (F.interpolate, align_corners=False, like bilinear_up_kernel), tap
+    // positions in the patch (columns clamped to the image), the 1x1 layer's B operand (channel 4 s + q of the lane's positions) ----
+    float lx0[kLcGPW], lx1[kLcGPW], ly0[kLcGPW], ly1[kLcGPW];
+    bool inside[kLcGPW];
+    int offa[kLcGPW], offb[kLcGPW];
+    float fr[kLcGPW][KS];
+    auto setup_a = [&](const Work& k) __attribute__((always_inline)) {
+        const int jlo = k.ox0 == 0 ? 1 : 0, jhi = min(kLcPW - 1, Wc - 1 - ((k.ox0 >> 1) - 1));
+#pragma unroll
+        for (int g = 0; g < kLcGPW; ++g) {
+            const int ja = min(max(mx[g] >> 1, jlo), jhi), jb = min(max((mx[g] >> 1) + 1, jlo), jhi);
+            offa[g] = ((my[g] >> 1) * kLcPW + ja) * kLcPS + q * 4;
+            offb[g] = ((my[g] >> 1) * kLcPW + jb) * kLcPS + q * 4;
+            const int gy = k.oy0 - 1 + my[g], gx = k.ox0 - 1 + mx[g];
+            inside[g] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            float sy = ((float)gy + 0.5f) * 0.5f - 0.5f, sx = ((float)gx + 0.5f) * 0.5f - 0.5f;
+            sy = sy < 0.0f ? 0.0f : sy;
+            sx = sx < 0.0f ? 0.0f : sx;
+            int y0 = (int)sy, x0 = (int)sx;
+            y0 = y0 > Hc - 1 ? Hc - 1 : y0;
+            x0 = x0 > Wc - 1 ? Wc - 1 : x0;
+            ly1[g] = sy - (float)y0;
+            lx1[g] = sx - (float)x0;
+            ly0[g] = 1.0f - ly1[g];
+            lx0[g] = 1.0f - lx1[g];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) fr[g][s] = Ft[((4 * s + q) * kLcMH + my[g]) * kLcFW + mx[g]];
+        }
+    };
+    // A: chunk c of the intra tile -> chunk buffer `buf`.  The NG groups of this wave are interleaved: their matrix-instruction
+    // chains and 4 NG patch reads are independent and issued before the first result is needed.  No lane guard on the stores:
+    // group 21's positions 340..351 land in the padding of the planes (kLcPLB holds 352 positions).
+    auto phase_a_n = [&](int c, int buf, auto ng_tag) __attribute__((always_inline)) {
+        constexpr int NG = decltype(ng_tag)::value;
+        char* __restrict__ tb = T0 + buf * kLcChunkB;
+        f32x4 m[NG], t00[NG], t01[NG], t10[NG], t11[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            // taps: patch rows (my >> 1, + 1) -- replicated at the image border when fetched --, columns clamped in setup_a
+            t00[g] = *reinterpret_cast<const f32x4*>(Pt + offa[g] + c * 16);
+            t01[g] = *reinterpret_cast<const f32x4*>(Pt + offb[g] + c * 16);
+            t10[g] = *reinterpret_cast<const f32x4*>(Pt + offa[g] + kLcPW * kLcPS + c * 16);
+            t11[g] = *reinterpret_cast<const f32x4*>(Pt + offb[g] + kLcPW * kLcPS + c * 16);
+            m[g] = bl[c];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) m[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[c][s], fr[g][s], m[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float top = t00[g][r] * lx0[g] + t01[g][r] * lx1[g];
+                const float bot = t10[g][r] * lx0[g] + t11[g][r] * lx1[g];
+                const float x = m[g][r] + (top * ly0[g] + bot * ly1[g]);
+                v[r] = inside[g] ? x : 0.0f;
+            }
+            uint32_t h0, m0, l0, h1, m1, l1;
+            split_pair(v[0], v[1], h0, m0, l0);
+            split_pair(v[2], v[3], h1, m1, l1);
+            char* __restrict__ d = tb + (q >> 1) * kLcPLB + mpos[g] * 16 + (q & 1) * 8;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + 2 * kLcPLB) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2*>(d + 4 * kLcPLB) = u32x2{l0, l1};
+        }
+    };
+    auto phase_a = [&](int c, int buf) __attribute__((always_inline)) {
+        if (wave < kLcMG - (kLcGPW - 1) * kLcWaves) phase_a_n(c, buf, std::integral_constant<int, kLcGPW>{});      // wave-uniform
+        else phase_a_n(c, buf, std::integral_constant<int, kLcGPW - 1>{});
+    };
+    // B: the 9 taps of chunk c from chunk buffer `buf`
+    f32x4 acc[MBO][NB];
+    auto phase_b = [&](int c, int buf) __attribute__((always_inline)) {
+        const char* __restrict__ tb = T0 + buf * kLcChunkB;
+        const char* __restrict__ x1 = tb + x1o;
+        const char* __restrict__ x3 = tb + x3o;
+        bf8 a1[2][MBO], a2[2][MBO], a3[2][MBO], b1[2][NB], b3[2][NB];
+        auto read = [&](int tap, int set) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int to = (ky * kLcMW + kx) * 16;
+#pragma unroll
+            for (int mb = 0; mb < MBO; ++mb) {
+                const int o = ((mb * 3 + c) * 9 + tap) * 1536;
+                a1[set][mb] = *reinterpret_cast<const bf8*>(wa + o);
+                a2[set][mb] = *reinterpret_cast<const bf8*>(wa + o + 512);
+                a3[set][mb] = *reinterpret_cast<const bf8*>(wa3 + o);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                b1[set][nb] = *reinterpret_cast<const bf8*>(x1 + boff[nb] + to);
+                b3[set][nb] = *reinterpret_cast<const bf8*>(x3 + boff[nb] + to);
+            }
+        };
+        read(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int s = tap & 1;
+            if (tap + 1 < 9) read(tap + 1, s ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mb = 0; mb < MBO; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[s][mb], b3[s][nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < MBO; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[s][mb], b1[s][nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < MBO; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s][mb], b1[s][nb], acc[mb][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // results of tile k (D: column = pixel l16, row = output channel 4 q + r: the shared epilogue's layout)
+    auto store = [&](const Work& k) __attribute__((always_inline)) {
+        uint32_t pix_off[NB];
+        int py[NB], px[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int pos = (wave + nb * kLcWaves) * 16 + l16;
+            const int oy = k.oy0 + pos / kLcTW, ox = k.ox0 + pos % kLcTW;
+            pix_off[nb] = oy < a.H && ox < a.W ? (uint32_t)(oy * a.W + ox) * 4u : kEpiOob;
+            py[nb] = oy;
+            px[nb] = ox;
+        }
+        EpilogueArgs e;
+        e.out = epi_out_base(a.out, (int64_t)k.n * a.out_sn, a.out_nhwc);
+        e.out2 = a.out2 ? a.out2 + (int64_t)k.n * a.Cout * P : nullptr;
+        e.add = nullptr; e.aux1 = nullptr; e.aux2 = nullptr;
+        e.Cout = a.Cout; e.P = P; e.act = 0;
+        e.add_mode = 0; e.Hout = a.H; e.Wout = a.W; e.out_nhwc = a.out_nhwc;
+        conv_epilogue<MBO, NB>(e, acc, 0, q, pix_off, py, px);
+    };
+    // One step = B of a finished chunk and A of the next one.  The two waves that share a SIMD (w and w + 4) take the halves in
+    // opposite order, so that the bf16 matrix work of one runs under the vector work of the other (they overlap across waves,
+    // tools/ubench/mfma_bf16_rate.hip); in lock step both would be in the same half at the same time.
+    const bool b_first = wave < kLcWaves / 2;
+
     // Tile order: workgroup b runs on XCD b % 8 (round-robin dispatch); the tiles of one XCD are a contiguous run of the tile list
-    // (whole image bands), so that tiles sharing halo rows / patch cache lines meet in the same 4 MB L2 instead of being fetched
-    // from the fabric by up to eight of them
+    // (whole image bands), so that tiles sharing halo rows / patch cache lines meet in the same 4 MB L2
     int w, wstep, wend;
     if (a.banded) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -169,7 +341,8 @@ __global__ void __launch_bounds__(kLcThreads) lat_conv_kernel(const LatConvArgs 
     }
     if (w >= wend) return;
     Work cur = decode(w);
-    fetch(cur, 0);
+#pragma unroll
+    for (int i = 0; i < kParts; ++i) fetch_part(cur, i);
     // split weights of the 3x3 layer -> LDS, once per workgroup (all loads in flight, then the stores; behind the first tile's fetch)
     {
         const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(a.w_out);
@@ -191,197 +364,68 @@ __global__ void __launch_bounds__(kLcThreads) lat_conv_kernel(const LatConvArgs 
             if (pc < total) reinterpret_cast<u32x4*>(Wt)[pc] = t[i];
         }
     }
-    auto tile = [&](int set) __attribute__((always_inline)) -> bool {
-        // ---- fine tile and coarse patch -> LDS ----
-#pragma unroll
-        for (int j = 0; j < FIT; ++j) {
-            const int item = tid + j * kLcThreads;
-            if (j < FIT - 1 || item < kFItems) {
-                const int ch = item / (kLcMH * kLcFQ), rem = item - ch * (kLcMH * kLcFQ);
-                const int row = rem / kLcFQ, jq = rem - row * kLcFQ;
-                u32x4 v = fv[set][j];
-                if (cur.ox0 == 0 && jq == 0) v = u32x4{0u, v[0], v[1], v[2]};           // fetched from column 0 instead of -1
-                *reinterpret_cast<u32x4*>(Ft + (ch * kLcMH + row) * kLcFW + 4 * jq) = v;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kLcPIT; ++j) {
-            const int item = tid + j * kLcThreads;
-            if (j < kLcPIT - 1 || item < kLcPItems) {
-                const int rem = item / 48, ch = item - rem * 48;
-                const int pr = rem / kLcPQ, jq = rem - pr * kLcPQ;
-                // element e is patch column 4 jq + e; in the first tile column piece 0 was fetched from image column 0 = patch column 1
-                const int pc0 = 4 * jq + (cur.ox0 == 0 && jq == 0 ? 1 : 0);
-                float* __restrict__ d = Pt + (pr * kLcPW + pc0) * kLcPS + ch;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (pc0 + e < kLcPW) d[e * kLcPS] = __uint_as_float(pv[set][j][e]);
-            }
-        }
-        // per-group up-sampling weights and patch position (F.interpolate, align_corners=False, like bilinear_up_kernel)
-        float lx0[kLcGPW], lx1[kLcGPW], ly0[kLcGPW], ly1[kLcGPW];
-        bool inside[kLcGPW];
-        int offa[kLcGPW], offb[kLcGPW];     // patch offsets of the left / right tap column (top row), columns clamped to the image
-        const int jlo = cur.ox0 == 0 ? 1 : 0, jhi = min(kLcPW - 1, Wc - 1 - ((cur.ox0 >> 1) - 1));
-#pragma unroll
-        for (int g = 0; g < kLcGPW; ++g) {
-            const int ja = min(max(mx[g] >> 1, jlo), jhi), jb = min(max((mx[g] >> 1) + 1, jlo), jhi);
-            offa[g] = ((my[g] >> 1) * kLcPW + ja) * kLcPS + q * 4;
-            offb[g] = ((my[g] >> 1) * kLcPW + jb) * kLcPS + q * 4;
-            const int gy = cur.oy0 - 1 + my[g], gx = cur.ox0 - 1 + mx[g];
-            inside[g] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            float sy = ((float)gy + 0.5f) * 0.5f - 0.5f, sx = ((float)gx + 0.5f) * 0.5f - 0.5f;
-            sy = sy < 0.0f ? 0.0f : sy;
-            sx = sx < 0.0f ? 0.0f : sx;
-            int y0 = (int)sy, x0 = (int)sx;
-            y0 = y0 > Hc - 1 ? Hc - 1 : y0;
-            x0 = x0 > Wc - 1 ? Wc - 1 : x0;
-            ly1[g] = sy - (float)y0;
-            lx1[g] = sx - (float)x0;
-            ly0[g] = 1.0f - ly1[g];
-            lx0[g] = 1.0f - lx1[g];
-        }
-        __syncthreads();            // fine tile and patch complete; the previous tile's B(2) is done with buffer 0
-        // the 1x1 layer's B operand: channel 4 s + q of the lane's positions, once per tile
-        float fr[kLcGPW][KS];
-#pragma unroll
-        for (int g = 0; g < kLcGPW; ++g)
-#pragma unroll
-            for (int s = 0; s < KS; ++s) fr[g][s] = Ft[((4 * s + q) * kLcMH + my[g]) * kLcFW + mx[g]];
-        const int wn = w + wstep;
-        Work nxt = cur;
-        if (wn < wend) {
-            nxt = decode(wn);
-            fetch(nxt, set ^ 1);
-        }
-
-        f32x4 acc[MBO][NB];
+    stage(cur);
+    __syncthreads();
+    setup_a(cur);
+    int wn = w + wstep;
+    bool more = wn < wend;          // a tile follows `cur`: its loads are issued during cur's steps
+    Work nxt = cur;
+    if (more) {
+        nxt = decode(wn);
+        fetch_part(nxt, 0);
+        fetch_part(nxt, 1);
+    }
+    int buf = 0;                    // chunk buffer the NEXT A phase writes (alternates per chunk, across tiles)
+    phase_a(0, buf);
+    __syncthreads();
+    while (true) {
 #pragma unroll
         for (int mb = 0; mb < MBO; ++mb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = bo[mb];
-
-        // NG groups of this wave, interleaved: the NG matrix-instruction chains and the 4 NG patch reads are independent and
-        // issued before the first result is needed.  No lane guard on the stores: group 21's positions 340..351 land in the
-        // padding of the planes (kLcPLB holds 352 positions).
-        auto phase_a_n = [&](int c, auto ng_tag) __attribute__((always_inline)) {
-            constexpr int NG = decltype(ng_tag)::value;
-            char* __restrict__ tb = T0 + (c & 1) * kLcChunkB;
-            f32x4 m[NG], t00[NG], t01[NG], t10[NG], t11[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                // taps: patch rows (my >> 1, + 1) -- replicated at the image border when fetched --, columns clamped above
-                t00[g] = *reinterpret_cast<const f32x4*>(Pt + offa[g] + c * 16);
-                t01[g] = *reinterpret_cast<const f32x4*>(Pt + offb[g] + c * 16);
-                t10[g] = *reinterpret_cast<const f32x4*>(Pt + offa[g] + kLcPW * kLcPS + c * 16);
-                t11[g] = *reinterpret_cast<const f32x4*>(Pt + offb[g] + kLcPW * kLcPS + c * 16);
-                m[g] = bl[c];
-            }
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int g = 0; g < NG; ++g) m[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[c][s], fr[g][s], m[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float top = t00[g][r] * lx0[g] + t01[g][r] * lx1[g];
-                    const float bot = t10[g][r] * lx0[g] + t11[g][r] * lx1[g];
-                    const float x = m[g][r] + (top * ly0[g] + bot * ly1[g]);
-                    v[r] = inside[g] ? x : 0.0f;
-                }
-                uint32_t h0, m0, l0, h1, m1, l1;
-                split_pair(v[0], v[1], h0, m0, l0);
-                split_pair(v[2], v[3], h1, m1, l1);
-                char* __restrict__ d = tb + (q >> 1) * kLcPLB + mpos[g] * 16 + (q & 1) * 8;
-                *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
-                *reinterpret_cast<u32x2*>(d + 2 * kLcPLB) = u32x2{m0, m1};
-                *reinterpret_cast<u32x2*>(d + 4 * kLcPLB) = u32x2{l0, l1};
-            }
-        };
-        auto phase_a = [&](int c) __attribute__((always_inline)) {
-            if (wave < kLcMG - (kLcGPW - 1) * kLcWaves) phase_a_n(c, std::integral_constant<int, kLcGPW>{});      // wave-uniform
-            else phase_a_n(c, std::integral_constant<int, kLcGPW - 1>{});
-        };
-        auto phase_b = [&](int c) __attribute__((always_inline)) {
-            const char* __restrict__ tb = T0 + (c & 1) * kLcChunkB;
-            const char* __restrict__ x1 = tb + x1o;
-            const char* __restrict__ x3 = tb + x3o;
-            bf8 a1[2][MBO], a2[2][MBO], a3[2][MBO], b1[2][NB], b3[2][NB];
-            auto read = [&](int tap, int set) {
-                const int ky = tap / 3, kx = tap - ky * 3;
-                const int to = (ky * kLcMW + kx) * 16;
-#pragma unroll
-                for (int mb = 0; mb < MBO; ++mb) {
-                    const int o = ((mb * 3 + c) * 9 + tap) * 1536;
-                    a1[set][mb] = *reinterpret_cast<const bf8*>(wa + o);
-                    a2[set][mb] = *reinterpret_cast<const bf8*>(wa + o + 512);
-                    a3[set][mb] = *reinterpret_cast<const bf8*>(wa3 + o);
-                }
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    b1[set][nb] = *reinterpret_cast<const bf8*>(x1 + boff[nb] + to);
-                    b3[set][nb] = *reinterpret_cast<const bf8*>(x3 + boff[nb] + to);
-                }
-            };
-            read(0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int s = tap & 1;
-                if (tap + 1 < 9) read(tap + 1, s ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mb = 0; mb < MBO; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[s][mb], b3[s][nb], acc[mb][nb], 0, 0, 0);
-#pragma unroll
-                for (int mb = 0; mb < MBO; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[s][mb], b1[s][nb], acc[mb][nb], 0, 0, 0);
-#pragma unroll
-                for (int mb = 0; mb < MBO; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s][mb], b1[s][nb], acc[mb][nb], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-
-        phase_a(0);
-        __syncthreads();
-        phase_b(0);
-        phase_a(1);
-        __syncthreads();
-        phase_b(1);
-        phase_a(2);
-        __syncthreads();            // every wave is done with the patch
-        phase_b(2);
-
-        // ---- results (D: column = pixel l16, row = output channel 4 q + r: the shared epilogue's layout) ----
-        uint32_t pix_off[NB];
-        int py[NB], px[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int pos = (wave + nb * kLcWaves) * 16 + l16;
-            const int oy = cur.oy0 + pos / kLcTW, ox = cur.ox0 + pos % kLcTW;
-            pix_off[nb] = oy < a.H && ox < a.W ? (uint32_t)(oy * a.W + ox) * 4u : kEpiOob;
-            py[nb] = oy;
-            px[nb] = ox;
+        // chunk 0 | chunk 1
+        if (more) {
+            fetch_part(nxt, 2);
+            fetch_part(nxt, 3);
         }
-        EpilogueArgs e;
-        e.out = epi_out_base(a.out, (int64_t)cur.n * a.out_sn, a.out_nhwc);
-        e.out2 = a.out2 ? a.out2 + (int64_t)cur.n * a.Cout * P : nullptr;
-        e.add = nullptr; e.aux1 = nullptr; e.aux2 = nullptr;
-        e.Cout = a.Cout; e.P = P; e.act = 0;
-        e.add_mode = 0; e.Hout = a.H; e.Wout = a.W; e.out_nhwc = a.out_nhwc;
-        conv_epilogue<MBO, NB>(e, acc, 0, q, pix_off, py, px);
-        if (wn >= wend) return false;
-        w = wn;
-        cur = nxt;
-        return true;
-    };
-    while (tile(0) && tile(1)) {}
+        if (b_first) { phase_b(0, buf); phase_a(1, buf ^ 1); } else { phase_a(1, buf ^ 1); phase_b(0, buf); }
+        __syncthreads();
+        if (more) {
+            fetch_part(nxt, 4);
+            fetch_part(nxt, 5);
+        }
+        if (b_first) { phase_b(1, buf ^ 1); phase_a(2, buf); } else { phase_a(2, buf); phase_b(1, buf ^ 1); }
+        __syncthreads();            // every wave is done with the patch and the fine tile of this tile
+        const bool had_more = more;
+        const Work done = cur;
+        if (had_more) {
+            stage(nxt);             // (waits for the loads issued over the last three steps)
+            __syncthreads();
+            cur = nxt;
+            w = wn;
+            wn = w + wstep;
+            setup_a(cur);
+            more = wn < wend;
+            if (more) {
+                nxt = decode(wn);
+                fetch_part(nxt, 0);
+                fetch_part(nxt, 1);
+            }
+        }
+        // the last chunk of this tile | chunk 0 of the next one
+        if (b_first || !had_more) {
+            phase_b(2, buf);
+            store(done);
+            if (had_more) phase_a(0, buf ^ 1);
+        } else {
+            phase_a(0, buf ^ 1);
+            phase_b(2, buf);
+            store(done);
+        }
+        if (!had_more) break;
+        buf ^= 1;
+        __syncthreads();
+    }
 }
 
 template <int KS, int MBO>
