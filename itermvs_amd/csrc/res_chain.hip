@@ -164,12 +164,14 @@ __global__ void __launch_bounds__(kRcThreads) res_chain16_kernel(const ResChainA
         return k;
     };
     float stage[NIT][8];
-    auto fetch = [&](const Work& k) {
+    // item j of tile k's staging loads.  The next tile's items are issued one per layer: issued together they fill the CU's
+    // address path and the issuing waves stand at the instruction while the others wait at the next barrier (seen in
+    // lat_conv.hip's phase stamps, profiles/r06/r06k_*)
+    auto fetch_item = [&](const Work& k, int j) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t ir =
             __builtin_amdgcn_make_buffer_rsrc((void*)(a.y1 + (int64_t)k.n * a.y1_sn), 0, (int)(16u * plane * 4u), 0x00020000);
         const int iy0 = k.oy0 - 3, ix0 = k.ox0 - 3;
-#pragma unroll
-        for (int j = 0; j < NIT; ++j) {
+        {
             const int item = tid + j * kRcThreads;
             const int hf = item >= G::YPX ? 1 : 0, px = item - hf * G::YPX;
             const int y = px / G::YW, x = px - y * G::YW;
@@ -192,10 +194,12 @@ __global__ void __launch_bounds__(kRcThreads) res_chain16_kernel(const ResChainA
         }
     };
 
+    static_assert(NIT == 3, "one staging item per layer");
     int w = blockIdx.x;
     if (w >= a.total) return;
     Work cur = decode(w);
-    fetch(cur);
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) fetch_item(cur, j);
     while (true) {
         // ---- y1 tile: split, three planes to LDS ----
 #pragma unroll
@@ -218,6 +222,7 @@ __global__ void __launch_bounds__(kRcThreads) res_chain16_kernel(const ResChainA
         __syncthreads();
         const int wn = w + gridDim.x;
         Work nxt = cur;
+        if (wn < a.total) nxt = decode(wn);
 
         // ---- a = relu(conv(y1) + ba + ds) on (TH+4) x (TW+4), origin (oy0 - 2, ox0 - 2) ----
         {
@@ -243,6 +248,7 @@ __global__ void __launch_bounds__(kRcThreads) res_chain16_kernel(const ResChainA
                         dsv[nb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, go, (uint32_t)r * plane * 4u, 0));
                 }
             }
+            if (wn < a.total) fetch_item(nxt, 0);      // (behind the shortcut's loads: memory returns in order; the staging registers are free once the y1 tile is split)
             f32x4 acc[NBA];
 #pragma unroll
             for (int nb = 0; nb < NBA; ++nb) acc[nb] = *reinterpret_cast<const f32x4*>(Bs + 0 + q * 4);
@@ -262,10 +268,7 @@ __global__ void __launch_bounds__(kRcThreads) res_chain16_kernel(const ResChainA
             }
         }
         __syncthreads();
-        if (wn < a.total) {                 // the next tile's loads fly while layers 2 and 3 compute (registers: free of the shortcut now)
-            nxt = decode(wn);
-            fetch(nxt);
-        }
+        if (wn < a.total) fetch_item(nxt, 1);
 
         // ---- b = relu(conv(a) + bb) on (TH+2) x (TW+2), origin (oy0 - 1, ox0 - 1); overwrites the y1 tile ----
         {
@@ -288,6 +291,7 @@ __global__ void __launch_bounds__(kRcThreads) res_chain16_kernel(const ResChainA
             }
         }
         __syncthreads();
+        if (wn < a.total) fetch_item(nxt, 2);
 
         // ---- c = relu(conv(b) + bc + a) on TH x TW -> global planes ----
         {
