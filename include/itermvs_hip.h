@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define ITERMVS_ABI_VERSION 11
+#define ITERMVS_ABI_VERSION 12
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -311,16 +311,21 @@ int itermvs_head_regress(const float* x, int64_t x_sb, int32_t B, int32_t P, con
 
 /* itermvs_head_fused -- the whole depth head in one launch: its first layer (3x3, dilation 2, 32 -> 32, ReLU; weights in
  * itermvs_conv2d's weight_format 2 = [9][2][4][32][4]) evaluated from an LDS tile of `hidden` [B,32,H,W] (planes, batch
- * stride hidden_sb) and chained in registers into itermvs_head_regress (models/itermvs.py:121-126, 171-190, 201-219). */
+ * stride hidden_sb) and chained in registers into itermvs_head_regress (models/itermvs.py:121-126, 171-190, 201-219).
+ * w2_format: 0 = w2_packed is itermvs_head_regress's fp32 operand layout (exact fp32 matrix instruction);
+ *            3 = the 64 -> 256 layer in the bf16x3 form of itermvs_conv2d's weight_format 3 (both operands split exactly into three
+ *                bf16 terms, the six largest cross products, fp32 accumulation): w2_packed = bf16 [16][2][3][64][8] whose element
+ *                (ob, g, p, lane = 16 q + i, j) is term p of W2[ob*16 + i][(2g + j/4)*16 + 4q + j%4]
+ *                (itermvs_amd.ops.pack_head_w2_split3).  w2_packed 16-byte aligned in both forms. */
 int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W,
-                       const float* w0_tile, const float* w1_packed, const float* w2_packed, const float* bias2,
+                       const float* w0_tile, const float* w1_packed, const void* w2_packed, int32_t w2_format, const float* bias2,
                        float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream);
 /* itermvs_head_fused_conf -- itermvs_head_fused and, in the SAME launch on the same staged tile of `hidden`, the confidence
  * head (models/itermvs.py:147-151 with the sigmoid of :198, run on the last GRU iteration :197-199): wc_tile = its dilated
  * 3x3 layer 32 -> 32 in weight_format 2 ([9][2][4][32][4], 16-byte aligned), conf_dot = the 32 weights of its 1x1 layer + bias,
  * conf [B,1,H,W] planes at batch stride conf_sb receives sigmoid(conv1x1(relu(conv3x3(hidden)))). */
 int itermvs_head_fused_conf(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W,
-                            const float* w0_tile, const float* w1_packed, const float* w2_packed, const float* bias2,
+                            const float* w0_tile, const float* w1_packed, const void* w2_packed, int32_t w2_format, const float* bias2,
                             float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best,
                             const float* wc_tile, const float* conf_dot, float* conf, int64_t conf_sb, void* stream);
 

@@ -22,6 +22,7 @@
 namespace itermvs {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
 
 constexpr int kHeadBins = ITERMVS_PROB_BINS;
 constexpr int kHeadWin = 2 * ITERMVS_WINDOW_RADIUS + 1;
@@ -229,7 +230,7 @@ struct FusedArgs {
     int64_t h_sb;
     const float* w0t;        // 3x3 weights, tile format [9][2][4][32][4]
     const float* w1p;
-    const float* w2p;
+    const void* w2p;         // W2B: bf16 [16][2][3][64][8] (ops.pack_head_w2_split3), else fp32 packed like itermvs_head_regress
     const float* bias2;
     HeadOut out;
     int H, W, tiles_x;
@@ -262,9 +263,10 @@ struct FusedArgs {
 // ---------------------------------------------------------------------------------------------
 constexpr int kCoT = 2 * 4 * 3 * 20 * 4;   // staged tile: [chunk][q][row][col][s]
 constexpr int kCoP = 2 * 2 * 4 * 16 * 4;   // conv partials: [chunk][mb0][q][l16][r]
-constexpr int kCoY = 4 * 4 * 16 * 4;       // hidden layer: [mb1][q][l16][r]
+constexpr int kCoY = 3 * 2 * 64 * 4;       // hidden layer: fp32 [mb1][q][l16][r] (1024 floats), or -- W2B -- its three bf16 terms as B
+                                           // operands of the 64 -> 256 layer: [plane h,m,l][k group][lane][8 bf16]
 constexpr int kCoLgStride = 256 + 4;       // logits [16 pixels][256 bins], rows padded against bank conflicts
-constexpr int kCoLds = 2 * kCoT + kCoP + kCoY + 16 * kCoLgStride;
+constexpr int kCoLds = 2 * kCoT + kCoP + kCoY + 16 * kCoLgStride + kHeadBins;      // (+ the 256 biases of the last layer)
 constexpr int kCoWc = 9 * 2 * 4 * 32 * 4;  // the confidence head's 3x3 weights (CONF form): [tap][chunk][q][co 32][s]
 static_assert(kCoP <= 16 * kCoLgStride, "the confidence partials alias the logits buffer");
 
@@ -272,13 +274,19 @@ static_assert(kCoP <= 16 * kCoLgStride, "the confidence partials alias the logit
 // tile -- the last GRU iteration's launch carries it instead of a launch of its own (11.5 us at cfg 1).  Its 3x3 weights sit in
 // LDS (37 KB; the depth head's fill the wave's registers), its two chunk partials use the logits buffer, which is idle until the
 // 64 -> 256 layer is done; wave 0 folds ReLU, the 1x1 layer and the sigmoid into the phase of the depth head's first 1x1 layer.
-template <bool CONF>
+// W2B: the 64 -> 256 layer (64 of a wave's 108 fp32 matrix instructions per tile, 32 cycles each) in the bf16x3 form of conv_tile3.hip:
+// the hidden layer's ReLU results are split exactly into three bf16 terms by the wave that produces them (8 bytes per lane and
+// plane), the wave's W2 slice -- split on the host -- sits in registers as A operands of v_mfma_f32_16x16x32_bf16 (K = 32 = the
+// lane's own eight channels (2g + j/4) * 16 + 4q + j%4 of k group g: the D layout of the 32 -> 64 layer IS this B layout), and
+// the six largest cross products per k group replace 32 fp32 instructions: 48 x 16 instead of 64 x 32 matrix-pipe cycles.
+template <bool CONF, bool W2B>
 __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, const int tiles_total) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* __restrict__ Pp = smem + 2 * kCoT;       // (two tile buffers in front: the next tile is stashed while this one computes)
     float* __restrict__ Y = Pp + kCoP;
     float* __restrict__ LG = Y + kCoY;
     float* __restrict__ PC = LG;                    // CONF: conv partials of the confidence head
+    float* __restrict__ BS = LG + 16 * kCoLgStride; // the last layer's biases (accumulator start values, re-read per tile: 16 registers less)
     float* __restrict__ WC = smem + kCoLds;         // CONF: its 3x3 weights
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -287,20 +295,29 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
     const uint32_t plane = (uint32_t)(a.H * a.W);
 
     // this wave's weight slices -> registers, once
-    f32x4 wc[9], w1r[2], w2r[4][4];
+    f32x4 wc[9], w1r[2], w2r[W2B ? 1 : 4][W2B ? 1 : 4];
+    bf8 w2b[W2B ? 4 : 1][W2B ? 2 : 1][W2B ? 3 : 1];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
         wc[tap] = *reinterpret_cast<const f32x4*>(a.w0t + ((((tap * 2 + ch) * 4 + q) * 32) + mb0 * 16 + l16) * 4);
 #pragma unroll
     for (int u = 0; u < 2; ++u) w1r[u] = *reinterpret_cast<const f32x4*>(a.w1p + ((((wave * 2 + u) * 4 + q) * 16) + l16) * 4);
+    if constexpr (W2B) {
 #pragma unroll
-    for (int mbl = 0; mbl < 4; ++mbl)
+        for (int mbl = 0; mbl < 4; ++mbl)
 #pragma unroll
-        for (int m1 = 0; m1 < 4; ++m1)
-            w2r[mbl][m1] = *reinterpret_cast<const f32x4*>(a.w2p + (((((wave * 4 + mbl) * 4 + m1) * 4 + q) * 16) + l16) * 4);
-    f32x4 bias[4];
+            for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int mbl = 0; mbl < 4; ++mbl) bias[mbl] = *reinterpret_cast<const f32x4*>(a.bias2 + (wave * 4 + mbl) * 16 + q * 4);
+                for (int pl = 0; pl < 3; ++pl)
+                    w2b[mbl][g][pl] = reinterpret_cast<const bf8*>(a.w2p)[(((wave * 4 + mbl) * 2 + g) * 3 + pl) * 64 + lane];
+    } else {
+#pragma unroll
+        for (int mbl = 0; mbl < 4; ++mbl)
+#pragma unroll
+            for (int m1 = 0; m1 < 4; ++m1)
+                w2r[mbl][m1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.w2p) + (((((wave * 4 + mbl) * 4 + m1) * 4 + q) * 16) + l16) * 4);
+    }
+    BS[tid] = a.bias2[tid];                         // (256 threads, 256 bins; visible after the loop's first barrier)
     if constexpr (CONF) {
         f32x4 t[kCoWc / 4 / 256];
 #pragma unroll
@@ -315,18 +332,17 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
     // computed once.
     constexpr int ITEMS = (32 * 60 + 255) / 256;
     float st[ITEMS];
-    uint32_t it_plane[ITEMS];
-    int it_dy[ITEMS], it_dx[ITEMS], it_lds[ITEMS];
+    // (two registers per item: the plane offset, and LDS slot | column << 12 | row << 17 | live << 19 packed)
+    uint32_t it_plane[ITEMS], it_meta[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int item = tid + i * 256;
         const int c = item / 60, r = item - c * 60;
         const int row = r / 20, col = r - row * 20;
         it_plane[i] = (uint32_t)c * plane;
-        it_dy[i] = item < 32 * 60 ? 2 * (row - 1) : -(1 << 20);        // surplus items: always out of range
-        it_dx[i] = col - 2;
         // channel c = chunk*16 + qq*4 + s  ->  T[chunk][qq][row][col][s]
-        it_lds[i] = item < 32 * 60 ? ((((c >> 4) * 4 + ((c >> 2) & 3)) * 3 + row) * 20 + col) * 4 + (c & 3) : -1;
+        const int lds = ((((c >> 4) * 4 + ((c >> 2) & 3)) * 3 + row) * 20 + col) * 4 + (c & 3);
+        it_meta[i] = item < 32 * 60 ? (uint32_t)lds | (uint32_t)col << 12 | (uint32_t)row << 17 | 1u << 19 : 0u;      // surplus items: dead
     }
     const int rows_per_b = a.H * a.tiles_x;
     auto fetch = [&](int tile) {
@@ -335,15 +351,15 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
         const float* __restrict__ base = a.hidden + (int64_t)b * a.h_sb;
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            const int gy = y + it_dy[i], gx = x0 + it_dx[i];
-            const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const int gy = y + 2 * (int)((it_meta[i] >> 17) & 3u) - 2, gx = x0 + (int)((it_meta[i] >> 12) & 31u) - 2;
+            const bool ok = (it_meta[i] >> 19) != 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             st[i] = ok ? base[it_plane[i] + (uint32_t)(gy * a.W + gx)] : 0.0f;
         }
     };
     auto stash = [&](float* __restrict__ T) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i)
-            if (it_lds[i] >= 0) T[it_lds[i]] = st[i];
+            if (it_meta[i] >> 19) T[it_meta[i] & 0xfffu] = st[i];
     };
 
     int tile = blockIdx.x, buf = 0;
@@ -400,7 +416,18 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc1[r] = fmaxf(acc1[r], 0.0f);
-        *reinterpret_cast<f32x4*>(Y + ((wave * 4 + q) * 16 + l16) * 4) = acc1;
+        if constexpr (W2B) {
+            // channels wave*16 + 4q + r = slots (wave & 1) * 4 + r of k group wave >> 1: 8 bytes per plane
+            uint32_t h0, m0, l0, h1, m1, l1;
+            split_pair(acc1[0], acc1[1], h0, m0, l0);
+            split_pair(acc1[2], acc1[3], h1, m1, l1);
+            char* __restrict__ d = reinterpret_cast<char*>(Y) + (((wave >> 1) * 64 + lane) * 16) + (wave & 1) * 8;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + 2 * 64 * 16) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2*>(d + 4 * 64 * 16) = u32x2{l0, l1};
+        } else {
+            *reinterpret_cast<f32x4*>(Y + ((wave * 4 + q) * 16 + l16) * 4) = acc1;
+        }
         if constexpr (CONF) {
             if (wave == 0) {        // confidence = sigmoid(sum_c relu(conv)[c] w[c] + b): lane (q, l16) holds channels u*16 + q*4 + r
                 float sdot = 0.0f;
@@ -424,14 +451,41 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
         // ---- 1x1 layer 64 -> 256: bins 64*wave .. 64*wave + 63 ----
         f32x4 acc2[4];
 #pragma unroll
-        for (int mbl = 0; mbl < 4; ++mbl) acc2[mbl] = bias[mbl];
+        for (int mbl = 0; mbl < 4; ++mbl) acc2[mbl] = *reinterpret_cast<const f32x4*>(BS + (wave * 4 + mbl) * 16 + q * 4);
+        if constexpr (W2B) {
+            bf8 yh[2], ym[2], yl[2];
 #pragma unroll
-        for (int m1 = 0; m1 < 4; ++m1) {
-            const f32x4 yv = *reinterpret_cast<const f32x4*>(Y + ((m1 * 4 + q) * 16 + l16) * 4);
+            for (int g = 0; g < 2; ++g) {
+                const char* __restrict__ sy = reinterpret_cast<const char*>(Y) + (g * 64 + lane) * 16;
+                yh[g] = *reinterpret_cast<const bf8*>(sy);
+                ym[g] = *reinterpret_cast<const bf8*>(sy + 2 * 64 * 16);
+                yl[g] = *reinterpret_cast<const bf8*>(sy + 4 * 64 * 16);
+            }
+            // six cross products per k group, small terms first; the four output blocks interleaved (independent accumulators)
 #pragma unroll
-            for (int mbl = 0; mbl < 4; ++mbl)
+            for (int g = 0; g < 2; ++g) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc2[mbl] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[mbl][m1][r], yv[r], acc2[mbl], 0, 0, 0);
+                for (int mbl = 0; mbl < 4; ++mbl) acc2[mbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2b[mbl][g][2], yh[g], acc2[mbl], 0, 0, 0);
+#pragma unroll
+                for (int mbl = 0; mbl < 4; ++mbl) acc2[mbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2b[mbl][g][0], yl[g], acc2[mbl], 0, 0, 0);
+#pragma unroll
+                for (int mbl = 0; mbl < 4; ++mbl) acc2[mbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2b[mbl][g][1], ym[g], acc2[mbl], 0, 0, 0);
+#pragma unroll
+                for (int mbl = 0; mbl < 4; ++mbl) acc2[mbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2b[mbl][g][1], yh[g], acc2[mbl], 0, 0, 0);
+#pragma unroll
+                for (int mbl = 0; mbl < 4; ++mbl) acc2[mbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2b[mbl][g][0], ym[g], acc2[mbl], 0, 0, 0);
+#pragma unroll
+                for (int mbl = 0; mbl < 4; ++mbl) acc2[mbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2b[mbl][g][0], yh[g], acc2[mbl], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int m1 = 0; m1 < 4; ++m1) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(Y + ((m1 * 4 + q) * 16 + l16) * 4);
+#pragma unroll
+                for (int mbl = 0; mbl < 4; ++mbl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc2[mbl] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[mbl][m1][r], yv[r], acc2[mbl], 0, 0, 0);
+            }
         }
 
         // ---- logits -> LDS [pixel][bin]; then wave w owns pixels 4w .. 4w+3 completely (16 lanes x 16 bins each): the
@@ -541,12 +595,24 @@ extern "C" int itermvs_head_regress(const float* x, int64_t x_sb, int32_t B, int
     return itermvs_launch_status();
 }
 
+template <bool CONF, bool W2B>
+static int launch_head_coop(const FusedArgs& a, int grid, int tiles, hipStream_t stream) {
+    constexpr int lds = (kCoLds + (CONF ? kCoWc + 36 : 0)) * 4;      // CONF: 78 KB, two workgroups per CU still fit the 160 KB
+    auto kern = head_coop_kernel<CONF, W2B>;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    if (!attr_ok) return ITERMVS_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, tiles);
+    return itermvs_launch_status();
+}
+
 static int launch_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W, const float* w0_tile,
-                             const float* w1_packed, const float* w2_packed, const float* bias2, float* nd_out0, int64_t nd_sb0,
+                             const float* w1_packed, const void* w2_packed, int32_t w2_format, const float* bias2, float* nd_out0, int64_t nd_sb0,
                              float* nd_out1, int64_t nd_sb1, int64_t* best, const float* wc_tile, const float* conf_dot, float* conf,
                              int64_t conf_sb, void* stream) {
     ITERMVS_RETURN_IF(!hidden || !w0_tile || !w1_packed || !w2_packed || !bias2, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(B < 1 || H < 1 || W < 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(w2_format != 0 && w2_format != 3, ITERMVS_ERR_LAYOUT);
+    ITERMVS_RETURN_IF((((uintptr_t)w2_packed) & 15) != 0, ITERMVS_ERR_ALIGN);
     FusedArgs a;
     a.hidden = hidden; a.h_sb = hidden_sb; a.w0t = w0_tile; a.w1p = w1_packed; a.w2p = w2_packed; a.bias2 = bias2;
     a.out.nd0 = nd_out0; a.out.nd1 = nd_out1; a.out.nd_sb0 = nd_sb0; a.out.nd_sb1 = nd_sb1; a.out.best = best; a.out.P = H * W;
@@ -557,31 +623,24 @@ static int launch_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, 
     const int tiles = a.tiles_x * H * B;
     static const int wgs_per_cu = [] { const char* e = itermvs_tuning_env("ITERMVS_HEAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
     const int grid = tiles < wgs_per_cu * cus ? tiles : wgs_per_cu * cus;
-    if (conf) {
-        constexpr int lds = (kCoLds + kCoWc + 36) * 4;      // 77 KB: two workgroups per CU still fit the 160 KB
-        static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(head_coop_kernel<true>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
-        ITERMVS_RETURN_IF(!attr_ok, ITERMVS_ERR_LAUNCH);
-        hipLaunchKernelGGL(head_coop_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, tiles);
-    } else {
-        hipLaunchKernelGGL(head_coop_kernel<false>, dim3(grid), dim3(256), kCoLds * 4, (hipStream_t)stream, a, tiles);
-    }
-    return itermvs_launch_status();
+    hipStream_t st = (hipStream_t)stream;
+    if (conf) return w2_format ? launch_head_coop<true, true>(a, grid, tiles, st) : launch_head_coop<true, false>(a, grid, tiles, st);
+    return w2_format ? launch_head_coop<false, true>(a, grid, tiles, st) : launch_head_coop<false, false>(a, grid, tiles, st);
 }
 
 extern "C" int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W,
-                                  const float* w0_tile, const float* w1_packed, const float* w2_packed, const float* bias2,
+                                  const float* w0_tile, const float* w1_packed, const void* w2_packed, int32_t w2_format, const float* bias2,
                                   float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream) {
-    return launch_head_fused(hidden, hidden_sb, B, H, W, w0_tile, w1_packed, w2_packed, bias2, nd_out0, nd_sb0, nd_out1, nd_sb1, best,
+    return launch_head_fused(hidden, hidden_sb, B, H, W, w0_tile, w1_packed, w2_packed, w2_format, bias2, nd_out0, nd_sb0, nd_out1, nd_sb1, best,
                              nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int itermvs_head_fused_conf(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W,
-                                       const float* w0_tile, const float* w1_packed, const float* w2_packed, const float* bias2,
+                                       const float* w0_tile, const float* w1_packed, const void* w2_packed, int32_t w2_format, const float* bias2,
                                        float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best,
                                        const float* wc_tile, const float* conf_dot, float* conf, int64_t conf_sb, void* stream) {
     ITERMVS_RETURN_IF(!wc_tile || !conf_dot || !conf, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF((((uintptr_t)wc_tile) & 15) != 0, ITERMVS_ERR_ALIGN);
-    return launch_head_fused(hidden, hidden_sb, B, H, W, w0_tile, w1_packed, w2_packed, bias2, nd_out0, nd_sb0, nd_out1, nd_sb1, best,
+    return launch_head_fused(hidden, hidden_sb, B, H, W, w0_tile, w1_packed, w2_packed, w2_format, bias2, nd_out0, nd_sb0, nd_out1, nd_sb1, best,
                              wc_tile, conf_dot, conf, conf_sb, stream);
 }

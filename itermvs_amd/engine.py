@@ -146,6 +146,10 @@ class InferenceEngine:
         self.corrnet_w = {l: ops.pack_corrnet_weights(w, f"iter_mvs.evaluation.corr_conv1.{l - 1}.", split3=self.split3) for l in (1, 2, 3)}
         dh = "iter_mvs.update.depth_head."
         self.head_w1, self.head_w2 = ops.pack_head_weights(w[dh + "2.weight"], w[dh + "4.weight"])
+        if self.split3:     # the 64 -> 256 layer of the fused head on the bf16 matrix instruction (bf16x3 arithmetic, head.hip W2B)
+            self.head_w2_fused = ops.pack_head_w2_split3(w[dh + "4.weight"])
+        else:
+            self.head_w2_fused = self.head_w2
         # (z / r gates, 43 -> 64 dilated at 1/4 resolution: the bf16x3 form measured 18.7 us against 18.2 us -- four channel
         #  blocks stage and split each tile four times; the q convolution, two blocks, gains: 11.1 vs 13.1 us)
         self.pk_zr = ops.MfmaWeight(self.w_zr, split3=False)
@@ -362,7 +366,7 @@ class InferenceEngine:
         if not want_logits:
             p = "iter_mvs.update.depth_head."
             conf = (self.pk_conf, self.conf_dot, ws["conf"]) if with_conf else None
-            _, best = ops.head_fused(hidden, self.pk[p + "0.weight"], self.head_w1, self.head_w2, self.w[p + "4.bias"],
+            _, best = ops.head_fused(hidden, self.pk[p + "0.weight"], self.head_w1, self.head_w2_fused, self.w[p + "4.bias"],
                                      nd_out=nd_out, want_best=want_best, conf=conf)
             return None, best
         if with_conf:

@@ -664,6 +664,17 @@ def pack_head_weights(w1: Tensor, w2: Tensor) -> Tuple[Tensor, Tensor]:
     return a1, a2
 
 
+def pack_head_w2_split3(w2: Tensor) -> Tensor:
+    """depth_head[4].weight [256,64,1,1] -> the bf16x3 A operands of itermvs_head_fused's 64 -> 256 layer (w2_format 3):
+    bfloat16 [16][2][3][64][8] whose element (ob, g, p, lane = 16 q + i, j) is term p (h, m, l of ``split_bf16x3``) of
+    W2[ob*16 + i][(2g + j//4)*16 + 4q + j%4]."""
+    if w2.numel() != 256 * 64:
+        raise RuntimeError("pack_head_w2_split3: expects the [256,64,1,1] weight")
+    t = w2.reshape(16, 16, 2, 2, 4, 4).float()                    # [ob, i, g, jj, q, r]: channel (2g + jj)*16 + 4q + r
+    t = t.permute(0, 2, 4, 1, 3, 5).reshape(16, 2, 64, 8)         # [ob, g, (q, i), (jj, r)]
+    return torch.stack(split_bf16x3(t), 2).contiguous()           # [16, 2, 3, 64, 8]
+
+
 def pack_conv1x1_operand(w1: Tensor, bias: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """Conv2d(64, NO, 1) weight [NO,64,1,1] (+ bias [NO]) -> the matrix-core operand layout of itermvs_conv3x3_conv1x1:
     [NOB][4][4][16][4] with element (ob,m,q,i,r) = W1[ob*16+i][m*16+q*4+r], NO zero-padded to NOB*16 (bias likewise)."""
@@ -741,6 +752,16 @@ def head_fused(hidden: Tensor, w0: "MfmaWeight", w1p: Tensor, w2p: Tensor, bias2
         raise RuntimeError("head_fused: expects the 32-channel hidden state and the 32 -> 32 3x3 weight")
     ptr, sb = _planes(hidden, "hidden")
     p = h * w
+    if not isinstance(w2p, torch.Tensor) or not w2p.is_cuda:
+        raise RuntimeError("w2: expected a CUDA/ROCm tensor - the IterMVS HIP engine has no CPU path")
+    if w2p.dtype == torch.bfloat16:          # pack_head_w2_split3: the 64 -> 256 layer in the bf16x3 form
+        if tuple(w2p.shape) != (16, 2, 3, 64, 8) or not w2p.is_contiguous():
+            raise RuntimeError("head_fused: a bfloat16 w2 must come from pack_head_w2_split3")
+        w2_format = 3
+    elif w2p.dtype == torch.float32 and w2p.numel() == 256 * 64 and w2p.is_contiguous():
+        w2_format = 0
+    else:
+        raise RuntimeError("head_fused: w2 must come from pack_head_weights (float32) or pack_head_w2_split3 (bfloat16)")
     nd, dests = None, []
     if nd_out is None:
         nd = torch.empty((b, 1, h, w), device=hidden.device, dtype=torch.float32)
@@ -758,12 +779,12 @@ def head_fused(hidden: Tensor, w0: "MfmaWeight", w1p: Tensor, w2p: Tensor, bias2
         if wc.tile is None or wc.cin != 32 or wc.cout != 32 or cdot.numel() != 33 or tuple(cout.shape) != (b, 1, h, w) or not cout.is_contiguous():
             raise RuntimeError("head_fused: conf = (32 -> 32 3x3 MfmaWeight in the fp32 tile format, 33 floats, contiguous [B,1,H,W] output)")
         check(_lib.load().itermvs_head_fused_conf(ptr, sb, b, h, w, w0.tile.data_ptr(), _dev(w1p, "w1").data_ptr(),
-                                                  _dev(w2p, "w2").data_ptr(), _dev(bias2, "bias2").data_ptr(), dests[0][0], dests[0][1],
+                                                  w2p.data_ptr(), w2_format, _dev(bias2, "bias2").data_ptr(), dests[0][0], dests[0][1],
                                                   dests[1][0], dests[1][1], _ptr(best), wc.tile.data_ptr(), _dev(cdot, "conf_dot").data_ptr(),
                                                   _dev(cout, "conf").data_ptr(), p, _stream()), "itermvs_head_fused_conf")
         return nd, best
     check(_lib.load().itermvs_head_fused(ptr, sb, b, h, w, w0.tile.data_ptr(), _dev(w1p, "w1").data_ptr(),
-                                         _dev(w2p, "w2").data_ptr(), _dev(bias2, "bias2").data_ptr(), dests[0][0], dests[0][1],
+                                         w2p.data_ptr(), w2_format, _dev(bias2, "bias2").data_ptr(), dests[0][0], dests[0][1],
                                          dests[1][0], dests[1][1], _ptr(best), _stream()), "itermvs_head_fused")
     return nd, best
 

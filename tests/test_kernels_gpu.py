@@ -494,12 +494,15 @@ def test_head_regress_fused_matches_chain(tag):
         assert float(buf0[:, :3].abs().max()) == 0.0 and float(buf1[:, 2:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("w2_form", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("size", [(1, 16, 32), (2, 23, 37), (1, 128, 160)])
-def test_head_fused_equals_conv_plus_head_regress(size):
+def test_head_fused_equals_conv_plus_head_regress(size, w2_form):
     """the one-launch depth head (3x3 dilated layer + two 1x1 layers + regression; one tile shared by the four waves of a
     workgroup) against the two-launch form: the two input-channel chunks of the 3x3 layer and the four 64-bin slices of
     the softmax sum are accumulated separately and then added, so sums may differ in the last bit -- arg-max bins equal
-    wherever the two best probabilities are not within rounding of each other, normalised depth to 1e-6."""
+    wherever the two best probabilities are not within rounding of each other, normalised depth to 1e-6.
+    ``bf16x3``: the 64 -> 256 layer on the bf16 matrix instruction (both operands split exactly into three bf16 terms, six cross
+    products, fp32 accumulation: pack_head_w2_split3) -- same gates."""
     b, h, w = size
     wts = load_weights("seed0")
     p = "iter_mvs.update.depth_head."
@@ -510,6 +513,14 @@ def test_head_fused_equals_conv_plus_head_regress(size):
     a1, a2 = ops().pack_head_weights(w1, w2)
     x = ops().conv2d(hidden, pk0, None, pad=2, dilation=2, act="relu")
     nd_ref, best_ref = ops().head_regress(x, a1, a2, b2, want_best=True)
+    if w2_form == "bf16x3":
+        a2 = ops().pack_head_w2_split3(w2)
+        assert a2.dtype == torch.bfloat16 and tuple(a2.shape) == (16, 2, 3, 64, 8)
+        # the three terms add up to the weight exactly, element (ob, g, p, 16 q + i, j) = W2[ob*16 + i][(2g + j//4)*16 + 4q + j%4]
+        back = a2.float().sum(2).reshape(16, 2, 4, 16, 2, 4).permute(0, 3, 1, 4, 2, 5).reshape(256, 64)
+        assert torch.equal(back, w2.reshape(256, 64))
+        with pytest.raises(RuntimeError):
+            ops().head_fused(hidden, pk0, a1, a2[:8], b2)
     nd, best = ops().head_fused(hidden, pk0, a1, a2, b2, want_best=True)
     flips = float((best != best_ref).float().mean())
     assert flips <= 2e-4, flips
@@ -522,8 +533,9 @@ def test_head_fused_equals_conv_plus_head_regress(size):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w2_form", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("size", [(1, 16, 32), (2, 23, 37), (1, 128, 160)])
-def test_head_fused_with_confidence_head(size):
+def test_head_fused_with_confidence_head(size, w2_form):
     """itermvs_head_fused_conf: the confidence head (itermvs.py:147-151 + the sigmoid of :198) evaluated in the depth head's launch
     on the same staged tile.  Depth outputs must be bit-identical to itermvs_head_fused; the confidence equals
     sigmoid(conv1x1(relu(conv3x3 dil 2 (hidden)))) by torch to 2e-6 and the separate one-launch form (itermvs_conv2d act
@@ -538,6 +550,8 @@ def test_head_fused_with_confidence_head(size):
     hidden = torch.tanh(torch.randn((b, 32, h, w), generator=gen)).to(DEV)
     pk0, pkc = ops().MfmaWeight(w0, split3=False), ops().MfmaWeight(c0, split3=False)
     a1, a2 = ops().pack_head_weights(w1, w2)
+    if w2_form == "bf16x3":
+        a2 = ops().pack_head_w2_split3(w2)
     cdot = torch.cat([c2w.reshape(-1), c2b.reshape(-1)]).contiguous()
     nd_ref, best_ref = ops().head_fused(hidden, pk0, a1, a2, b2, want_best=True)
     conf = torch.full((b, 1, h, w), -1.0, device=DEV)

@@ -9,7 +9,7 @@ if "--lib" in sys.argv:     # a TUNING build (make TUNING=1) reads ITERMVS_HEAD_
     del sys.argv[_i:_i + 2]
 from itermvs_amd import ops
 
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+reps = int([a for a in sys.argv[1:] if a.isdigit()][0]) if any(a.isdigit() for a in sys.argv[1:]) else 300
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(1)
 hidden = torch.randn((1, 32, 128, 160), generator=g).to(dev)
@@ -19,6 +19,9 @@ w2 = (torch.randn((256, 64, 1, 1), generator=g) * 0.1).to(dev)
 b2 = torch.randn((256,), generator=g).to(dev)
 hw1, hw2 = ops.pack_head_weights(w1, w2)
 hx = torch.zeros((1, 43, 128, 160), device=dev)
+if "--w2-bf16x3" in sys.argv:      # the 64 -> 256 layer on the bf16 matrix instruction (w2_format 3)
+    sys.argv.remove("--w2-bf16x3")
+    hw2 = ops.pack_head_w2_split3(w2)
 run = lambda: ops.head_fused(hidden, w0, hw1, hw2, b2, nd_out=[(hx, 32)])
 st = torch.cuda.Stream()
 with torch.cuda.stream(st):            # 20 launches per graph replay: no host launch cost between them
