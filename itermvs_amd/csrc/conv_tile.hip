@@ -219,7 +219,15 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
     // Persistent workgroups: the grid is about two workgroups per CU and each walks the tile list with
     // stride gridDim.x.  The next stage (chunks of this tile, or the first ones of the next tile) is fetched
     // into registers while the matrix cores work on the current one.
-    int w = blockIdx.x;
+    // Tile order (a.banded): workgroup column x runs on XCD x % 8 (round-robin dispatch, gridDim.x a multiple of 8); the tiles of
+    // one XCD are a contiguous run of the tile list (whole image bands), so that tiles sharing halo rows meet in the same 4 MB L2
+    int w = blockIdx.x, wstep = gridDim.x, wend = a.total;
+    if (a.banded) {
+        const int xcd = blockIdx.x & 7;
+        w = (int)((int64_t)a.total * xcd / 8) + (blockIdx.x >> 3);
+        wend = (int)((int64_t)a.total * (xcd + 1) / 8);
+        wstep = gridDim.x >> 3;
+    }
 #ifdef ITERMVS_TILE_TRACE
     int trace_tile = 0;
 #endif
@@ -231,7 +239,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
         const int seg = (cur.n >= a.seg_end[0]) + (cur.n >= a.seg_end[1]);
         f32x4 acc[MB][NB];
         conv_bias_init<MB, NB>(acc, a.bias[seg], a.Cout, m0, q);
-        const int wn = w + gridDim.x;
+        const int wn = w + wstep;
         Work nxt = cur;
         for (int st = 0; st < a.nstage; ++st) {
             TILE_STAMP(0);
@@ -254,7 +262,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
             uint32_t pf_soff = 0;
             if (st + 1 < a.nstage) {
                 pf_soff = (uint32_t)((st + 1) * CPS) * chunk_b;
-            } else if (wn < a.total) {
+            } else if (wn < wend) {
                 nxt = decode(wn);
                 setup(nxt);
             } else {
@@ -327,7 +335,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(const TileArgs a) {
 #ifdef ITERMVS_TILE_TRACE
         ++trace_tile;
 #endif
-        if (wn >= a.total) break;
+        if (wn >= wend) break;
         w = wn;
         cur = nxt;
     }
@@ -363,6 +371,7 @@ static int launch_tile(TileArgs& a, int mt, hipStream_t stream) {
     int gx = 256 * (want < fit ? want : fit) / a.ncb;
     if (gx > a.total) gx = a.total;
     if (gx < 1) gx = 1;
+    a.banded = gx % 8 == 0 && a.total >= gx ? 1 : 0;
     const dim3 grid(gx, a.ncb);
     hipLaunchKernelGGL((conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS>), grid, dim3(256), lds, stream, a);
     return 0;
@@ -540,6 +549,7 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
     const bool s1d2 = p->stride == 1 && p->dilation == 2;
     if (!s1d1 && !s2d1 && !s1d2) return 1;
     TileArgs a;
+    a.banded = 0;
     a.in = p->in; a.out = p->out; a.out2 = p->out2; a.add = p->add; a.aux1 = p->aux1; a.aux2 = p->aux2;
     a.in_sn = p->in_sn; a.out_sn = p->out_sn; a.add_sn = p->add_sn; a.aux1_sn = p->aux1_sn; a.aux2_sn = p->aux2_sn;
     for (int i = 0; i < 3; ++i) {
@@ -646,6 +656,7 @@ int itermvs_conv2d_tile(const itermvs_conv_params* p, int hout, int wout, hipStr
 int itermvs_deconv2d_tile(const itermvs_conv_params* p, hipStream_t stream) {
     if (p->ksize != 3 || p->stride != 2 || p->pad != 1 || p->act > 1 || p->Cin <= 4 || p->Cin > 32) return 1;
     TileArgs a;
+    a.banded = 0;
     a.in = p->in; a.out = p->out; a.out2 = p->out2; a.add = p->add; a.aux1 = nullptr; a.aux2 = nullptr;
     a.in_sn = p->in_sn; a.out_sn = p->out_sn; a.add_sn = p->add_sn; a.aux1_sn = 0; a.aux2_sn = 0;
     for (int i = 0; i < 3; ++i) {

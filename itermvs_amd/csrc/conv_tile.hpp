@@ -23,6 +23,7 @@ struct TileArgs {
     int split, act_b;
     int pad, act, add_mode, out_nhwc, nchunk, nstage, tiles_x, tiles_y, ncb, total;
     uint32_t rcp_tiles_x, rcp_tiles_y;   // floor(2^32 / d) + 1
+    int banded;                          // XCD-banded tile order (see the kernels)
 };
 
 constexpr uint32_t kTileOob = 0x7fffffffu;

@@ -183,7 +183,15 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
     const char* __restrict__ abase3 = abase + (second ? 0 : 2 * WPL);                             // A3 = [wl | wh]
     const int P = a.Hout * a.Wout;
 
-    int w = blockIdx.x;
+    // Tile order (a.banded): workgroup column x runs on XCD x % 8 (round-robin dispatch, gridDim.x a multiple of 8); the tiles of
+    // one XCD are a contiguous run of the tile list (whole image bands), so that tiles sharing halo rows meet in the same 4 MB L2
+    int w = blockIdx.x, wstep = gridDim.x, wend = a.total;
+    if (a.banded) {
+        const int xcd = blockIdx.x & 7;
+        w = (int)((int64_t)a.total * xcd / 8) + (blockIdx.x >> 3);
+        wend = (int)((int64_t)a.total * (xcd + 1) / 8);
+        wstep = gridDim.x >> 3;
+    }
     int wseg = -1;
     Work cur = decode(w);
     setup(cur);
@@ -192,7 +200,7 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
         const int seg = (cur.n >= a.seg_end[0]) + (cur.n >= a.seg_end[1]);
         f32x4 acc[MB][NB];
         conv_bias_init<MB, NB>(acc, a.bias[seg], a.Cout, m0, q);
-        const int wn = w + gridDim.x;
+        const int wn = w + wstep;
         Work nxt = cur;
         for (int st = 0; st < a.nstage; ++st) {
             __syncthreads();                        // the previous stage's LDS reads are done
@@ -224,7 +232,7 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
             uint32_t pf_soff = 0;
             if (st + 1 < a.nstage) {
                 pf_soff = (uint32_t)((st + 1) * CPS) * chunk_b;
-            } else if (wn < a.total) {
+            } else if (wn < wend) {
                 nxt = decode(wn);
                 setup(nxt);
             } else {
@@ -314,7 +322,7 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
             }
         }
         conv_epilogue<MB, NB>(e, acc, me, q, pix_off, py, px);
-        if (wn >= a.total) break;
+        if (wn >= wend) break;
         w = wn;
         cur = nxt;
     }
@@ -353,6 +361,7 @@ static int launch_tile3_pair(TileArgs& a, int mt, hipStream_t stream) {
     int gx = itermvs_num_cus() * (4 < fit ? 4 : fit) / a.ncb;
     if (gx > a.total) gx = a.total;
     if (gx < 1) gx = 1;
+    a.banded = gx % 8 == 0 && a.total >= gx ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(gx, a.ncb), dim3(256), lds, stream, a);
     return 0;
 }
@@ -378,6 +387,7 @@ static int launch_tile3(TileArgs& a, int mt, hipStream_t stream) {
     int gx = itermvs_num_cus() * (want < fit ? want : fit) / a.ncb;
     if (gx > a.total) gx = a.total;
     if (gx < 1) gx = 1;
+    a.banded = gx % 8 == 0 && a.total >= gx ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(gx, a.ncb), dim3(256), lds, stream, a);
     return 0;
 }
@@ -430,6 +440,7 @@ int itermvs_conv2d_tile3(const itermvs_conv_params* p, int hout, int wout, hipSt
     const bool s1d2 = p->stride == 1 && p->dilation == 2;
     if (!s1d1 && !s2d1 && !s1d2) return 1;
     TileArgs a;
+    a.banded = 0;
     a.in = p->in; a.out = p->out; a.out2 = p->out2; a.add = p->add; a.aux1 = p->aux1; a.aux2 = p->aux2;
     a.in_sn = p->in_sn; a.out_sn = p->out_sn; a.add_sn = p->add_sn; a.aux1_sn = p->aux1_sn; a.aux2_sn = p->aux2_sn;
     for (int i = 0; i < 3; ++i) {

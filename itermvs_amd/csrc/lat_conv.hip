@@ -133,9 +133,13 @@ __global__ void __launch_bounds__(kLcThreads) lat_conv_kernel(const LatConvArgs 
             const __amdgpu_buffer_rsrc_t cr_ =
                 __builtin_amdgcn_make_buffer_rsrc((void*)(a.coarse + (int64_t)k.n * a.coarse_sn), 0, (int)(48u * cplane * 4u), 0x00020000);
             const int cy0 = (k.oy0 >> 1) - 1, cx0 = (k.ox0 >> 1) - 1;
-            const int item = tid + j * kLcThreads;                       // channel fastest: the LDS stores of a wave hit every bank once
-            const int rem = item / 48, ch = item - rem * 48;
-            const int pr = rem / kLcPQ, jq = rem - pr * kLcPQ;
+            // piece fastest, then patch row, then channel: a wave's 64 pieces are ~13 runs of 80 contiguous bytes (13-26 cache
+            // lines).  With the channel fastest every piece of a wave-level load lay in another line, the tile's 288 lines
+            // (37-74 KB) did not survive in the 32 KB L1 until their other four pieces came by, and the kernel moved 227 MB
+            // through the L2 for 33 MB of patches (profiles/r06/r06k_*)
+            const int item = tid + j * kLcThreads;
+            const int rem = item / kLcPQ, jq = item - rem * kLcPQ;
+            const int ch = rem / kLcPH, pr = rem - ch * kLcPH;
             const int cy = min(max(cy0 + pr, 0), Hc - 1);                // rows: border-replicated here; columns: clamped when read
             const uint32_t go = item < kLcPItems ? ((uint32_t)ch * cplane + (uint32_t)(cy * Wc + max(cx0 + 4 * jq, 0))) * 4u : kLcOob;
             pv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(cr_, go, 0, 0));
@@ -160,8 +164,8 @@ __global__ void __launch_bounds__(kLcThreads) lat_conv_kernel(const LatConvArgs 
         for (int j = 0; j < kLcPIT; ++j) {
             const int item = tid + j * kLcThreads;
             if (j < kLcPIT - 1 || item < kLcPItems) {
-                const int rem = item / 48, ch = item - rem * 48;
-                const int pr = rem / kLcPQ, jq = rem - pr * kLcPQ;
+                const int rem = item / kLcPQ, jq = item - rem * kLcPQ;
+                const int ch = rem / kLcPH, pr = rem - ch * kLcPH;
                 // element e is patch column 4 jq + e; in the first tile column piece 0 was fetched from image column 0 = patch column 1
                 const int pc0 = 4 * jq + (k.ox0 == 0 && jq == 0 ? 1 : 0);
                 float* __restrict__ d = Pt + (pr * kLcPW + pc0) * kLcPS + ch;
