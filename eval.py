@@ -134,6 +134,10 @@ def load_model(args, dev) -> Pipeline:
     # one hipGraph replay per depth map (bit-identical to the eager launches); host_fp32 with device-resident cameras cannot be
     # captured -- save_depth keeps the cameras on the host for that mode
     model.use_graphs = not getattr(args, "no_graphs", False)
+    # which arithmetic produced the PFMs of this run (device_fp64 moves ~1e-5 of the tap floors against the reference's host fp32
+    # composition; host_fp32 follows module.py:77-90 operation for operation)
+    print("depth maps: projection = {}, conv arithmetic = {}, feature storage = {}".format(
+        model.projection, model.conv_arithmetic, model.feature_dtype))
     if args.loadckpt:
         print("loading model {}".format(args.loadckpt))
         state = torch.load(args.loadckpt, map_location="cpu", weights_only=False)

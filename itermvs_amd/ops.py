@@ -1276,6 +1276,9 @@ def res_chain16(y1: Tensor, shortcut: Tensor, weights: Sequence["MfmaWeight"], b
     bl = [None if b is None else _dev(b, "res_chain16 bias").float().contiguous() for b in biases]
     bp = (C.c_void_p * 3)(*[_ptr(b) for b in bl])
     check(_lib.load().itermvs_res_chain16(ptr, y_sn, sp, s_sn, int(quads), n, h, w, wp, bp, po, o_sn, _stream()), "itermvs_res_chain16")
+    if CONV_FLOP_COUNTER["enabled"]:         # the three layers' FLOPs (the recomputed halo is not counted), one bracketed launch
+        CONV_FLOP_COUNTER["flops"] += 3 * 2.0 * n * h * w * 16 * 16 * 9
+        CONV_FLOP_COUNTER["launches"] += 1
     return out
 
 
@@ -1319,6 +1322,9 @@ def lateral_conv3x3(fine: Tensor, coarse: Tensor, w_lat: "MfmaWeight", b_lat: Op
     bo = None if b_out is None else _dev(b_out, "lateral_conv3x3 bias").float().contiguous()
     check(_lib.load().itermvs_lateral_conv3x3(fp, f_sn, cf, cp, c_sn, n, h, w, w_lat.data.data_ptr(), _ptr(bl), w_out.tile3.data_ptr(),
                                               _ptr(bo), cout, po, o_sn, layout, _ptr(out2), _stream()), "itermvs_lateral_conv3x3")
+    if CONV_FLOP_COUNTER["enabled"]:         # 1x1 layer + 3x3 layer (the recomputed halo is not counted), one bracketed launch
+        CONV_FLOP_COUNTER["flops"] += 2.0 * n * h * w * (cf * 48 + 48 * cout * 9)
+        CONV_FLOP_COUNTER["launches"] += 1
     return out
 
 
