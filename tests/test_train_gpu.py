@@ -269,7 +269,9 @@ def test_two_rank_training_step_on_one_gpu(feature_dtype):
         mean = (l0[name] + l1[name]) / 2
         assert torch.equal(r0[name], r1[name]), name                              # every rank holds the same averaged gradient
         assert torch.allclose(r0[name], mean, rtol=1e-6, atol=1e-12), name        # == mean of the two rank-local gradients
-        assert not torch.equal(l0[name], l1[name]) or float(l0[name].abs().max()) == 0.0, name   # the ranks really saw different data
+        # the ranks really saw different data (a gradient that is zero in exact arithmetic -- the bias in front of a softmax -- is
+        # rounding noise of a few 2^-26 and may coincide)
+        assert not torch.equal(l0[name], l1[name]) or float(l0[name].abs().max()) <= 1e-7, name
         checked += 1
     assert checked >= 95
 
