@@ -21,4 +21,4 @@ for k in ("staged_inputs", "pipelined", "with_transfers", "roofline_conv", "cpu_
         print(f"{k}: {v.get('value', v.get('achieved')):.2f} {v.get('unit', '')} {('ms/step %.3f' % v['ms_per_step']) if 'ms_per_step' in v else ''}{extra}")
 print("workload:", d["config"]["workload"])
 if d.get("box"):
-    print("box:", {k: round(v, 2) for k, v in d["box"].items()}, " normalised:", d.get("value_normalised"), " affinity:", d["config"].get("cpu_affinity"))
+    print("box:", {k: (round(v, 2) if isinstance(v, (int, float)) else v) for k, v in d["box"].items()}, " normalised:", d.get("value_normalised"), " affinity:", d["config"].get("cpu_affinity"))

@@ -26,9 +26,17 @@ print("| run | depth-maps/s | ms/step | " + " | ".join(keys) + " | GPU |")
 print("|---|---|---|" + "---|" * (len(keys) + 1))
 for name, v, ms, box, gpu in rows:
     print(f"| {name} | {v:.1f} | {ms:.4f} | " + " | ".join(f"{box[k]:.2f}" if k in box and box[k] else "" for k in keys) + f" | {gpu} |")
-for grp, sel in (("frozen source (sessions s1-s6)", [r for r in rows if "frozen" in r[0]]),
+def _sess(name):          # session number of "s27_bench_1.json"
+    digits = "".join(ch for ch in name.split("_")[0][1:] if ch.isdigit())
+    return int(digits) if digits else -1
+
+
+for grp, sel in (("frozen source of the round's first half (sessions s1-s9)", [r for r in rows if "frozen" in r[0] and _sess(r[0]) < 12]),
+                 ("frozen source eb59622 (sessions s12-s33: the A/B partner of every later change)", [r for r in rows if "frozen" in r[0] and _sess(r[0]) >= 12]),
+                 ("final source (sessions s31, s32: XCD-banded conv tiles, lat_conv, res_chain16, bf16x3 head)",
+                  [r for r in rows if "frozen" not in r[0] and _sess(r[0]) in (31, 32)]),
                  ("round-6 source after the tail fusions (sessions s3, s6-s9; kernels differ by < 1 %)",
-                  [r for r in rows if "frozen" not in r[0] and r[0][:2] in ("s3", "s6", "s7", "s8", "s9")])):
+                  [r for r in rows if "frozen" not in r[0] and _sess(r[0]) in (3, 6, 7, 8, 9)])):
     if len(sel) < 3:
         continue
     print(f"\n## {grp}: {len(sel)} runs, depth-maps/s {min(r[1] for r in sel):.1f} .. {max(r[1] for r in sel):.1f} "
