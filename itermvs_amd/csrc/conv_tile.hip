@@ -371,6 +371,7 @@ static int launch_tile(TileArgs& a, int mt, hipStream_t stream) {
     int gx = 256 * (want < fit ? want : fit) / a.ncb;
     if (gx > a.total) gx = a.total;
     if (gx < 1) gx = 1;
+    if (gx >= 16) gx &= ~7;              // a multiple of 8 workgroup columns: the XCD-banded tile order needs it (85 -> 80 costs nothing)
     a.banded = gx % 8 == 0 && a.total >= gx ? 1 : 0;
     const dim3 grid(gx, a.ncb);
     hipLaunchKernelGGL((conv_tile_kernel<MB, S, STRIDE, DIL, TH, TWT, CPS>), grid, dim3(256), lds, stream, a);

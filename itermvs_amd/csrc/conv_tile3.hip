@@ -361,6 +361,7 @@ static int launch_tile3_pair(TileArgs& a, int mt, hipStream_t stream) {
     int gx = itermvs_num_cus() * (4 < fit ? 4 : fit) / a.ncb;
     if (gx > a.total) gx = a.total;
     if (gx < 1) gx = 1;
+    if (gx >= 16) gx &= ~7;              // a multiple of 8 workgroup columns: the XCD-banded tile order needs it (85 -> 80 costs nothing)
     a.banded = gx % 8 == 0 && a.total >= gx ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(gx, a.ncb), dim3(256), lds, stream, a);
     return 0;
@@ -387,6 +388,7 @@ static int launch_tile3(TileArgs& a, int mt, hipStream_t stream) {
     int gx = itermvs_num_cus() * (want < fit ? want : fit) / a.ncb;
     if (gx > a.total) gx = a.total;
     if (gx < 1) gx = 1;
+    if (gx >= 16) gx &= ~7;              // a multiple of 8 workgroup columns: the XCD-banded tile order needs it (85 -> 80 costs nothing)
     a.banded = gx % 8 == 0 && a.total >= gx ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(gx, a.ncb), dim3(256), lds, stream, a);
     return 0;

@@ -442,7 +442,7 @@ static int launch_lat_conv(LatConvArgs& a, hipStream_t stream) {
     if (!attr_ok) return ITERMVS_ERR_LAUNCH;
     const int cus = itermvs_num_cus();
     const int grid = a.total < cus ? a.total : cus;
-    a.banded = grid % 8 == 0 && a.total >= 8 * grid ? 1 : 0;      // (few tiles: plain order keeps every workgroup busy)
+    a.banded = grid % 8 == 0 && a.total >= grid ? 1 : 0;          // (grid < 8 or ragged: plain order)
     itermvs_profile_begin(3, stream);           // bench.py's convolution roofline brackets this launch like an itermvs_conv2d one
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kLcThreads), lds, stream, a);
     itermvs_profile_end(3, stream);

@@ -378,7 +378,7 @@ extern "C" int itermvs_res_chain16(const float* y1, int64_t y1_sn, const float* 
     ITERMVS_RETURN_IF(!attr_ok, ITERMVS_ERR_LAUNCH);
     const int cus = itermvs_num_cus();
     const int grid = a.total < cus ? a.total : cus;
-    a.banded = grid % 8 == 0 && a.total >= 8 * grid ? 1 : 0;      // (few tiles: plain order keeps every workgroup busy)
+    a.banded = grid % 8 == 0 && a.total >= grid ? 1 : 0;          // (grid < 8 or ragged: plain order)
     itermvs_profile_begin(3, (hipStream_t)stream);          // bench.py's convolution roofline brackets this launch like an itermvs_conv2d one
     if (in_layout) hipLaunchKernelGGL((res_chain16_kernel<TH, TW, true>), dim3(grid), dim3(kRcThreads), G::LDS, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((res_chain16_kernel<TH, TW, false>), dim3(grid), dim3(kRcThreads), G::LDS, (hipStream_t)stream, a);
