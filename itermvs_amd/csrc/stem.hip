@@ -99,7 +99,17 @@ __global__ __launch_bounds__(kStThreads) void stem_kernel(StemArgs a, int tiles,
         compose_proj_body(comp, (int)blockIdx.x * kStThreads + (int)threadIdx.x);
         return;
     }
-    const int wg = (int)blockIdx.x - n_comp, n_wg = (int)gridDim.x - n_comp;
+    // Tile order: workgroup b runs on XCD b % 8 (round-robin dispatch); the tiles of one XCD are a contiguous run of the tile list
+    // (whole image bands), so that the image rows two vertically adjacent tiles share meet in the same 4 MB L2.  (The n_comp
+    // composing workgroups in front shift which workgroups an XCD gets, not the rule.)
+    int tile0 = (int)blockIdx.x - n_comp, tstep = (int)gridDim.x - n_comp, tend = tiles;
+    if (tstep >= 8) {
+        const int b = (int)blockIdx.x, xcd = b & 7;
+        const int first = n_comp + ((xcd - n_comp) & 7);             // the XCD's first tile workgroup
+        tile0 = (int)((int64_t)tiles * xcd / 8) + ((b - first) >> 3);
+        tend = (int)((int64_t)tiles * (xcd + 1) / 8);
+        tstep = ((int)gridDim.x - 1 - first) / 8 + 1;
+    }
 
     constexpr int kStIR = 2 * kStTH + 3, kStFR = 2 * kStTH + 1;      // image / f0 patch rows
     constexpr int kStFPL = kStFR * kStFP + 1;                        // odd plane stride (1123 / 595)
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(kStThreads) void stem_kernel(StemArgs a, int tiles,
     const int q = lane >> 4, l16 = lane & 15;
 
     StemPatch<kStTH> patch;
-    patch.fetch(a, wg, wave, lane);
+    if (tile0 < tend) patch.fetch(a, tile0, wave, lane);
 
     // the stride-2 layer's A operands and biases (registers for the whole kernel)
     float aw[36];
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(kStThreads) void stem_kernel(StemArgs a, int tiles,
     const int oplane = a.H2 * a.W2;
 
 #pragma unroll 1
-    for (int tile = wg; tile < tiles; tile += n_wg) {
+    for (int tile = tile0; tile < tend; tile += tstep) {
         int t = tile;
         const int tx = t % a.tiles_x; t /= a.tiles_x;
         const int ty = t % a.tiles_y;
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(kStThreads) void stem_kernel(StemArgs a, int tiles,
 
         patch.commit(IMG, wave, lane);
         __syncthreads();
-        if (tile + n_wg < tiles) patch.fetch(a, tile + n_wg, wave, lane);    // lands while this tile computes
+        if (tile + tstep < tend) patch.fetch(a, tile + tstep, wave, lane);    // lands while this tile computes
 
         // f0 = relu(conv0(x) + b) on the patch: work item = (row, column), a thread evaluates all 8 channels of a position,
         // two channels per packed FMA.  Items FR x 64 (wave w: rows w, w+4, ..; lane = column) and the 65th column
