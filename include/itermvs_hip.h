@@ -510,12 +510,15 @@ int itermvs_conv2d(const itermvs_conv_params* p, void* stream);
  * ------------------------------------------------------------------------------------------ */
 int itermvs_corrnet(const float* x, int64_t x_sn, const float* const* weights, const int32_t* seg_end, int32_t n_seg,
                     int32_t M, int32_t H, int32_t W, float* out, int64_t out_sn, float* out2, int64_t out2_sn, void* stream);
-/* itermvs_corrnet_bf16x3 -- the same launch with conv0 (8 -> 8 at full resolution, 40 % of CorrNet's matrix work) on
- * v_mfma_f32_16x16x32_bf16: both operands split EXACTLY into three bf16 terms, the six largest cross products accumulated in fp32
- * (error of the size of one fp32 rounding per product, like itermvs_conv2d's weight_format 3).  Packed set: 17360 floats = conv0 as
- * bf16 A operands [18 MFMAs][64 lanes][8 bf16] (4608 floats: MFMA 2v / 2v+1 = terms h / m of the window-position pair v, 12 + v =
- * [l l | h h]; lane (q, m): window position 2v + (q & 1), output row-channel m as in the fp32 form), then layers 1..5 as in
- * itermvs_corrnet (itermvs_amd.ops.pack_corrnet_weights(split3=True)). */
+/* itermvs_corrnet_bf16x3 -- the same launch with conv0, conv2 and the two transposed convolutions on v_mfma_f32_16x16x32_bf16:
+ * both operands split EXACTLY into three bf16 terms, the six largest cross products accumulated in fp32 (error of the size of one
+ * fp32 rounding per product, like itermvs_conv2d's weight_format 3); conv1 stays on the fp32 instruction (its input is kept in fp32
+ * for the skip connection and the last layer).  Packed set: 23120 floats = conv0 as bf16 A operands [18 MFMAs][64 lanes][8 bf16]
+ * (4608 floats: MFMA 2v / 2v+1 = terms h / m of the window-position pair v, 12 + v = [l l | h h]; lane (q, m): window position
+ * 2v + (q & 1), output row-channel m as in the fp32 form) | conv1 as in itermvs_corrnet (1152 floats) | conv2, conv3, conv4 in
+ * weight_format 3 = bf16 [tap 9][chunk ci/16][term h, m, l][row co][16 ci] with 32 / 16 / 16 rows (6912 + 6912 + 3456 floats; a
+ * transposed convolution as the convolution weight [co][ci][ky][kx] = w[ci][co][ky][kx]) | conv5 [ci 8][tap 9], the bias, 7 pad
+ * (itermvs_amd.ops.pack_corrnet_weights(split3=True)). */
 int itermvs_corrnet_bf16x3(const float* x, int64_t x_sn, const float* const* weights, const int32_t* seg_end, int32_t n_seg,
                            int32_t M, int32_t H, int32_t W, float* out, int64_t out_sn, float* out2, int64_t out2_sn, void* stream);
 

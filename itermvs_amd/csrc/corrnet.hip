@@ -21,6 +21,7 @@
 namespace itermvs {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
 
 constexpr int kCnTile = 32;
 #ifndef ITERMVS_CORRNET_THREADS
@@ -45,8 +46,9 @@ constexpr int kSzX = 8 * XPL, kSzC0 = 8 * C0PL, kSzC1 = 16 * C1PL, kSzC2 = 32 * 
 constexpr int kOffC0 = kSzX, kOffC1 = 0, kOffC2 = kSzC1;      // c1 / c2 reuse the x region once c0 is complete
 static_assert(kSzC1 + kSzC2 <= kSzX, "c1 + c2 must fit the x region");
 constexpr int kOffW = kSzX + kSzC0;                           // the current layer's weights
-constexpr int kSzW = 4608;
+constexpr int kSzW = 6912;                                    // (bf16x3 form: the split weights of conv2 / conv3, 27 648 B)
 constexpr int kCnLdsFloats = kOffW + kSzW;
+static_assert(kCnLdsFloats * 4 <= 160 * 1024, "LDS budget");
 // packed weight set of one CorrNet (floats), every layer in MFMA operand order [tap][k-step][q][co padded to 16 / 32]:
 // see ops.pack_corrnet_weights
 constexpr int kW0 = 0;                         // conv0, two output rows per MFMA (conv0_layer): 12 x 2 x 4 x 16
@@ -64,7 +66,24 @@ constexpr int kSplitShift = kW0Split - (kW1 - kW0);        // every later offset
 static_assert(kW0Split <= kSzW, "conv0's split weights must fit the weight buffer");
 constexpr int kXPlaneB = XS * XP * 16;                     // bytes of one bf16 plane of the x tile: [row 45][col 46][8 channels]
 static_assert(2 * kXPlaneB <= kSzX * 4 && kXPlaneB <= kSzC0 * 4, "planes h, m of x must fit the x region, plane l the c0 region");
-static_assert(kCnWeightFloats + kSplitShift == 17360, "packed set of the bf16x3 form (include/itermvs_hip.h)");
+// bf16x3 form, layers 2..4 (conv2, the two transposed convolutions): the split weights of itermvs_conv2d's weight_format 3,
+// bf16 [tap 9][chunk = ci / 16][term h, m, l][row co, padded to 16 / 32][16 ci] -- conv2 [9][1][3][32][16], conv3 [9][2][3][16][16]
+// (27 648 B each), conv4 [9][1][3][16][16] (13 824 B); conv1 stays on the fp32 instruction (its input c0 stays fp32 for the skip
+// and the last layer).  Offsets in floats:
+constexpr int kS3W1 = kW0Split;                // conv1, fp32 operand order as above
+constexpr int kS3W2 = kS3W1 + (kW2 - kW1);     // conv2 split
+constexpr int kS3W3 = kS3W2 + 6912;            // conv3 split
+constexpr int kS3W4 = kS3W3 + 6912;            // conv4 split
+constexpr int kS3W5 = kS3W4 + 3456;            // conv5 [ci 8][tap 9]
+constexpr int kS3Bias = kS3W5 + 72;
+constexpr int kS3WeightFloats = kS3Bias + 8;
+static_assert(kS3WeightFloats == 23120, "packed set of the bf16x3 form (include/itermvs_hip.h)");
+// c1 and c2 as bf16 triples (the B operands of conv2 and of the transposed convolutions) in the x region, which is free once conv0 has
+// read it: [chunk = channel / 16][term h, m, l][half = 8 channels][position][16 B], positions padded to a multiple of 16 (256 B)
+constexpr int kC1PP = (C1S * C1P + 15) / 16 * 16, kC1HalfB = kC1PP * 16, kC1PlaneB = 2 * kC1HalfB;          // 464 positions
+constexpr int kC2PP = (C2S * C2P + 15) / 16 * 16, kC2HalfB = kC2PP * 16, kC2PlaneB = 2 * kC2HalfB, kC2ChunkB = 3 * kC2PlaneB;
+constexpr int kOffC1sB = 0, kOffC2sB = 3 * kC1PlaneB;          // byte offsets inside the x region
+static_assert(kOffC2sB + 2 * kC2ChunkB <= kSzX * 4, "c1 + c2 as bf16 triples must fit the x region");
 
 struct CorrNetArgs {
     const float* x;
@@ -96,9 +115,36 @@ struct WeightStage {
 // 3x3 convolution LDS -> LDS on the matrix cores.  In: CIN planes of stride INPL, row pitch INP, whose (0,0) is tap (0,0) of
 // output (0,0) (stride S); Out: COUT planes of stride OUTPL, OUTS x OUTS positions at row pitch OUTP; Wl: [9][CIN/4][4][MB*16].  Output position (oy, ox) has image coordinates
 // (gy0 + oy, gx0 + ox) at this layer's resolution; outside [0,imgH) x [0,imgW) a zero is stored.
-template <int CIN, int COUT, int MB, int S, int INPL, int INP, int OUTS, int OUTPL, int OUTP>
+// four channels (4 qq .. 4 qq + 3 of a 16-channel chunk) of one position -> the three 8-byte entries of a split map chunk
+__device__ __forceinline__ void split_put4(char* __restrict__ chunk, int half_b, int qq, int pos, float v0, float v1, float v2, float v3) {
+    uint32_t h0, m0, l0, h1, m1, l1;
+    split_pair(v0, v1, h0, m0, l0);
+    split_pair(v2, v3, h1, m1, l1);
+    char* __restrict__ d = chunk + (qq >> 1) * half_b + pos * 16 + (qq & 1) * 8;
+    *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(d + 2 * half_b) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2*>(d + 4 * half_b) = u32x2{l0, l1};
+}
+// ... and back: h + m + l, exact (8 + 8 + 8 significant bits)
+__device__ __forceinline__ void split_get4(const char* __restrict__ chunk, int half_b, int qq, int pos, float (&v)[4]) {
+    const char* __restrict__ s = chunk + (qq >> 1) * half_b + pos * 16 + (qq & 1) * 8;
+    const u32x2 hh = *reinterpret_cast<const u32x2*>(s);
+    const u32x2 mm = *reinterpret_cast<const u32x2*>(s + 2 * half_b);
+    const u32x2 ll = *reinterpret_cast<const u32x2*>(s + 4 * half_b);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t hw = r < 2 ? hh[0] : hh[1], mw = r < 2 ? mm[0] : mm[1], lw = r < 2 ? ll[0] : ll[1];
+        const float ah = __uint_as_float((r & 1) ? (hw & 0xffff0000u) : (hw << 16));
+        const float am = __uint_as_float((r & 1) ? (mw & 0xffff0000u) : (mw << 16));
+        const float al = __uint_as_float((r & 1) ? (lw & 0xffff0000u) : (lw << 16));
+        v[r] = (ah + am) + al;
+    }
+}
+
+// SPLIT_HALF_B > 0 (16 output channels): the results go to `OutS` as bf16 triples (position oy * OUTP + ox) instead of fp32 planes
+template <int CIN, int COUT, int MB, int S, int INPL, int INP, int OUTS, int OUTPL, int OUTP, int SPLIT_HALF_B = 0>
 __device__ __forceinline__ void conv_layer(const float* __restrict__ In, float* __restrict__ Out, const float* __restrict__ Wl,
-                                           int gy0, int gx0, int imgH, int imgW, int wave, int lane) {
+                                           int gy0, int gx0, int imgH, int imgW, int wave, int lane, char* __restrict__ OutS = nullptr) {
     constexpr int KS = CIN / 4, NPOS = OUTS * OUTS, GROUPS = (NPOS + 15) / 16;
     const int q = lane >> 4, l16 = lane & 15;
     // the A operands (this lane's weight of every (tap, k-step, block)) are the same for every group: read them once
@@ -129,12 +175,138 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ In, float* 
         const int gy = gy0 + oy, gx = gx0 + ox;
         const bool inside = gy >= 0 && gy < imgH && gx >= 0 && gx < imgW;
         if (pos < NPOS) {
+            if constexpr (SPLIT_HALF_B > 0) {
+                static_assert(MB == 1 && COUT == 16, "split output: one 16-channel chunk");
+                float v[4];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+                for (int r = 0; r < 4; ++r) v[r] = inside ? fmaxf(acc[0][r], 0.0f) : 0.0f;
+                split_put4(OutS, SPLIT_HALF_B, q, oy * OUTP + ox, v[0], v[1], v[2], v[3]);
+            } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = mb * 16 + q * 4 + r;
-                    if (co < COUT) Out[co * OUTPL + oy * OUTP + ox] = inside ? fmaxf(acc[mb][r], 0.0f) : 0.0f;
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = mb * 16 + q * 4 + r;
+                        if (co < COUT) Out[co * OUTPL + oy * OUTP + ox] = inside ? fmaxf(acc[mb][r], 0.0f) : 0.0f;
+                    }
+            }
+        }
+    }
+}
+
+// ---- layers on v_mfma_f32_16x16x32_bf16 from split maps (bf16x3 arithmetic of conv_tile3.hip: K = 32 = two 16-channel terms,
+//      A1 = [wh | wh], A2 = [wm | wm], A3 = [wl | wh]; B1 = [xh | xm], B3 = [xh | xl]; acc += A3 B3 + A2 B1 + A1 B1) ----
+// a lane's B operands of one 16-channel chunk at a position, and its three A operands of (tap, chunk): Wl = bf16 [tap][chunk][3][ROWS][16]
+struct SplitLane {
+    int half, second, l16, q;
+    __device__ __forceinline__ explicit SplitLane(int lane) : half((lane >> 4) & 1), second(lane >> 5), l16(lane & 15), q(lane >> 4) {}
+    template <int HALF_B>
+    __device__ __forceinline__ void b(const char* __restrict__ chunk, int pos, bf8& b1, bf8& b3) const {
+        const char* __restrict__ p = chunk + half * HALF_B + pos * 16;
+        b1 = *reinterpret_cast<const bf8*>(p + (second ? 2 * HALF_B : 0));
+        b3 = *reinterpret_cast<const bf8*>(p + (second ? 4 * HALF_B : 0));
+    }
+    template <int ROWS>
+    __device__ __forceinline__ void a(const char* __restrict__ wtap, int row0, bf8& a1, bf8& a2, bf8& a3) const {
+        const char* __restrict__ p = wtap + (row0 + l16) * 32 + half * 16;
+        a1 = *reinterpret_cast<const bf8*>(p);
+        a2 = *reinterpret_cast<const bf8*>(p + ROWS * 32);
+        a3 = *reinterpret_cast<const bf8*>(p + (second ? 0 : 2 * ROWS * 32));
+    }
+};
+
+// conv2 (16 -> 32, stride 2, ReLU): c1 triples -> c2 triples.  Work unit = (group of 16 output positions, block of 16 output
+// channels): 14 units over the 16 waves, 27 MFMAs of 16 cycles each (the fp32 form: 7 groups x 72 MFMAs of 40 cycles on 7 waves)
+__device__ __forceinline__ void conv2_split(const char* __restrict__ In, char* __restrict__ Out, const char* __restrict__ Wl,
+                                            int gy0, int gx0, int imgH, int imgW, int wave, int lane) {
+    constexpr int NPOS = C2S * C2S, GROUPS = (NPOS + 15) / 16;
+    const SplitLane L(lane);
+    for (int u = wave; u < GROUPS * 2; u += kCnWaves) {
+        const int g = u >> 1, mb = u & 1;
+        const int pos = g * 16 + L.l16;
+        const int pc = pos < NPOS ? pos : NPOS - 1;
+        const int oy = pc / C2S, ox = pc - oy * C2S;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            bf8 a1, a2, a3, b1, b3;
+            L.a<32>(Wl + tap * (3 * 32 * 32), mb * 16, a1, a2, a3);
+            L.b<kC1HalfB>(In, (2 * oy + ky) * C1P + 2 * ox + kx, b1, b3);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b3, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc, 0, 0, 0);
+        }
+        const int gy = gy0 + oy, gx = gx0 + ox;
+        const bool inside = gy >= 0 && gy < imgH && gx >= 0 && gx < imgW;
+        if (pos < NPOS)
+            split_put4(Out + mb * kC2ChunkB, kC2HalfB, L.q, oy * C2P + ox, inside ? fmaxf(acc[0], 0.0f) : 0.0f, inside ? fmaxf(acc[1], 0.0f) : 0.0f,
+                       inside ? fmaxf(acc[2], 0.0f) : 0.0f, inside ? fmaxf(acc[3], 0.0f) : 0.0f);
+    }
+}
+
+// Transposed convolution + skip from a split map (see deconv_layer for the parity classes): NCH input chunks of 16 channels at
+// In (chunk stride IN_CHUNK_B, half stride IN_HALF_B, pitch INP); the skip tensor is updated in place -- as bf16 triples
+// (SKIP_HALF_B > 0: u1 over c1, 16 channels) or as fp32 planes (u0 over c0, COUT = 8).  Wl = bf16 [tap][chunk][3][16][16].
+template <int NCH, int IN_HALF_B, int IN_CHUNK_B, int COUT, int NB, int IO, int INP, int OO, int OUTPL, int OUTP, int SKIP_HALF_B>
+__device__ __forceinline__ void deconv_split(const char* __restrict__ In, float* __restrict__ Skip, char* __restrict__ SkipS,
+                                             const char* __restrict__ Wl, int gy0, int gx0, int imgH, int imgW, int wave, int lane) {
+    constexpr int NPOS = NB * NB, GROUPS = (NPOS + 15) / 16;
+    const SplitLane L(lane);
+    for (int g = wave; g < GROUPS; g += kCnWaves) {
+        const int pos = g * 16 + L.l16;
+        const int pc = pos < NPOS ? pos : NPOS - 1;
+        const int ba = pc / NB, bb = pc - ba * NB;
+        f32x4 acc[4];                                        // class py * 2 + px
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    bf8 b1, b3;
+                    L.b<IN_HALF_B>(In + ch * IN_CHUNK_B, (ba + IO + dy) * INP + bb + IO + dx, b1, b3);
+#pragma unroll
+                    for (int py = 0; py <= dy; ++py)
+#pragma unroll
+                        for (int px = 0; px <= dx; ++px) {
+                            const int ky = dy == 1 ? py : 2, kx = dx == 1 ? px : 2;
+                            bf8 a1, a2, a3;
+                            L.a<16>(Wl + ((ky * 3 + kx) * NCH + ch) * (3 * 16 * 32), 0, a1, a2, a3);
+                            f32x4& c = acc[py * 2 + px];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b3, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c, 0, 0, 0);
+                        }
+                }
+        if (pos < NPOS) {
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    const int o = 2 * ba + py, p = 2 * bb + px;
+                    const int gy = gy0 + o, gx = gx0 + p;
+                    const bool inside = gy >= 0 && gy < imgH && gx >= 0 && gx < imgW;
+                    if constexpr (SKIP_HALF_B > 0) {
+                        static_assert(COUT == 16, "split skip: one 16-channel chunk");
+                        const int sp = (o + OO) * OUTP + p + OO;
+                        float v[4];
+                        split_get4(SkipS, SKIP_HALF_B, L.q, sp, v);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = inside ? v[r] + acc[py * 2 + px][r] : 0.0f;
+                        split_put4(SkipS, SKIP_HALF_B, L.q, sp, v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int co = L.q * 4 + r;
+                            if (co < COUT) {
+                                float* __restrict__ d = Skip + co * OUTPL + (o + OO) * OUTP + p + OO;
+                                *d = inside ? *d + acc[py * 2 + px][r] : 0.0f;
+                            }
+                        }
+                    }
                 }
         }
     }
@@ -325,7 +497,6 @@ __device__ __forceinline__ void deconv_layer(const float* __restrict__ In, float
 
 template <bool S3>
 __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a) {
-    constexpr int SH = S3 ? kSplitShift : 0;          // offset of layers 1..5 in the packed weight set
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* __restrict__ X = lds;
     float* __restrict__ C0 = lds + kOffC0;
@@ -368,7 +539,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
         __syncthreads();
         Conv0Split<XS, XP, C0S, C0PL, C0P> c0;
         WeightStage<kW2 - kW1> nw;
-        nw.fetch(wt + kW1 + SH, tid);
+        nw.fetch(wt + kS3W1, tid);
         c0.run(Xb, Lb, reinterpret_cast<const char*>(WL), wave, lane);
         __syncthreads();                                   // every wave is done with the l plane (c0 region) and conv0's weights
         c0.store(C0, Y0 - 7, X0 - 7, H, W, wave, lane);
@@ -448,39 +619,75 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
         }
         __syncthreads();
     }
-    {   // c1 = relu(conv s2 (c0)): 21 x 21 at half resolution (over the x region)
-        WeightStage<kW3 - kW2> nw;
-        nw.fetch(wt + kW2 + SH, tid);
-        conv_layer<8, 16, 1, 2, C0PL, C0P, C1S, C1PL, C1P>(C0, C1, WL, (Y0 >> 1) - 3, (X0 >> 1) - 3, H2, W2, wave, lane);
+    if constexpr (S3) {
+        // ---- conv2 and the two transposed convolutions on the bf16 matrix instruction (the four fp32 layers were 31.5 k of the
+        //      launch's 52 k cycles, profiles/r06/r06k_*): c1 and c2 live as bf16 triples in the x region, c0 / u0 stay fp32 ----
+        char* __restrict__ C1s = reinterpret_cast<char*>(X) + kOffC1sB;
+        char* __restrict__ C2s = reinterpret_cast<char*>(X) + kOffC2sB;
+        const char* __restrict__ WLb = reinterpret_cast<const char*>(WL);
+        {   // c1 = relu(conv s2 (c0)): 21 x 21 at half resolution, fp32 instruction (c0 is fp32), stored as triples
+            WeightStage<6912> nw;
+            nw.fetch(wt + kS3W2, tid);
+            conv_layer<8, 16, 1, 2, C0PL, C0P, C1S, C1PL, C1P, kC1HalfB>(C0, nullptr, WL, (Y0 >> 1) - 3, (X0 >> 1) - 3, H2, W2, wave, lane, C1s);
+            __syncthreads();
+            nw.commit(WL, tid);
+        }
         __syncthreads();
-        nw.commit(WL, tid);
-    }
-    __syncthreads();
-    {   // c2 = relu(conv s2 (c1)): 10 x 10 at quarter resolution
-        WeightStage<kW4 - kW3> nw;
-        nw.fetch(wt + kW3 + SH, tid);
-        conv_layer<16, 32, 2, 2, C1PL, C1P, C2S, C2PL, C2P>(C1, C2, WL, (Y0 >> 2) - 1, (X0 >> 2) - 1, H4, W4, wave, lane);
+        {   // c2 = relu(conv s2 (c1)): 10 x 10 at quarter resolution
+            WeightStage<6912> nw;
+            nw.fetch(wt + kS3W3, tid);
+            conv2_split(C1s, C2s, WLb, (Y0 >> 2) - 1, (X0 >> 2) - 1, H4, W4, wave, lane);
+            __syncthreads();
+            nw.commit(WL, tid);
+        }
         __syncthreads();
-        nw.commit(WL, tid);
-    }
-    __syncthreads();
-    {   // u1 = c1 + deconv(c2): 18 x 18 = c1 rows / columns 2 .. 19, in place
-        WeightStage<kW5 - kW4> nw;
-        nw.fetch(wt + kW4 + SH, tid);
-        deconv_layer<32, 16, 9, 0, C2PL, C2P, 2, C1PL, C1P>(C2, C1, WL, (Y0 >> 1) - 1, (X0 >> 1) - 1, H2, W2, wave, lane);
+        {   // u1 = c1 + deconv(c2): 18 x 18 = c1 rows / columns 2 .. 19, in place (triples)
+            WeightStage<3456> nw;
+            nw.fetch(wt + kS3W4, tid);
+            deconv_split<2, kC2HalfB, kC2ChunkB, 16, 9, 0, C2P, 2, 0, C1P, kC1HalfB>(C2s, nullptr, C1s, WLb, (Y0 >> 1) - 1, (X0 >> 1) - 1, H2, W2, wave, lane);
+            __syncthreads();
+            nw.commit(WL, tid);
+        }
         __syncthreads();
-        nw.commit(WL, tid);
+        // u0 = c0 + deconv(u1): 34 x 34 = c0 rows / columns 6 .. 39, in place (fp32 planes)
+        deconv_split<1, kC1HalfB, 0, 8, 17, 2, C1P, 6, C0PL, C0P, 0>(C1s, C0, nullptr, WLb, Y0 - 1, X0 - 1, H, W, wave, lane);
+        __syncthreads();
+    } else {
+        {   // c1 = relu(conv s2 (c0)): 21 x 21 at half resolution (over the x region)
+            WeightStage<kW3 - kW2> nw;
+            nw.fetch(wt + kW2, tid);
+            conv_layer<8, 16, 1, 2, C0PL, C0P, C1S, C1PL, C1P>(C0, C1, WL, (Y0 >> 1) - 3, (X0 >> 1) - 3, H2, W2, wave, lane);
+            __syncthreads();
+            nw.commit(WL, tid);
+        }
+        __syncthreads();
+        {   // c2 = relu(conv s2 (c1)): 10 x 10 at quarter resolution
+            WeightStage<kW4 - kW3> nw;
+            nw.fetch(wt + kW3, tid);
+            conv_layer<16, 32, 2, 2, C1PL, C1P, C2S, C2PL, C2P>(C1, C2, WL, (Y0 >> 2) - 1, (X0 >> 2) - 1, H4, W4, wave, lane);
+            __syncthreads();
+            nw.commit(WL, tid);
+        }
+        __syncthreads();
+        {   // u1 = c1 + deconv(c2): 18 x 18 = c1 rows / columns 2 .. 19, in place
+            WeightStage<kW5 - kW4> nw;
+            nw.fetch(wt + kW4, tid);
+            deconv_layer<32, 16, 9, 0, C2PL, C2P, 2, C1PL, C1P>(C2, C1, WL, (Y0 >> 1) - 1, (X0 >> 1) - 1, H2, W2, wave, lane);
+            __syncthreads();
+            nw.commit(WL, tid);
+        }
+        __syncthreads();
+        // u0 = c0 + deconv(u1): 34 x 34 = c0 rows / columns 6 .. 39, in place
+        deconv_layer<16, 8, 17, 2, C1PL, C1P, 6, C0PL, C0P>(C1, C0, WL, Y0 - 1, X0 - 1, H, W, wave, lane);
+        __syncthreads();
+
     }
-    __syncthreads();
-    // u0 = c0 + deconv(u1): 34 x 34 = c0 rows / columns 6 .. 39, in place
-    deconv_layer<16, 8, 17, 2, C1PL, C1P, 6, C0PL, C0P>(C1, C0, WL, Y0 - 1, X0 - 1, H, W, wave, lane);
-    __syncthreads();
 
     // ---- y = conv(u0, 8 -> 1) + bias on the vector ALUs: 32 x 32, a thread owns 2 neighbouring pixels; the 72 weights are
     //      wave-uniform (scalar loads) ----
     if (tid < 512) {
         const int oy = tid >> 4, ox = (tid & 15) * 2;
-        float y0 = wt[kWBias + SH], y1 = y0;
+        float y0 = wt[S3 ? kS3Bias : kWBias], y1 = y0;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
@@ -489,7 +696,7 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
                 const float in[4] = {row[0], row[1], row[2], row[3]};
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const float wv = wt[kW5 + SH + ci * 9 + ky * 3 + kx];
+                    const float wv = wt[(S3 ? kS3W5 : kW5) + ci * 9 + ky * 3 + kx];
                     y0 = fmaf(wv, in[kx], y0);
                     y1 = fmaf(wv, in[kx + 1], y1);
                 }

@@ -1143,7 +1143,7 @@ def fuse_depth(depth_ref: Tensor, conf_ref: Tensor, depth_src: Sequence[Tensor],
 
 
 CORRNET_WEIGHT_FLOATS = 14288
-CORRNET_WEIGHT_FLOATS_SPLIT3 = 14288 - 1536 + 4608          # conv0 as bf16x3 operands (itermvs_corrnet_bf16x3)
+CORRNET_WEIGHT_FLOATS_SPLIT3 = 23120     # bf16x3 form: conv0 + conv2 + the two transposed convolutions as split bf16 operands
 
 
 def _mfma_operand_order(w_tap_ci_co: Tensor, co_pad: int) -> Tensor:
@@ -1158,7 +1158,9 @@ def pack_corrnet_weights(w: Dict[str, Tensor], prefix: str, split3: bool = False
     """the six layers of one CorrNet (state-dict names ``prefix`` + conv0.conv.weight ... conv5.bias) in the layout of
     itermvs_corrnet (include/itermvs_hip.h): the five matrix-core layers in operand order [tap][k-step][q][co], conv5 as
     [ci][tap], the bias, padding.  ``split3``: the set of itermvs_corrnet_bf16x3 -- conv0 as the bf16 A operands of its 18
-    v_mfma_f32_16x16x32_bf16 ([mfma][q][row m][8 channels], three-term split of the fp32 weights), layers 1..5 unchanged."""
+    v_mfma_f32_16x16x32_bf16 ([mfma][q][row m][8 channels], three-term split of the fp32 weights), conv1 unchanged (fp32), conv2 and
+    the two transposed convolutions in itermvs_conv2d's weight_format 3 (bf16 [tap][chunk][h, m, l][row co][16 ci]; a transposed
+    convolution as the convolution weight [co][ci][ky][kx] = w[ci][co][ky][kx]), conv5 and the bias unchanged."""
     conv = lambda name, pad: _mfma_operand_order(w[prefix + name].float().permute(2, 3, 1, 0).reshape(9, w[prefix + name].shape[1], -1), pad)
     # ConvTranspose2d weights are [ci, co, ky, kx]
     dconv = lambda name, pad: _mfma_operand_order(w[prefix + name].float().permute(2, 3, 0, 1).reshape(9, w[prefix + name].shape[0], -1), pad)
@@ -1181,8 +1183,14 @@ def pack_corrnet_weights(w: Dict[str, Tensor], prefix: str, split3: bool = False
         first = torch.stack(ops_a).contiguous().view(torch.int16).reshape(-1).view(torch.float32)              # 18 x 64 x 8 bf16 = 4608 floats
     else:
         first = _mfma_operand_order(two.reshape(12, 8, 16), 16)
-    parts = [first, conv("conv1.conv.weight", 16), conv("conv2.conv.weight", 32),
-             dconv("conv3.weight", 16), dconv("conv4.weight", 16),
+    if split3:
+        as_floats = lambda wt: MfmaWeight(wt, split3=True).tile3.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
+        mid = [as_floats(w[prefix + "conv2.conv.weight"].float()),                       # [9][1][3][32][16] bf16 = 6912 floats
+               as_floats(w[prefix + "conv3.weight"].float().permute(1, 0, 2, 3)),          # [9][2][3][16][16]
+               as_floats(w[prefix + "conv4.weight"].float().permute(1, 0, 2, 3))]          # [9][1][3][16 (8 used)][16] = 3456 floats
+    else:
+        mid = [conv("conv2.conv.weight", 32), dconv("conv3.weight", 16), dconv("conv4.weight", 16)]
+    parts = [first, conv("conv1.conv.weight", 16)] + mid + [
              w[prefix + "conv5.weight"].float().permute(1, 2, 3, 0).reshape(-1), w[prefix + "conv5.bias"].float().reshape(-1)]
     flat = torch.cat(parts + [torch.zeros(7, device=parts[0].device)])
     assert flat.numel() == (CORRNET_WEIGHT_FLOATS_SPLIT3 if split3 else CORRNET_WEIGHT_FLOATS)
