@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define ITERMVS_ABI_VERSION 12
+#define ITERMVS_ABI_VERSION 13
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -194,14 +194,15 @@ int itermvs_corr_iter(const itermvs_corr_iter_params* p, void* stream);
  * ------------------------------------------------------------------------------------------ */
 typedef struct itermvs_corr_init_params {
     int32_t B, S, H, W, N;                     /* sample grid = level-3 size; N = 32      */
-    int32_t _pad0;
+    int32_t out_layout;                        /* 0 = out [B,S,N,8,H,W]; 1 = groups last [B,S,N,H,W,8] (out 16-byte aligned): the layout
+                                                * itermvs_conv2d (in_layout 1) stages with two 16-byte loads per pixel.  The backward takes 0 */
     itermvs_level_src src;                     /* level-3 source features, channels-last  */
     itermvs_fmap ref;                          /* level-3 reference features (any strides) */
     const float* proj;                         /* [B,S,12]                                */
     const float* depth;                        /* [B,N,H,W] or NULL (generate uniform inverse depth) */
     const float* inv_depth_min;                /* device [B] */
     const float* inv_depth_max;                /* device [B] */
-    float* out;                                /* [B,S,N,8,H,W] */
+    float* out;                                /* [B,S,N,8,H,W] (see out_layout) */
 } itermvs_corr_init_params;
 
 int itermvs_corr_init(const itermvs_corr_init_params* p, void* stream);
@@ -267,9 +268,10 @@ int itermvs_view_aggregate(const float* corr, const float* w, int32_t S, int32_t
 /* itermvs_view_aggregate_up -- the same, and in the SAME launch (extra blocks: two independent pieces of work that only
  * read w) the x2 bilinear up-sampling of the view weights the iterations use (models/itermvs.py:56-57,71):
  *   w [B,S,H3,W3] -> w_up [B,S,2*H3,2*W3], or, with w_up_interleaved != 0, the same values stored [B,2*H3,2*W3,S] (the
- *   layout itermvs_corr_iter reads fastest: view_w_ss = 1, view_w_sp = S). */
-int itermvs_view_aggregate_up(const float* corr, const float* w, int32_t S, int32_t B, int32_t N, int32_t H3, int32_t W3,
-                              float* out, float* w_up, int32_t w_up_interleaved, void* stream);
+ *   layout itermvs_corr_iter reads fastest: view_w_ss = 1, view_w_sp = S).
+ *   corr_layout: 0 = corr [B,S,N,8,P]; 1 = groups last [B,S,N,P,8] (itermvs_corr_init's out_layout 1; 16-byte aligned). */
+int itermvs_view_aggregate_up(const float* corr, int32_t corr_layout, const float* w, int32_t S, int32_t B, int32_t N, int32_t H3,
+                              int32_t W3, float* out, float* w_up, int32_t w_up_interleaved, void* stream);
 
 /* itermvs_softmax_max -- models/itermvs.py:347-348 (PixelViewWeight tail)
  *   out[m,p] = max_n softmax_n(x[m,n,p]);  x [M,N,P] contiguous, out [M,P]. */
@@ -489,6 +491,9 @@ typedef struct itermvs_conv_params {
     int32_t out_layout;
     int32_t split_cout;
     int32_t act_b;
+    int32_t in_layout;                         /* 0 = `in` [N,Cin,Hin,Win] planes; 1 = channels last [N,Hin,Win,8] -- only the 3x3 layers with
+                                                * exactly 8 input channels in weight_format 3 (stride 1, no dilation: PixelViewWeight's layer
+                                                * reading itermvs_corr_init's out_layout 1); `in` 16-byte aligned, in_sn a multiple of 4 */
     float* out_b;
     int64_t out_b_sn;
 } itermvs_conv_params;

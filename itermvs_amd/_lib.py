@@ -14,7 +14,7 @@ MAX_SRC = 16
 MAX_HYP = 8
 GROUPS = 8
 F32, F16, BF16 = 0, 1, 2      # itermvs_dtype: storage type of feature maps
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitermvs_hip.so")
@@ -50,7 +50,7 @@ class CorrIterParams(C.Structure):
 class CorrInitParams(C.Structure):
     """itermvs_corr_init_params"""
     _fields_ = [("B", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("N", C.c_int32),
-                ("_pad0", C.c_int32),
+                ("out_layout", C.c_int32),
                 ("src", LevelSrc), ("ref", FMap),
                 ("proj", C.c_void_p), ("depth", C.c_void_p),
                 ("inv_depth_min", C.c_void_p), ("inv_depth_max", C.c_void_p), ("out", C.c_void_p)]
@@ -75,7 +75,7 @@ class ConvParams(C.Structure):
                 ("N", C.c_int32), ("Cin", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cout", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dilation", C.c_int32),
                 ("transposed", C.c_int32), ("act", C.c_int32), ("weight_format", C.c_int32), ("add_mode", C.c_int32), ("out_layout", C.c_int32),
-                ("split_cout", C.c_int32), ("act_b", C.c_int32), ("out_b", C.c_void_p), ("out_b_sn", C.c_int64)]
+                ("split_cout", C.c_int32), ("act_b", C.c_int32), ("in_layout", C.c_int32), ("out_b", C.c_void_p), ("out_b_sn", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/itermvs_hip.h declares
@@ -90,7 +90,7 @@ PROTOTYPES = {
     "itermvs_ref_quarter": (C.c_int, [C.POINTER(FMap)] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "itermvs_ref_quarter_compose": (C.c_int, [C.POINTER(FMap)] * 3 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "itermvs_view_aggregate_up": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+    "itermvs_view_aggregate_up": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "itermvs_final_upsample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,

@@ -151,6 +151,11 @@ static int conv2d_impl(const itermvs_conv_params* p, void* stream) {
     ITERMVS_RETURN_IF(p->act >= 2 && p->add, ITERMVS_ERR_DIMS);   // residual add only with none / relu
     ITERMVS_RETURN_IF(p->add_mode < 0 || p->add_mode > 1, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(p->out_layout < 0 || p->out_layout > 3, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(p->in_layout != 0 && p->in_layout != 1, ITERMVS_ERR_LAYOUT);
+    // channels-last input: the 8-channel tap-pair form of the bf16x3 kernel only (conv_tile3.hip)
+    ITERMVS_RETURN_IF(p->in_layout == 1 && (p->weight_format != 3 || p->ksize != 3 || p->Cin != 8 || p->stride != 1 || p->dilation != 1 || p->transposed),
+                      ITERMVS_ERR_LAYOUT);
+    ITERMVS_RETURN_IF(p->in_layout == 1 && (((uintptr_t)p->in) % 16 || p->in_sn % 4), ITERMVS_ERR_ALIGN);
     if (p->split_cout != 0) {
         ITERMVS_RETURN_IF((p->weight_format != 2 && p->weight_format != 3) || p->transposed || p->out_layout != 0 || p->add || p->out2, ITERMVS_ERR_DIMS);
         ITERMVS_RETURN_IF(p->split_cout < 16 || p->split_cout >= p->Cout || (p->split_cout & 15), ITERMVS_ERR_DIMS);

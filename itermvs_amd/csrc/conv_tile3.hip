@@ -62,8 +62,12 @@ struct Tile3Geom {
 #define ITERMVS_TILE3_DBUF 1
 #endif
 
-template <int MB, int STRIDE, int DIL, int TH, int TWT, int CPS, int PAIR = 0>
+// INCL (PAIR form, exactly 8 input channels): the input is channels last, [N][H][W][8] -- a staging item (the 8 channels of a pixel)
+// is two 16-byte loads instead of eight dword loads.  At 64 wave-level loads per tile and ~64 cycles of the CU's address path each,
+// the dword form's staging alone was 21 of the 24 us of PixelViewWeight's 3x3 layer (3 072 tiles on 512 workgroups).
+template <int MB, int STRIDE, int DIL, int TH, int TWT, int CPS, int PAIR = 0, int INCL = 0>
 __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
+    static_assert(!INCL || PAIR, "channels-last input: tap-pair form only");
     using G = Tile3Geom<STRIDE, DIL, TH, TWT>;
     constexpr int NB = G::NB;
     constexpr int TAPS = PAIR ? 5 : 9;               // K-steps per chunk: taps, or tap pairs
@@ -132,7 +136,7 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
         const int y = px / G::IN_W, x = px - y * G::IN_W;
         const bool live = item < NLIVE;
         rel[j] = live ? (y << 12) | x : -1;
-        reloff[j] = live ? ((uint32_t)(hf * 8) * plane + (uint32_t)(y * a.Win + x)) * 4u : kTileOob;
+        reloff[j] = !live ? kTileOob : INCL ? (uint32_t)(y * a.Win + x) * 32u : ((uint32_t)(hf * 8) * plane + (uint32_t)(y * a.Win + x)) * 4u;
         loff[j] = hf * PLB + px * 16;
     }
     uint32_t goff[NIT];
@@ -140,12 +144,13 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
     auto setup = [&](const Work& k) {
         ir = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (int64_t)k.n * a.in_sn), 0, (int)(a.Cin * plane * 4u), 0x00020000);
         const int iy0 = k.oy0 * STRIDE - a.pad, ix0 = k.ox0 * STRIDE - a.pad;
+        constexpr uint32_t kPxB = INCL ? 32u : 4u;      // bytes per pixel step
         if (iy0 >= 0 && ix0 >= 0 && iy0 + G::IN_H <= a.Hin && ix0 + G::IN_W <= a.Win) {
-            const uint32_t base = (uint32_t)(iy0 * a.Win + ix0) * 4u;
+            const uint32_t base = (uint32_t)(iy0 * a.Win + ix0) * kPxB;
 #pragma unroll
             for (int j = 0; j < NIT; ++j) goff[j] = reloff[j] + base;
         } else {
-            const int base = (iy0 * a.Win + ix0) * 4;
+            const int base = (iy0 * a.Win + ix0) * (int)kPxB;
 #pragma unroll
             for (int j = 0; j < NIT; ++j) {
                 const int gy = iy0 + (rel[j] >> 12), gx = ix0 + (rel[j] & 0xfff);
@@ -156,15 +161,22 @@ __global__ void __launch_bounds__(256) conv_tile3_kernel(const TileArgs a) {
     };
     float stage[CPS][NIT][8];
     const uint32_t chunk_b = 16u * plane * 4u;       // bytes between chunks in the input planes
-    constexpr int kLoads = CPS * NIT * 8;
+    constexpr int kLoads = INCL ? NIT * 2 : CPS * NIT * 8;
     constexpr int kParts = TAPS * CPS;
     auto fetch_part = [&](uint32_t soff, int part) {
 #pragma unroll
         for (int e = 0; e < kLoads; ++e)
             if (e * kParts / kLoads == part) {
-                const int c = e / (NIT * 8), j = (e / 8) % NIT, k = e % 8;
-                stage[c][j][k] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(ir, goff[j], soff + c * chunk_b + k * plane * 4u, 0));
+                if constexpr (INCL) {
+                    const int j = e / 2, hl = e % 2;
+                    const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ir, goff[j], soff + hl * 16u, 0));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) stage[0][j][hl * 4 + k] = __uint_as_float(v[k]);
+                } else {
+                    const int c = e / (NIT * 8), j = (e / 8) % NIT, k = e % 8;
+                    stage[c][j][k] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(ir, goff[j], soff + c * chunk_b + k * plane * 4u, 0));
+                }
             }
     };
     auto fetch = [&](uint32_t soff) {
@@ -344,11 +356,11 @@ static constexpr int tile3_lds_bytes(int nchunk, int taps = 9) {
 }
 
 // PAIR form: one instantiation per channel blocking (8 x 32 tiles, one chunk)
-template <int MB>
+template <int MB, int INCL = 0>
 static int launch_tile3_pair(TileArgs& a, int mt, hipStream_t stream) {
     constexpr int TH = 8, TWT = 2, TW = 16 * TWT;
     const int lds = tile3_lds_bytes<MB, 1, 1, TH, TWT, 1>(1, 5);
-    auto kern = conv_tile3_kernel<MB, 1, 1, TH, TWT, 1, 1>;
+    auto kern = conv_tile3_kernel<MB, 1, 1, TH, TWT, 1, 1, INCL>;
     a.tiles_x = (a.Wout + TW - 1) / TW;
     a.tiles_y = (a.Hout + TH - 1) / TH;
     a.ncb = mt / MB;
@@ -437,6 +449,7 @@ using namespace itermvs;
 // called from itermvs_conv2d (conv.hip) when weight_format == 3; returns 1 when the shape is not covered
 int itermvs_conv2d_tile3(const itermvs_conv_params* p, int hout, int wout, hipStream_t stream) {
     if (p->ksize != 3 || p->Cin <= 4) return 1;
+    if (p->in_layout == 1 && !(p->Cin == 8 && p->stride == 1 && p->dilation == 1)) return 1;      // channels-last input: the tap-pair form only
     if (p->Cin <= 8 && !(p->stride == 1 && p->dilation == 1)) return 1;      // the tap-pair form: stride 1, no dilation
     const bool s1d1 = p->stride == 1 && p->dilation == 1, s2d1 = p->stride == 2 && p->dilation == 1;
     const bool s1d2 = p->stride == 1 && p->dilation == 2;
@@ -477,7 +490,11 @@ int itermvs_conv2d_tile3(const itermvs_conv_params* p, int hout, int wout, hipSt
         if (p->split_cout) return 1;
         const bool dotp = p->act == 6 || p->act == 7;
         int rcp = 1;
-        if (mt == 1) rcp = launch_tile3_pair<1>(a, mt, stream);
+        if (p->in_layout == 1) {            // channels-last input: exactly 8 channels, 16-byte aligned pixels (checked in itermvs_conv2d)
+            if (mt == 1) rcp = launch_tile3_pair<1, 1>(a, mt, stream);
+            else if (mt == 2 && dotp) rcp = launch_tile3_pair<2, 1>(a, mt, stream);
+            else if (!dotp) rcp = launch_tile3_pair<1, 1>(a, mt, stream);
+        } else if (mt == 1) rcp = launch_tile3_pair<1>(a, mt, stream);
         else if (mt == 2 && dotp) rcp = launch_tile3_pair<2>(a, mt, stream);
         else if (!dotp) rcp = launch_tile3_pair<1>(a, mt, stream);
         if (rcp != 0) return 1;

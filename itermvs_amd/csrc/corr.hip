@@ -172,6 +172,7 @@ struct InitArgs {
     const float* inv_max;
     float* out;
     int B, S, H, W, N, C, H1, W1, NB;  // NB = hypotheses per block
+    int out_cl;                        // out as [B,S,N,H,W,8] (groups last) instead of [B,S,N,8,H,W]
 };
 
 constexpr int kInitNB = 8;  // hypotheses per block
@@ -280,6 +281,20 @@ __device__ __forceinline__ void corr_init_body(const InitArgs& a, float* __restr
     __syncthreads();
     const int rows = nb * ITERMVS_GROUPS;
     float* o = a.out + (((size_t)b * a.S + s) * a.N + n0) * ITERMVS_GROUPS * P;
+    if (a.out_cl) {
+        // groups-last output [B,S,N,H,W,8] (what itermvs_conv2d's in_layout 1 stages with two 16-byte loads per pixel): item =
+        // (hypothesis, pixel, half of the 8 groups) = one 16-byte store; a tile row of 16 pixels is one 512-byte run
+        for (int idx = threadIdx.x; idx < nb * TILE * 2; idx += kThreads) {
+            const int n = idx / (TILE * 2), r = idx - n * (TILE * 2);
+            const int px = r >> 1, hf = r & 1;
+            const int x = x0 + (px & (TW - 1)), y = y0 + px / TW;
+            if (x < a.W && y < a.H) {
+                const float* __restrict__ l = lds + (n * ITERMVS_GROUPS + hf * 4) * LS + px;
+                *reinterpret_cast<float4*>(o + ((size_t)n * P + (size_t)y * a.W + x) * ITERMVS_GROUPS + hf * 4) = make_float4(l[0], l[LS], l[2 * LS], l[3 * LS]);
+            }
+        }
+        return;
+    }
     if ((a.W & 3) == 0 && ((uintptr_t)a.out & 15) == 0) {      // 16-byte stores (see corr_iter_level)
         for (int idx = threadIdx.x; idx < rows * (TILE / 4); idx += kThreads) {
             const int row = idx / (TILE / 4), px = (idx - row * (TILE / 4)) * 4;
@@ -319,12 +334,36 @@ __global__ void __launch_bounds__(kThreads) corr_init_kernel(const InitArgs a) {
 // iterations (itermvs.py:56-57,71): both only read `w`, one launch instead of two.
 __global__ void view_aggregate_kernel(const float* __restrict__ corr, const float* __restrict__ w, int S, int B, int NG,
                                       int P, float* __restrict__ out, int n_agg, int H3, int W3, float* __restrict__ w_up, int vec4,
-                                      int up_interleaved) {
+                                      int up_interleaved, int corr_cl) {
     if ((int)blockIdx.x >= n_agg) {
         bilinear_up_body(w, B * S, H3, W3, 2, 0, w_up, (int64_t)(blockIdx.x - n_agg) * blockDim.x + threadIdx.x, up_interleaved ? S : 0);
         return;
     }
     const int64_t per = (int64_t)NG * P;
+    if (corr_cl) {
+        // corr stored groups last, [B,S,N,P,8] (itermvs_corr_init's out_layout 1): a thread owns one (hypothesis, pixel) and its 8
+        // groups -- two 16-byte loads per view; out stays [B,N,8,P] (lanes = consecutive pixels: every store instruction one run).
+        // The same per-element arithmetic as the forms below.
+        const int N = NG / ITERMVS_GROUPS;
+        const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (t >= (int64_t)B * N * P) return;
+        const int p = (int)(t % P);
+        const int bn = (int)(t / P), b = bn / N, n = bn - b * N;
+        float acc[ITERMVS_GROUPS], wsum = 1e-5f;
+#pragma unroll
+        for (int g = 0; g < ITERMVS_GROUPS; ++g) acc[g] = 0.0f;
+        for (int s = 0; s < S; ++s) {
+            const float ws = w[((size_t)b * S + s) * P + p];
+            const float4* __restrict__ c = reinterpret_cast<const float4*>(corr + ((((size_t)b * S + s) * N + n) * P + p) * ITERMVS_GROUPS);
+            const float4 c0 = c[0], c1 = c[1];
+            acc[0] = acc[0] + c0.x * ws; acc[1] = acc[1] + c0.y * ws; acc[2] = acc[2] + c0.z * ws; acc[3] = acc[3] + c0.w * ws;
+            acc[4] = acc[4] + c1.x * ws; acc[5] = acc[5] + c1.y * ws; acc[6] = acc[6] + c1.z * ws; acc[7] = acc[7] + c1.w * ws;
+            wsum = wsum + ws;
+        }
+#pragma unroll
+        for (int g = 0; g < ITERMVS_GROUPS; ++g) out[((size_t)b * NG + (size_t)n * ITERMVS_GROUPS + g) * P + p] = acc[g] / wsum;
+        return;
+    }
     if (vec4) {                    // four consecutive pixels per thread: 16-byte loads and stores (same arithmetic per element)
         const int64_t t4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         const int64_t t = t4 * 4;
@@ -630,6 +669,9 @@ extern "C" int itermvs_corr_init(const itermvs_corr_init_params* p, void* stream
     a.inv_min = p->inv_depth_min; a.inv_max = p->inv_depth_max; a.out = p->out;
     a.B = p->B; a.S = p->S; a.H = p->H; a.W = p->W; a.N = p->N;
     a.C = p->src.C; a.H1 = p->src.H; a.W1 = p->src.W; a.NB = kInitNB;
+    ITERMVS_RETURN_IF(p->out_layout != 0 && p->out_layout != 1, ITERMVS_ERR_LAYOUT);
+    ITERMVS_RETURN_IF(p->out_layout == 1 && ((uintptr_t)p->out) % 16, ITERMVS_ERR_ALIGN);
+    a.out_cl = p->out_layout;
     constexpr int TILE = 32;
     const int nblocks = (p->N + kInitNB - 1) / kInitNB;
     itermvs_profile_begin(2, (hipStream_t)stream);
@@ -674,20 +716,23 @@ extern "C" int itermvs_view_aggregate(const float* corr, const float* w, int32_t
     const int64_t total = ((int64_t)B * N * ITERMVS_GROUPS * P) / (vec4 ? 4 : 1);
     const int na = (int)((total + 255) / 256);
     hipLaunchKernelGGL(view_aggregate_kernel, dim3((unsigned)na), dim3(256), 0, (hipStream_t)stream,
-                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, 0, 0, (float*)nullptr, vec4, 0);
+                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, 0, 0, (float*)nullptr, vec4, 0, 0);
     return itermvs_launch_status();
 }
 
-extern "C" int itermvs_view_aggregate_up(const float* corr, const float* w, int32_t S, int32_t B, int32_t N, int32_t H3, int32_t W3,
-                                         float* out, float* w_up, int32_t w_up_interleaved, void* stream) {
+extern "C" int itermvs_view_aggregate_up(const float* corr, int32_t corr_layout, const float* w, int32_t S, int32_t B, int32_t N, int32_t H3,
+                                         int32_t W3, float* out, float* w_up, int32_t w_up_interleaved, void* stream) {
     ITERMVS_RETURN_IF(!corr || !w || !out || !w_up, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(S < 1 || B < 1 || N < 1 || H3 < 1 || W3 < 1, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF(corr_layout != 0 && corr_layout != 1, ITERMVS_ERR_LAYOUT);
+    ITERMVS_RETURN_IF(corr_layout == 1 && ((uintptr_t)corr) % 16, ITERMVS_ERR_ALIGN);
     const int P = H3 * W3;
     const int vec4 = (P & 3) == 0 && ((((uintptr_t)corr) | ((uintptr_t)w) | ((uintptr_t)out)) & 15) == 0;
-    const int na = (int)(((int64_t)B * N * ITERMVS_GROUPS * P / (vec4 ? 4 : 1) + 255) / 256);
+    const int na = corr_layout == 1 ? (int)(((int64_t)B * N * P + 255) / 256)
+                                    : (int)(((int64_t)B * N * ITERMVS_GROUPS * P / (vec4 ? 4 : 1) + 255) / 256);
     const int nu = (int)(((int64_t)B * S * P * 4 + 255) / 256);
     hipLaunchKernelGGL(view_aggregate_kernel, dim3((unsigned)(na + nu)), dim3(256), 0, (hipStream_t)stream,
-                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, H3, W3, w_up, vec4, w_up_interleaved ? 1 : 0);
+                       corr, w, S, B, N * ITERMVS_GROUPS, P, out, na, H3, W3, w_up, vec4, w_up_interleaved ? 1 : 0, corr_layout);
     return itermvs_launch_status();
 }
 

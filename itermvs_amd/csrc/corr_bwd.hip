@@ -505,6 +505,7 @@ extern "C" int itermvs_corr_iter_backward(const itermvs_corr_iter_params* p, con
 
 extern "C" int itermvs_corr_init_backward(const itermvs_corr_init_params* p, const float* grad_out, float* const* grad_src,
                                           float* grad_ref, void* stream) {
+    ITERMVS_RETURN_IF(p && p->out_layout != 0, ITERMVS_ERR_LAYOUT);      // grad_out is [B,S,N,8,H,W]
     ITERMVS_RETURN_IF(!p || !grad_out || !grad_src || !grad_ref, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(p->B < 1 || p->H < 1 || p->W < 1 || p->N < 2 || p->N > 32, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(p->S < 1 || p->S > ITERMVS_MAX_SRC, ITERMVS_ERR_VIEWS);

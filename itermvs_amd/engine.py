@@ -331,11 +331,13 @@ class InferenceEngine:
         b, _, h3, w3 = ref3.shape
         s = len(src3)
         w = self.w
-        corr_v = ops.corr_init(src3, ref3, proj3, inv_min, inv_max, INIT_SAMPLES, timed=self.profile_init)   # [B,S,32,8,h3,w3]
+        # [B,S,32,8,h3,w3]; bf16x3 arithmetic: stored groups last -- PixelViewWeight's 3x3 layer then stages a pixel's 8 group
+        # correlations with two 16-byte loads instead of eight dwords (its staging was 21 of its 24 us)
+        corr_v = ops.corr_init(src3, ref3, proj3, inv_min, inv_max, INIT_SAMPLES, timed=self.profile_init, groups_last=self.split3)
         pv = "iter_mvs.evaluation.pixel_view_weight."
         # PixelViewWeight (itermvs.py:333-350): 3x3 layer with ReLU and the 1x1 layer to one channel in its epilogue (the
         # 16-channel tensor is never stored), then softmax over the 32 hypotheses and its maximum
-        logit = self._conv(corr_v.view(b * s * INIT_SAMPLES, 8, h3, w3), pv + "conv.0.conv.", act="relu_dot", aux1=self.pvw_dot)
+        logit = self._conv(corr_v.reshape(b * s * INIT_SAMPLES, 8, h3, w3), pv + "conv.0.conv.", act="relu_dot", aux1=self.pvw_dot)
         vw = ops.softmax_max(logit.view(b * s, INIT_SAMPLES, h3, w3))
         # [B,32,8,h3,w3]; view weights x2 (itermvs.py:56-57,71), stored pixel-major [B,h,w,S] for the iteration kernel
         agg0, view_w = ops.view_aggregate_up(corr_v, vw.view(b, s, h3, w3), interleaved=True)

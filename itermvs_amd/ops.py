@@ -541,8 +541,10 @@ def corr_iter_kernel_name() -> str:
 
 def corr_init(src3: Sequence[Tensor], ref3: Tensor, proj: Tensor, inv_min: Tensor, inv_max: Tensor,
               num_samples: int = 32, depth: Optional[Tensor] = None, out: Optional[Tensor] = None,
-              timed: bool = True) -> Tensor:
-    """itermvs.py:48-51 (+ :11-19): per-view group correlation, [B,S,N,8,H,W]."""
+              timed: bool = True, groups_last: bool = False) -> Tensor:
+    """itermvs.py:48-51 (+ :11-19): per-view group correlation, [B,S,N,8,H,W].  ``groups_last``: STORED [B,S,N,H,W,8] and returned
+    as the [B,S,N,8,H,W] view of that storage -- as [B*S*N,8,H,W] it is a channels-last tensor, which conv2d's 8-channel bf16x3
+    layer stages with two 16-byte loads per pixel, and view_aggregate(_up) reads it as it is."""
     b, _, h, w = ref3.shape
     s = len(src3)
     p = CorrInitParams()
@@ -557,7 +559,18 @@ def corr_init(src3: Sequence[Tensor], ref3: Tensor, proj: Tensor, inv_min: Tenso
         p.depth = depth.data_ptr()
     p.inv_depth_min, p.inv_depth_max = _dev(inv_min, "inv_min").data_ptr(), _dev(inv_max, "inv_max").data_ptr()
     if out is None:
-        out = torch.empty((b, s, p.N, 8, h, w), device=ref3.device, dtype=torch.float32)
+        if groups_last:
+            out = torch.empty((b, s, p.N, h, w, 8), device=ref3.device, dtype=torch.float32).permute(0, 1, 2, 5, 3, 4)
+        else:
+            out = torch.empty((b, s, p.N, 8, h, w), device=ref3.device, dtype=torch.float32)
+    if tuple(out.shape) != (b, s, p.N, 8, h, w) or out.dtype != torch.float32:
+        raise RuntimeError(f"corr_init: out must be float32 [B,S,N,8,H,W] = {(b, s, p.N, 8, h, w)}")
+    if out.is_contiguous():
+        p.out_layout = 0
+    elif out.permute(0, 1, 2, 4, 5, 3).is_contiguous():
+        p.out_layout = 1
+    else:
+        raise RuntimeError("corr_init: out must be contiguous [B,S,N,8,H,W] or the view of contiguous [B,S,N,H,W,8] storage")
     p.out = out.data_ptr()
     lib = _lib.load()
     if not timed:               # no timing events around this launch: mask bit 1 off for the call
@@ -618,9 +631,12 @@ def view_aggregate_up(corr: Tensor, w: Tensor, interleaved: bool = False) -> Tup
     """view_aggregate and, in the same launch, the x2 bilinear up-sampling of the view weights (itermvs.py:56-57,71):
     corr [B,S,N,8,H,W], w [B,S,H,W] -> ([B,N,8,H,W], [B,S,2H,2W]).  ``interleaved``: the up-sampled weights are STORED
     [B,2H,2W,S] and returned as the permuted [B,S,2H,2W] view of that storage -- same values, the layout corr_iter reads with
-    one vector load per lane quad."""
+    one vector load per lane quad.  ``corr`` may be corr_init(..., groups_last=True)'s view of [B,S,N,H,W,8] storage."""
     b, s, n, g, h, wd = corr.shape
-    corr = _dev(corr, "corr").contiguous()
+    _dev(corr, "corr")
+    corr_layout = 1 if (g == 8 and not corr.is_contiguous() and corr.permute(0, 1, 2, 4, 5, 3).is_contiguous()) else 0
+    if corr_layout == 0:
+        corr = corr.contiguous()
     w = _dev(w, "w").contiguous()
     out = torch.empty((b, n, g, h, wd), device=corr.device, dtype=torch.float32)
     if interleaved:
@@ -628,7 +644,7 @@ def view_aggregate_up(corr: Tensor, w: Tensor, interleaved: bool = False) -> Tup
         w_up = store.permute(0, 3, 1, 2)
     else:
         store = w_up = torch.empty((b, s, 2 * h, 2 * wd), device=corr.device, dtype=torch.float32)
-    check(_lib.load().itermvs_view_aggregate_up(corr.data_ptr(), w.data_ptr(), s, b, n, h, wd, out.data_ptr(), store.data_ptr(),
+    check(_lib.load().itermvs_view_aggregate_up(corr.data_ptr(), corr_layout, w.data_ptr(), s, b, n, h, wd, out.data_ptr(), store.data_ptr(),
                                                 1 if interleaved else 0, _stream()), "itermvs_view_aggregate_up")
     return out, w_up
 
@@ -1062,7 +1078,13 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
     if not channels_last_out and out.dtype != torch.float32:
         raise RuntimeError("conv2d: 16-bit storage exists for channels-last outputs only")
     p = ConvParams()
-    p.inp, p.in_sn = _planes(x, "conv input")
+    if (cin == 8 and split3 and not transposed and x.dim() == 4 and not x.is_contiguous()
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        # channels-last input [N,H,W,8] (corr_init's groups-last volume): two 16-byte loads per pixel in the tap-pair kernel
+        _dev(x, "conv input")
+        p.inp, p.in_sn, p.in_layout = x.data_ptr(), 8 * hin * win, 1
+    else:
+        p.inp, p.in_sn = _planes(x, "conv input")
     if channels_last_out:
         if not out.is_contiguous(memory_format=torch.channels_last):
             raise RuntimeError("conv2d: channels_last_out needs a dense channels-last `out`")

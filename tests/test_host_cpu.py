@@ -165,7 +165,18 @@ def test_weight_packings_of_the_fused_kernels():
     pk = ops.pack_corrnet_weights(w, "p.")
     assert pk.numel() == ops.CORRNET_WEIGHT_FLOATS
     pk3 = ops.pack_corrnet_weights(w, "p.", split3=True)
-    assert pk3.numel() == ops.CORRNET_WEIGHT_FLOATS_SPLIT3 and torch.equal(pk3[4608:], pk[1536:])    # layers 1..5 unchanged
+    assert pk3.numel() == ops.CORRNET_WEIGHT_FLOATS_SPLIT3 == 23120
+    assert torch.equal(pk3[4608:5760], pk[1536:2688]) and torch.equal(pk3[23040:], pk[14208:])      # conv1, conv5 + bias unchanged
+    # conv2 and the two transposed convolutions: weight_format 3 = bf16 [tap][chunk][h, m, l][row co][16 ci]; the three terms add up
+    # to the fp32 weight exactly; a transposed convolution is packed as the convolution weight [co][ci][ky][kx] = w[ci][co][ky][kx]
+    for off, rows, chunks, wt in ((5760, 32, 1, w["p.conv2.conv.weight"]), (12672, 16, 2, w["p.conv3.weight"].permute(1, 0, 2, 3)),
+                                  (19584, 16, 1, w["p.conv4.weight"].permute(1, 0, 2, 3))):
+        n = 9 * chunks * 3 * rows * 16 // 2
+        t = pk3[off:off + n].view(torch.int16).view(torch.bfloat16).reshape(9, chunks, 3, rows, 16).float().sum(2)     # [tap, chunk, co, ci16]
+        want = torch.zeros((9, chunks, rows, 16))
+        co, ci = wt.shape[0], wt.shape[1]
+        want.view(9, chunks, rows, 16)[:, :, :co, :] = wt.float().permute(2, 3, 0, 1).reshape(9, co, chunks, 16).permute(0, 2, 1, 3)
+        assert torch.equal(t, want), off
     # conv0's bf16 operands: MFMA 2v / 2v+1 / 12+v of window-position pair v hold terms [h h|h h] / [m m|m m] / [l l|h h]; their sum over
     # the three terms of a position is the fp32 weight exactly
     a = pk3[:4608].view(torch.int16).view(torch.bfloat16).reshape(18, 4, 16, 8).float()

@@ -193,6 +193,20 @@ def test_corr_init_and_aggregate(tag):
     agg = ops().view_aggregate(corr, cu(vw))                                # [B,32,8,h,w]
     want = g["init.agg"].permute(0, 2, 1, 3, 4)
     assert maxdiff(agg, want) <= 5e-5 * max(1.0, float(want.abs().max()))
+    # groups-last storage of the per-view volume ([B,S,N,H,W,8] behind the same logical tensor: the layout PixelViewWeight's
+    # 3x3 layer stages with two 16-byte loads per pixel): same bits out of corr_init, same bits through the consumers
+    corr_gl = ops().corr_init(src[3], ref[3], p12[2], inv_min, inv_max, 32, groups_last=True)
+    assert corr_gl.shape == corr.shape and corr_gl.permute(0, 1, 2, 4, 5, 3).is_contiguous() and torch.equal(corr_gl, corr)
+    agg_a, up_a = ops().view_aggregate_up(corr, cu(vw))
+    agg_b, up_b = ops().view_aggregate_up(corr_gl, cu(vw))
+    assert torch.equal(agg_a, agg) and torch.equal(agg_b, agg) and torch.equal(up_a, up_b)
+    h3, w3 = corr.shape[-2:]
+    pw = cu(w["iter_mvs.evaluation.pixel_view_weight.conv.0.conv.weight"])
+    pk = ops().MfmaWeight(pw, split3=True)
+    x_pl = corr.reshape(-1, 8, h3, w3)
+    x_cl = corr_gl.reshape(-1, 8, h3, w3)
+    assert x_cl.is_contiguous(memory_format=torch.channels_last) and not x_cl.is_contiguous()
+    assert torch.equal(ops().conv2d(x_cl, pk, None, act="relu"), ops().conv2d(x_pl, pk, None, act="relu"))
 
 
 def test_bilinear_up_into_two_destinations():
