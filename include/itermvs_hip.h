@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define ITERMVS_ABI_VERSION 13
+#define ITERMVS_ABI_VERSION 14
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -338,9 +338,15 @@ int itermvs_head_fused_conf(const float* hidden, int64_t hidden_sb, int32_t B, i
  *   x [B,32,H,W] planes (batch stride x_sb); w0_tile = the 3x3 weight in itermvs_conv2d's weight_format 2 = [9][2][4][64][4];
  *   w1_packed [NOB][4][4][16][4] (NOB = ceil(NO/16), zero padded) with element (ob,m,q,i,r) = W1[ob*16+i][m*16+q*4+r];
  *   bias1 [NOB*16] or NULL; out [B,NO,H,W] planes (batch stride out_sb).  All weight pointers 16-byte aligned; NO <= 192.
+ *   weight_format 0: the fp32 layouts above (exact fp32 matrix instruction).  weight_format 3: both layers in the bf16x3 form of
+ *   itermvs_conv2d's weight_format 3 (operands split exactly into three bf16 terms, six cross products, fp32 accumulation):
+ *   w0_tile = bf16 [block 4][tap 9][term 3][lane 64][8] with element (w, tap, p, 16 q + i, j) = term p of
+ *   W0[16 w + i][(j/4)*16 + 4 q + j%4][tap]; w1_packed = bf16 [NOB][k group 2][term 3][lane 64][8] with element (ob, g, p, 16 q + i, j) =
+ *   term p of W1[ob*16 + i][(2g + j/4)*16 + 4 q + j%4] (itermvs_amd.ops.pack_conv3x3_conv1x1_split3).
  * ------------------------------------------------------------------------------------------ */
-int itermvs_conv3x3_conv1x1(const float* x, int64_t x_sb, int32_t B, int32_t H, int32_t W, const float* w0_tile,
-                            const float* w1_packed, const float* bias1, int32_t NO, float* out, int64_t out_sb, void* stream);
+int itermvs_conv3x3_conv1x1(const float* x, int64_t x_sb, int32_t B, int32_t H, int32_t W, const void* w0_tile,
+                            const void* w1_packed, int32_t weight_format, const float* bias1, int32_t NO, float* out, int64_t out_sb,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * itermvs_res_chain16 -- the three 3x3 16 -> 16 convolutions that follow the stem in FeatureNet's half-resolution stage

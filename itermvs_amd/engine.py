@@ -158,6 +158,9 @@ class InferenceEngine:
         self.pk_hi0, self.pk_up0 = ops.MfmaWeight(w[hi + "0.weight"], split3=False), ops.MfmaWeight(w[up + "0.weight"], split3=False)
         self.hi1, self.hi1_bias = ops.pack_conv1x1_operand(w[hi + "2.weight"], w[hi + "2.bias"])
         self.up1, _ = ops.pack_conv1x1_operand(w[up + "2.weight"])
+        if self.split3:          # both small heads in the bf16x3 arithmetic (stack2.hip W3)
+            self.pk_hi0, self.hi1, self.hi1_bias = ops.pack_conv3x3_conv1x1_split3(w[hi + "0.weight"], w[hi + "2.weight"], w[hi + "2.bias"])
+            self.pk_up0, self.up1, _ = ops.pack_conv3x3_conv1x1_split3(w[up + "0.weight"], w[up + "2.weight"])
         # the confidence head's 3x3 layer in the fp32 tile format (it rides in the depth head's last launch, csrc/head.hip)
         self.pk_conf = ops.MfmaWeight(w["iter_mvs.update.confidence_head.0.weight"], split3=False)
 

@@ -708,14 +708,51 @@ def pack_conv1x1_operand(w1: Tensor, bias: Optional[Tensor] = None) -> Tuple[Ten
     return a, bp
 
 
-def conv3x3_conv1x1(x: Tensor, w0: "MfmaWeight", w1p: Tensor, bias_p: Optional[Tensor], no: int, out: Optional[Tensor] = None) -> Tensor:
-    """itermvs_conv3x3_conv1x1: conv3x3 32 -> 64 (``w0``: its MfmaWeight, fp32 tile format) + ReLU + conv1x1 64 -> ``no``
-    (``w1p`` / ``bias_p`` from pack_conv1x1_operand) in one launch; x [B,32,H,W] -> [B,no,H,W]."""
+def pack_conv3x3_conv1x1_split3(w0: Tensor, w1: Tensor, bias: Optional[Tensor] = None):
+    """Conv2d(32, 64, 3) weight [64,32,3,3] and Conv2d(64, NO, 1) weight [NO,64,1,1] (+ bias) -> the bf16x3 operands of
+    itermvs_conv3x3_conv1x1 (weight_format 3): (bf16 [4][9][3][64][8], bf16 [NOB][2][3][64][8], fp32 bias [NOB*16] | None).  A lane
+    (q, i) holds, as its eight K slots j of a 32-channel group, the channels (j // 4) * 16 + 4 q + j % 4."""
+    if tuple(w0.shape) != (64, 32, 3, 3) or w1.shape[1] != 64 or w1.numel() != w1.shape[0] * 64:
+        raise RuntimeError("pack_conv3x3_conv1x1_split3: expects [64,32,3,3] and [NO,64,1,1] weights")
+    t0 = w0.float().reshape(4, 16, 2, 4, 4, 9)                       # [w, i, jj, q, r, tap]: input channel jj*16 + 4q + r
+    t0 = t0.permute(0, 5, 3, 1, 2, 4).reshape(4, 9, 64, 8)           # [w, tap, (q, i), (jj, r)]
+    a0 = torch.stack(split_bf16x3(t0), 2).contiguous()               # [4, 9, 3, 64, 8]
+    no = w1.shape[0]
+    nob = (no + 15) // 16
+    full = torch.zeros((nob * 16, 64), device=w1.device, dtype=torch.float32)
+    full[:no] = w1.reshape(no, 64).float()
+    t1 = full.reshape(nob, 16, 2, 2, 4, 4).permute(0, 2, 4, 1, 3, 5).reshape(nob, 2, 64, 8)      # [ob, g, (q, i), (jj, r)]
+    a1 = torch.stack(split_bf16x3(t1), 2).contiguous()               # [nob, 2, 3, 64, 8]
+    bp = None
+    if bias is not None:
+        bp = torch.zeros((nob * 16,), device=w1.device, dtype=torch.float32)
+        bp[:no] = bias.float()
+    return a0, a1, bp
+
+
+def conv3x3_conv1x1(x: Tensor, w0, w1p: Tensor, bias_p: Optional[Tensor], no: int, out: Optional[Tensor] = None) -> Tensor:
+    """itermvs_conv3x3_conv1x1: conv3x3 32 -> 64 + ReLU + conv1x1 64 -> ``no`` in one launch; x [B,32,H,W] -> [B,no,H,W].
+    ``w0``: the 3x3 layer's MfmaWeight (fp32 tile format) with ``w1p`` / ``bias_p`` from pack_conv1x1_operand (exact fp32 matrix
+    instruction), or both bfloat16 tensors of pack_conv3x3_conv1x1_split3 (bf16x3 arithmetic)."""
     ptr, sb = _planes(x, "conv3x3_conv1x1 input")
     b, c, h, w = x.shape
+    nob = (no + 15) // 16
+    if isinstance(w0, Tensor):
+        if not (w0.is_cuda and w1p.is_cuda and w0.dtype == w1p.dtype == torch.bfloat16 and tuple(w0.shape) == (4, 9, 3, 64, 8)
+                and tuple(w1p.shape) == (nob, 2, 3, 64, 8) and w0.is_contiguous() and w1p.is_contiguous()) or c != 32:
+            raise RuntimeError("conv3x3_conv1x1: bfloat16 weights must come from pack_conv3x3_conv1x1_split3 for this output width")
+        if bias_p is not None and bias_p.numel() != nob * 16:
+            raise RuntimeError("conv3x3_conv1x1: bias_p must come from pack_conv3x3_conv1x1_split3")
+        if out is None:
+            out = torch.empty((b, no, h, w), device=x.device, dtype=torch.float32)
+        elif tuple(out.shape) != (b, no, h, w):
+            raise RuntimeError(f"conv3x3_conv1x1: output has shape {tuple(out.shape)}, expected {(b, no, h, w)}")
+        po, so = _planes(out, "conv3x3_conv1x1 output")
+        check(_lib.load().itermvs_conv3x3_conv1x1(ptr, sb, b, h, w, w0.data_ptr(), w1p.data_ptr(), 3, _ptr(bias_p), no, po, so, _stream()),
+              "itermvs_conv3x3_conv1x1")
+        return out
     if c != 32 or w0.tile is None or w0.cin != 32 or w0.cout != 64 or w0.ksize != 3:
         raise RuntimeError("conv3x3_conv1x1: expects a 32-channel input and the 32 -> 64 3x3 weight")
-    nob = (no + 15) // 16
     if w1p.numel() != nob * 1024 or (bias_p is not None and bias_p.numel() != nob * 16):
         raise RuntimeError("conv3x3_conv1x1: w1p / bias_p must come from pack_conv1x1_operand for this output width")
     if out is None:
@@ -723,7 +760,7 @@ def conv3x3_conv1x1(x: Tensor, w0: "MfmaWeight", w1p: Tensor, bias_p: Optional[T
     elif tuple(out.shape) != (b, no, h, w):
         raise RuntimeError(f"conv3x3_conv1x1: output has shape {tuple(out.shape)}, expected {(b, no, h, w)}")
     po, so = _planes(out, "conv3x3_conv1x1 output")
-    check(_lib.load().itermvs_conv3x3_conv1x1(ptr, sb, b, h, w, w0.tile.data_ptr(), _dev(w1p, "w1p").data_ptr(), _ptr(bias_p), no,
+    check(_lib.load().itermvs_conv3x3_conv1x1(ptr, sb, b, h, w, w0.tile.data_ptr(), _dev(w1p, "w1p").data_ptr(), 0, _ptr(bias_p), no,
                                               po, so, _stream()), "itermvs_conv3x3_conv1x1")
     return out
 

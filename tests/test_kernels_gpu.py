@@ -939,3 +939,17 @@ def test_conv3x3_conv1x1_one_launch_matches_torch(head, size):
     assert torch.equal(wide[:, 2:2 + no], got) and float((wide[:, :2] - 7.0).abs().max()) == 0.0 and float((wide[:, 2 + no:] - 7.0).abs().max()) == 0.0
     with pytest.raises(RuntimeError):
         ops().conv3x3_conv1x1(x[:, :16], pk0, w1p, bp, no)
+    # both layers in the bf16x3 arithmetic (weight_format 3: operands split exactly into three bf16 terms, six cross products)
+    a0, a1, bp3 = ops().pack_conv3x3_conv1x1_split3(w0, w1, b1)
+    assert a0.dtype == a1.dtype == torch.bfloat16 and tuple(a0.shape) == (4, 9, 3, 64, 8) and tuple(a1.shape) == ((no + 15) // 16, 2, 3, 64, 8)
+    # the three terms add up to the weight exactly: element (wv, tap, p, 16 q + i, j) = W0[16 wv + i][(j//4)*16 + 4q + j%4][tap]
+    back = a0.float().sum(2).reshape(4, 9, 4, 16, 2, 4).permute(0, 3, 4, 2, 5, 1).reshape(64, 32, 3, 3)
+    assert torch.equal(back, w0)
+    got3 = ops().conv3x3_conv1x1(x, a0, a1, bp3, no)
+    err3 = float((got3 - want).abs().max() / want.abs().max())
+    assert got3.shape == want.shape and err3 <= 3e-6, err3
+    wide3 = torch.full((b, no + 3, h, w), 7.0, device=DEV)
+    ops().conv3x3_conv1x1(x, a0, a1, bp3, no, out=wide3[:, 2:2 + no])
+    assert torch.equal(wide3[:, 2:2 + no], got3) and float((wide3[:, :2] - 7.0).abs().max()) == 0.0 and float((wide3[:, 2 + no:] - 7.0).abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ops().conv3x3_conv1x1(x, a0, a1[:1] if a1.shape[0] > 1 else a1[:, :1], bp3, no)

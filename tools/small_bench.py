@@ -47,6 +47,8 @@ u = "iter_mvs.upsample."
 hi = "iter_mvs.update.hidden_init_head."
 timed("upsample weights: conv3x3 32->64 + conv1x1 64->144, two launches", lambda: eng._conv(eng._conv(x2, u + "0.", act="relu"), u + "2.", ksize=1, pad=0))
 timed("upsample weights: itermvs_conv3x3_conv1x1", lambda: ops.conv3x3_conv1x1(x2, eng.pk_up0, eng.up1, None, 144))
+_u0, _u1 = ops.MfmaWeight(eng.w[u + "0.weight"], split3=False), ops.pack_conv1x1_operand(eng.w[u + "2.weight"])[0]
+timed("upsample weights: itermvs_conv3x3_conv1x1, exact fp32 MFMA", lambda: ops.conv3x3_conv1x1(x2, _u0, _u1, None, 144))
 timed("hidden init: conv3x3 32->64 + conv1x1 64->32, two launches", lambda: eng._conv(eng._conv(x3, hi + "0.", act="relu"), hi + "2.", bias=True, ksize=1, pad=0))
 timed("hidden init: itermvs_conv3x3_conv1x1", lambda: ops.conv3x3_conv1x1(x3, eng.pk_hi0, eng.hi1, eng.hi1_bias, 32))
 xh = r(1, 32, 64, 80)
