@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define ITERMVS_ABI_VERSION 14
+#define ITERMVS_ABI_VERSION 15
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -318,10 +318,14 @@ int itermvs_head_regress(const float* x, int64_t x_sb, int32_t B, int32_t P, con
  *            3 = the 64 -> 256 layer in the bf16x3 form of itermvs_conv2d's weight_format 3 (both operands split exactly into three
  *                bf16 terms, the six largest cross products, fp32 accumulation): w2_packed = bf16 [16][2][3][64][8] whose element
  *                (ob, g, p, lane = 16 q + i, j) is term p of W2[ob*16 + i][(2g + j/4)*16 + 4q + j%4]
- *                (itermvs_amd.ops.pack_head_w2_split3).  w2_packed 16-byte aligned in both forms. */
+ *                (itermvs_amd.ops.pack_head_w2_split3).  w2_packed 16-byte aligned in both forms.
+ * w0_format: 0 = w0_tile is the fp32 tile format above; 3 (only together with w2_format 3) = the dilated 3x3 layer in bf16x3 as well:
+ *                w0_tile = bf16 [block 2][tap 9][term 3][lane 64][8] whose element (mb, tap, p, 16 q + i, j) is term p of
+ *                W0[16 mb + i][(j/4)*16 + 4 q + j%4][tap] (itermvs_amd.ops.pack_head_w0_split3); 16-byte aligned.
+ *                itermvs_head_fused_conf takes the fp32 3x3 weights only. */
 int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W,
-                       const float* w0_tile, const float* w1_packed, const void* w2_packed, int32_t w2_format, const float* bias2,
-                       float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream);
+                       const void* w0_tile, int32_t w0_format, const float* w1_packed, const void* w2_packed, int32_t w2_format,
+                       const float* bias2, float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream);
 /* itermvs_head_fused_conf -- itermvs_head_fused and, in the SAME launch on the same staged tile of `hidden`, the confidence
  * head (models/itermvs.py:147-151 with the sigmoid of :198, run on the last GRU iteration :197-199): wc_tile = its dilated
  * 3x3 layer 32 -> 32 in weight_format 2 ([9][2][4][32][4], 16-byte aligned), conf_dot = the 32 weights of its 1x1 layer + bias,

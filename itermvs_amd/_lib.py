@@ -14,7 +14,7 @@ MAX_SRC = 16
 MAX_HYP = 8
 GROUPS = 8
 F32, F16, BF16 = 0, 1, 2      # itermvs_dtype: storage type of feature maps
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitermvs_hip.so")
@@ -110,7 +110,7 @@ PROTOTYPES = {
     "itermvs_pvw_tail": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p]),
     "itermvs_softmax_max": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "itermvs_head_fused": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+    "itermvs_head_fused": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "itermvs_conv3x3_conv1x1": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                           C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),

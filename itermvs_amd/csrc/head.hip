@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) head_regress_kernel(const HeadArgs a) {
 struct FusedArgs {
     const float* hidden;     // [B,32,H,W] planes
     int64_t h_sb;
-    const float* w0t;        // 3x3 weights, tile format [9][2][4][32][4]
+    const void* w0t;         // 3x3 weights: fp32 tile format [9][2][4][32][4]; C3: bf16 [block 2][tap 9][term 3][lane 64][8]
     const float* w1p;
     const void* w2p;         // W2B: bf16 [16][2][3][64][8] (ops.pack_head_w2_split3), else fp32 packed like itermvs_head_regress
     const float* bias2;
@@ -279,15 +279,27 @@ static_assert(kCoP <= 16 * kCoLgStride, "the confidence partials alias the logit
 // plane), the wave's W2 slice -- split on the host -- sits in registers as A operands of v_mfma_f32_16x16x32_bf16 (K = 32 = the
 // lane's own eight channels (2g + j/4) * 16 + 4q + j%4 of k group g: the D layout of the 32 -> 64 layer IS this B layout), and
 // the six largest cross products per k group replace 32 fp32 instructions: 48 x 16 instead of 64 x 32 matrix-pipe cycles.
-template <bool CONF, bool W2B>
+// C3 (w0_format 3, with W2B, without CONF): the dilated 3x3 layer in bf16x3 as well.  K = 32 = ALL 32 input channels of a tap (a
+// lane's eight slots j = channels (j / 4) * 16 + 4 q + j % 4), so the four waves split as (output block w & 1, taps 0..4 | 5..8)
+// instead of (output block, input chunk): 30 / 24 MFMAs of 16 cycles instead of 36 of 40; the tile is staged as bf16 triples by
+// (q, row, column) items (eight plane loads, split, three 16-byte stores), the h and m terms of a wave's weights sit in registers,
+// the l terms in LDS (the kernel is at its register limit).  The two tap-half partials meet in LDS like the two chunk partials.
+constexpr int kC3T = 3 * 4 * 3 * 20 * 4;       // staged tile as bf16 triples, in floats: [term][q][row][col][16 B] = 11 520 B
+constexpr int kC3PlaneB = 4 * 3 * 20 * 16;
+constexpr int kC3WlB = 4 * 5 * 64 * 16;        // l terms of the 3x3 weights: [wave][tap of the wave <= 5][lane][16 B]
+
+template <bool CONF, bool W2B, bool C3 = false>
 __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, const int tiles_total) {
+    static_assert(!C3 || (W2B && !CONF), "bf16x3 3x3 layer: with the bf16x3 last layer, without the confidence rider");
+    constexpr int kTT = C3 ? kC3T : kCoT;           // floats per tile buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* __restrict__ Pp = smem + 2 * kCoT;       // (two tile buffers in front: the next tile is stashed while this one computes)
+    float* __restrict__ Pp = smem + 2 * kTT;        // (two tile buffers in front: the next tile is stashed while this one computes)
     float* __restrict__ Y = Pp + kCoP;
     float* __restrict__ LG = Y + kCoY;
     float* __restrict__ PC = LG;                    // CONF: conv partials of the confidence head
     float* __restrict__ BS = LG + 16 * kCoLgStride; // the last layer's biases (accumulator start values, re-read per tile: 16 registers less)
     float* __restrict__ WC = smem + kCoLds;         // CONF: its 3x3 weights
+    char* __restrict__ WL3 = reinterpret_cast<char*>(BS + kHeadBins);      // C3: l terms of this layer's weights
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l16 = lane & 15;
@@ -295,11 +307,23 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
     const uint32_t plane = (uint32_t)(a.H * a.W);
 
     // this wave's weight slices -> registers, once
-    f32x4 wc[9], w1r[2], w2r[W2B ? 1 : 4][W2B ? 1 : 4];
+    f32x4 wc[C3 ? 1 : 9], w1r[2], w2r[W2B ? 1 : 4][W2B ? 1 : 4];
     bf8 w2b[W2B ? 4 : 1][W2B ? 2 : 1][W2B ? 3 : 1];
+    bf8 w3h[C3 ? 5 : 1], w3m[C3 ? 5 : 1];           // C3: terms h, m of taps ch * 5 + k (the second half has four)
+    if constexpr (C3) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-        wc[tap] = *reinterpret_cast<const f32x4*>(a.w0t + ((((tap * 2 + ch) * 4 + q) * 32) + mb0 * 16 + l16) * 4);
+        for (int k = 0; k < 5; ++k) {
+            const int tap = min(ch * 5 + k, 8);
+            const bf8* __restrict__ src = reinterpret_cast<const bf8*>(a.w0t) + ((mb0 * 9 + tap) * 3) * 64 + lane;
+            w3h[k] = src[0];
+            w3m[k] = src[64];
+            reinterpret_cast<bf8*>(WL3)[(wave * 5 + k) * 64 + lane] = src[128];
+        }
+    } else {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+            wc[tap] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.w0t) + ((((tap * 2 + ch) * 4 + q) * 32) + mb0 * 16 + l16) * 4);
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) w1r[u] = *reinterpret_cast<const f32x4*>(a.w1p + ((((wave * 2 + u) * 4 + q) * 16) + l16) * 4);
     if constexpr (W2B) {
@@ -327,6 +351,38 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
         if (tid < 33) WC[kCoWc + tid] = a.cdot[tid];      // the 1x1 layer {w[32], bias} behind the 3x3 weights
     }
 
+    const int rows_per_b = a.H * a.tiles_x;
+    // C3 staging: item = (q, row, column) of the 3 x 20 halo tile = the lane-q channels {4q .. 4q+3, 16+4q .. 16+4q+3} of one pixel
+    const int c3_q = tid / 60, c3_r = tid - c3_q * 60;
+    const int c3_row = c3_r / 20, c3_col = c3_r - c3_row * 20;
+    float st3[C3 ? 8 : 1];
+    auto fetch3 = [&](int tile) {
+        const int b = tile / rows_per_b, rem = tile - b * rows_per_b;
+        const int y = rem / a.tiles_x, x0 = (rem - y * a.tiles_x) * 16;
+        const float* __restrict__ base = a.hidden + (int64_t)b * a.h_sb;
+        const int gy = y + 2 * c3_row - 2, gx = x0 + c3_col - 2;
+        const bool ok = tid < 240 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+        for (int j = 0; j < (C3 ? 8 : 1); ++j)
+            st3[j] = ok ? base[(uint32_t)((j >> 2) * 16 + 4 * c3_q + (j & 3)) * plane + (uint32_t)(gy * a.W + gx)] : 0.0f;
+    };
+    auto stash3 = [&](float* __restrict__ T) {
+        if constexpr (C3) {
+            if (tid < 240) {
+                u32x4 Hh, Mm, Ll;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t h, m, l;
+                    split_pair(st3[2 * k], st3[2 * k + 1], h, m, l);
+                    Hh[k] = h; Mm[k] = m; Ll[k] = l;
+                }
+                char* __restrict__ d = reinterpret_cast<char*>(T) + ((c3_q * 3 + c3_row) * 20 + c3_col) * 16;
+                *reinterpret_cast<u32x4*>(d) = Hh;
+                *reinterpret_cast<u32x4*>(d + kC3PlaneB) = Mm;
+                *reinterpret_cast<u32x4*>(d + 2 * kC3PlaneB) = Ll;
+            }
+        }
+    };
     // staging: 1920 floats per tile = [32 channels][3 rows][20 columns]; thread t moves items t, t+256, ...  Which (channel,
     // row, column) an item is does not depend on the tile: its plane offset, row / column displacement and LDS slot are
     // computed once.
@@ -344,7 +400,6 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
         const int lds = ((((c >> 4) * 4 + ((c >> 2) & 3)) * 3 + row) * 20 + col) * 4 + (c & 3);
         it_meta[i] = item < 32 * 60 ? (uint32_t)lds | (uint32_t)col << 12 | (uint32_t)row << 17 | 1u << 19 : 0u;      // surplus items: dead
     }
-    const int rows_per_b = a.H * a.tiles_x;
     auto fetch = [&](int tile) {
         const int b = tile / rows_per_b, rem = tile - b * rows_per_b;
         const int y = rem / a.tiles_x, x0 = (rem - y * a.tiles_x) * 16;
@@ -362,27 +417,50 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
             if (it_meta[i] >> 19) T[it_meta[i] & 0xfffu] = st[i];
     };
 
+    auto fetch_tile = [&](int t) { if constexpr (C3) fetch3(t); else fetch(t); };
+    auto stash_tile = [&](float* __restrict__ T) { if constexpr (C3) stash3(T); else stash(T); };
     int tile = blockIdx.x, buf = 0;
     if (tile < tiles_total) {
-        fetch(tile);
-        stash(smem);
+        fetch_tile(tile);
+        stash_tile(smem);
     }
-    if (tile + (int)gridDim.x < tiles_total) fetch(tile + gridDim.x);
+    if (tile + (int)gridDim.x < tiles_total) fetch_tile(tile + gridDim.x);
     for (; tile < tiles_total; tile += gridDim.x, buf ^= 1) {
         __syncthreads();            // this tile's staging is visible; the previous tile's readers of P / Y / LG are done
-        const float* __restrict__ T = smem + buf * kCoT;
+        const float* __restrict__ T = smem + buf * kTT;
         const int b = tile / rows_per_b, rem = tile - b * rows_per_b;
         const int y = rem / a.tiles_x, x0 = (rem - y * a.tiles_x) * 16;
 
-        // ---- dilated 3x3 layer: block mb0, input chunk ch ----
+        // ---- dilated 3x3 layer: block mb0, input chunk ch (C3: block mb0, tap half ch, all 32 input channels) ----
         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f};
         const float* __restrict__ tb = T + ((ch * 4 + q) * 3) * 80 + l16 * 4;
+        if constexpr (C3) {
+            const char* __restrict__ t3 = reinterpret_cast<const char*>(T) + (q * 3 * 20 + l16) * 16;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(tb + ky * 80 + kx * 8);
+            for (int k = 0; k < 5; ++k) {
+                if (k < 4 || ch == 0) {          // wave-uniform: taps 0..4 | 5..8
+                    const int tap = ch * 5 + k;      // (ch is wave-uniform; ky / kx below are folded per branch of it)
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    const char* __restrict__ bp = t3 + (ky * 20 + 2 * kx) * 16;
+                    const bf8 xh = *reinterpret_cast<const bf8*>(bp), xm = *reinterpret_cast<const bf8*>(bp + kC3PlaneB);
+                    const bf8 xl = *reinterpret_cast<const bf8*>(bp + 2 * kC3PlaneB);
+                    const bf8 wl = reinterpret_cast<const bf8*>(WL3)[(wave * 5 + k) * 64 + lane];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3h[k], xl, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3m[k], xm, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3m[k], xh, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3h[k], xm, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3h[k], xh, acc0, 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[tap][s2], bv[s2], acc0, 0, 0, 0);
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(tb + ky * 80 + kx * 8);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[tap][s2], bv[s2], acc0, 0, 0, 0);
+            }
         }
         *reinterpret_cast<f32x4*>(Pp + (((ch * 2 + mb0) * 4 + q) * 16 + l16) * 4) = acc0;
         if constexpr (CONF) {
@@ -399,8 +477,8 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
         }
         // the next tile's halo (fetched one iteration ago) goes to the other buffer, the one after it into registers
         if (tile + (int)gridDim.x < tiles_total) {
-            stash(smem + (buf ^ 1) * kCoT);
-            if (tile + 2 * (int)gridDim.x < tiles_total) fetch(tile + 2 * gridDim.x);
+            stash_tile(smem + (buf ^ 1) * kTT);
+            if (tile + 2 * (int)gridDim.x < tiles_total) fetch_tile(tile + 2 * gridDim.x);
         }
         __syncthreads();
 
@@ -595,23 +673,27 @@ extern "C" int itermvs_head_regress(const float* x, int64_t x_sb, int32_t B, int
     return itermvs_launch_status();
 }
 
-template <bool CONF, bool W2B>
+template <bool CONF, bool W2B, bool C3 = false>
 static int launch_head_coop(const FusedArgs& a, int grid, int tiles, hipStream_t stream) {
-    constexpr int lds = (kCoLds + (CONF ? kCoWc + 36 : 0)) * 4;      // CONF: 78 KB, two workgroups per CU still fit the 160 KB
-    auto kern = head_coop_kernel<CONF, W2B>;
+    // CONF: 80 KB, C3: 71 KB -- two workgroups per CU still fit the 160 KB
+    constexpr int lds = (kCoLds + (CONF ? kCoWc + 36 : 0) + (C3 ? 2 * (kC3T - kCoT) : 0)) * 4 + (C3 ? kC3WlB : 0);
+    auto kern = head_coop_kernel<CONF, W2B, C3>;
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     if (!attr_ok) return ITERMVS_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, tiles);
     return itermvs_launch_status();
 }
 
-static int launch_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W, const float* w0_tile,
+static int launch_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W, const void* w0_tile, int32_t w0_format,
                              const float* w1_packed, const void* w2_packed, int32_t w2_format, const float* bias2, float* nd_out0, int64_t nd_sb0,
                              float* nd_out1, int64_t nd_sb1, int64_t* best, const float* wc_tile, const float* conf_dot, float* conf,
                              int64_t conf_sb, void* stream) {
     ITERMVS_RETURN_IF(!hidden || !w0_tile || !w1_packed || !w2_packed || !bias2, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(B < 1 || H < 1 || W < 1, ITERMVS_ERR_DIMS);
     ITERMVS_RETURN_IF(w2_format != 0 && w2_format != 3, ITERMVS_ERR_LAYOUT);
+    // the 3x3 layer in bf16x3 (w0_format 3): with the bf16x3 last layer, without the confidence rider
+    ITERMVS_RETURN_IF(w0_format != 0 && !(w0_format == 3 && w2_format == 3 && !conf), ITERMVS_ERR_LAYOUT);
+    ITERMVS_RETURN_IF((((uintptr_t)w0_tile) & 15) != 0, ITERMVS_ERR_ALIGN);
     ITERMVS_RETURN_IF((((uintptr_t)w2_packed) & 15) != 0, ITERMVS_ERR_ALIGN);
     FusedArgs a;
     a.hidden = hidden; a.h_sb = hidden_sb; a.w0t = w0_tile; a.w1p = w1_packed; a.w2p = w2_packed; a.bias2 = bias2;
@@ -625,13 +707,15 @@ static int launch_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, 
     const int grid = tiles < wgs_per_cu * cus ? tiles : wgs_per_cu * cus;
     hipStream_t st = (hipStream_t)stream;
     if (conf) return w2_format ? launch_head_coop<true, true>(a, grid, tiles, st) : launch_head_coop<true, false>(a, grid, tiles, st);
+    if (w0_format == 3) return launch_head_coop<false, true, true>(a, grid, tiles, st);
     return w2_format ? launch_head_coop<false, true>(a, grid, tiles, st) : launch_head_coop<false, false>(a, grid, tiles, st);
 }
 
 extern "C" int itermvs_head_fused(const float* hidden, int64_t hidden_sb, int32_t B, int32_t H, int32_t W,
-                                  const float* w0_tile, const float* w1_packed, const void* w2_packed, int32_t w2_format, const float* bias2,
-                                  float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best, void* stream) {
-    return launch_head_fused(hidden, hidden_sb, B, H, W, w0_tile, w1_packed, w2_packed, w2_format, bias2, nd_out0, nd_sb0, nd_out1, nd_sb1, best,
+                                  const void* w0_tile, int32_t w0_format, const float* w1_packed, const void* w2_packed, int32_t w2_format,
+                                  const float* bias2, float* nd_out0, int64_t nd_sb0, float* nd_out1, int64_t nd_sb1, int64_t* best,
+                                  void* stream) {
+    return launch_head_fused(hidden, hidden_sb, B, H, W, w0_tile, w0_format, w1_packed, w2_packed, w2_format, bias2, nd_out0, nd_sb0, nd_out1, nd_sb1, best,
                              nullptr, nullptr, nullptr, 0, stream);
 }
 
@@ -641,6 +725,6 @@ extern "C" int itermvs_head_fused_conf(const float* hidden, int64_t hidden_sb, i
                                        const float* wc_tile, const float* conf_dot, float* conf, int64_t conf_sb, void* stream) {
     ITERMVS_RETURN_IF(!wc_tile || !conf_dot || !conf, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF((((uintptr_t)wc_tile) & 15) != 0, ITERMVS_ERR_ALIGN);
-    return launch_head_fused(hidden, hidden_sb, B, H, W, w0_tile, w1_packed, w2_packed, w2_format, bias2, nd_out0, nd_sb0, nd_out1, nd_sb1, best,
+    return launch_head_fused(hidden, hidden_sb, B, H, W, w0_tile, 0, w1_packed, w2_packed, w2_format, bias2, nd_out0, nd_sb0, nd_out1, nd_sb1, best,
                              wc_tile, conf_dot, conf, conf_sb, stream);
 }

@@ -148,8 +148,10 @@ class InferenceEngine:
         self.head_w1, self.head_w2 = ops.pack_head_weights(w[dh + "2.weight"], w[dh + "4.weight"])
         if self.split3:     # the 64 -> 256 layer of the fused head on the bf16 matrix instruction (bf16x3 arithmetic, head.hip W2B)
             self.head_w2_fused = ops.pack_head_w2_split3(w[dh + "4.weight"])
+            self.head_w0_fused = ops.pack_head_w0_split3(w[dh + "0.weight"])     # ... and its dilated 3x3 layer (launches without the confidence rider)
         else:
             self.head_w2_fused = self.head_w2
+            self.head_w0_fused = None
         # (z / r gates, 43 -> 64 dilated at 1/4 resolution: the bf16x3 form measured 18.7 us against 18.2 us -- four channel
         #  blocks stage and split each tile four times; the q convolution, two blocks, gains: 11.1 vs 13.1 us)
         self.pk_zr = ops.MfmaWeight(self.w_zr, split3=False)
@@ -371,7 +373,8 @@ class InferenceEngine:
         if not want_logits:
             p = "iter_mvs.update.depth_head."
             conf = (self.pk_conf, self.conf_dot, ws["conf"]) if with_conf else None
-            _, best = ops.head_fused(hidden, self.pk[p + "0.weight"], self.head_w1, self.head_w2_fused, self.w[p + "4.bias"],
+            w0 = self.head_w0_fused if (self.head_w0_fused is not None and conf is None) else self.pk[p + "0.weight"]
+            _, best = ops.head_fused(hidden, w0, self.head_w1, self.head_w2_fused, self.w[p + "4.bias"],
                                      nd_out=nd_out, want_best=want_best, conf=conf)
             return None, best
         if with_conf:

@@ -691,6 +691,15 @@ def pack_head_w2_split3(w2: Tensor) -> Tensor:
     return torch.stack(split_bf16x3(t), 2).contiguous()           # [16, 2, 3, 64, 8]
 
 
+def pack_head_w0_split3(w0: Tensor) -> Tensor:
+    """depth_head[0].weight [32,32,3,3] (dilated 3x3) -> the bf16x3 A operands of itermvs_head_fused's first layer (w0_format 3):
+    bfloat16 [2][9][3][64][8] whose element (mb, tap, p, lane = 16 q + i, j) is term p of W0[16 mb + i][(j//4)*16 + 4q + j%4][tap]."""
+    if tuple(w0.shape) != (32, 32, 3, 3):
+        raise RuntimeError("pack_head_w0_split3: expects the [32,32,3,3] weight")
+    t = w0.float().reshape(2, 16, 2, 4, 4, 9).permute(0, 5, 3, 1, 2, 4).reshape(2, 9, 64, 8)      # [mb, tap, (q, i), (jj, r)]
+    return torch.stack(split_bf16x3(t), 2).contiguous()                                            # [2, 9, 3, 64, 8]
+
+
 def pack_conv1x1_operand(w1: Tensor, bias: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """Conv2d(64, NO, 1) weight [NO,64,1,1] (+ bias [NO]) -> the matrix-core operand layout of itermvs_conv3x3_conv1x1:
     [NOB][4][4][16][4] with element (ob,m,q,i,r) = W1[ob*16+i][m*16+q*4+r], NO zero-padded to NOB*16 (bias likewise)."""
@@ -793,7 +802,7 @@ def head_regress(x: Tensor, w1p: Tensor, w2p: Tensor, bias2: Tensor,
     return nd, best
 
 
-def head_fused(hidden: Tensor, w0: "MfmaWeight", w1p: Tensor, w2p: Tensor, bias2: Tensor,
+def head_fused(hidden: Tensor, w0, w1p: Tensor, w2p: Tensor, bias2: Tensor,
                nd_out: Optional[Sequence[Tuple[Tensor, int]]] = None, want_best: bool = False, conf=None):
     """itermvs_head_fused: hidden [B,32,H,W] -> normalised depth (and arg-max bin); the dilated 3x3 layer (``w0``: its
     MfmaWeight), both 1x1 layers and the regression in one launch.  Returns (nd | None, best | None).
@@ -801,8 +810,16 @@ def head_fused(hidden: Tensor, w0: "MfmaWeight", w1p: Tensor, w2p: Tensor, bias2
     the confidence head (itermvs.py:147-151,198) rides in the same launch and writes sigmoid(...) to ``out``."""
     _dev(hidden, "hidden")
     b, c, h, w = hidden.shape
-    if c != 32 or w0.tile is None or w0.cin != 32 or w0.cout != 32:
-        raise RuntimeError("head_fused: expects the 32-channel hidden state and the 32 -> 32 3x3 weight")
+    if isinstance(w0, Tensor):               # pack_head_w0_split3: the dilated 3x3 layer in bf16x3 (needs the bf16x3 w2, no conf rider)
+        if not (w0.is_cuda and w0.dtype == torch.bfloat16 and tuple(w0.shape) == (2, 9, 3, 64, 8) and w0.is_contiguous()) or c != 32:
+            raise RuntimeError("head_fused: a tensor w0 must come from pack_head_w0_split3")
+        if conf is not None or not (isinstance(w2p, Tensor) and w2p.dtype == torch.bfloat16):
+            raise RuntimeError("head_fused: the bf16x3 3x3 layer needs the bf16x3 last layer (pack_head_w2_split3) and no confidence rider")
+        w0_ptr, w0_format = w0.data_ptr(), 3
+    else:
+        if c != 32 or w0.tile is None or w0.cin != 32 or w0.cout != 32:
+            raise RuntimeError("head_fused: expects the 32-channel hidden state and the 32 -> 32 3x3 weight")
+        w0_ptr, w0_format = w0.tile.data_ptr(), 0
     ptr, sb = _planes(hidden, "hidden")
     p = h * w
     if not isinstance(w2p, torch.Tensor) or not w2p.is_cuda:
@@ -831,12 +848,12 @@ def head_fused(hidden: Tensor, w0: "MfmaWeight", w1p: Tensor, w2p: Tensor, bias2
         wc, cdot, cout = conf
         if wc.tile is None or wc.cin != 32 or wc.cout != 32 or cdot.numel() != 33 or tuple(cout.shape) != (b, 1, h, w) or not cout.is_contiguous():
             raise RuntimeError("head_fused: conf = (32 -> 32 3x3 MfmaWeight in the fp32 tile format, 33 floats, contiguous [B,1,H,W] output)")
-        check(_lib.load().itermvs_head_fused_conf(ptr, sb, b, h, w, w0.tile.data_ptr(), _dev(w1p, "w1").data_ptr(),
+        check(_lib.load().itermvs_head_fused_conf(ptr, sb, b, h, w, w0_ptr, _dev(w1p, "w1").data_ptr(),
                                                   w2p.data_ptr(), w2_format, _dev(bias2, "bias2").data_ptr(), dests[0][0], dests[0][1],
                                                   dests[1][0], dests[1][1], _ptr(best), wc.tile.data_ptr(), _dev(cdot, "conf_dot").data_ptr(),
                                                   _dev(cout, "conf").data_ptr(), p, _stream()), "itermvs_head_fused_conf")
         return nd, best
-    check(_lib.load().itermvs_head_fused(ptr, sb, b, h, w, w0.tile.data_ptr(), _dev(w1p, "w1").data_ptr(),
+    check(_lib.load().itermvs_head_fused(ptr, sb, b, h, w, w0_ptr, w0_format, _dev(w1p, "w1").data_ptr(),
                                          w2p.data_ptr(), w2_format, _dev(bias2, "bias2").data_ptr(), dests[0][0], dests[0][1],
                                          dests[1][0], dests[1][1], _ptr(best), _stream()), "itermvs_head_fused")
     return nd, best

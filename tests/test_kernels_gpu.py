@@ -508,7 +508,7 @@ def test_head_regress_fused_matches_chain(tag):
         assert float(buf0[:, :3].abs().max()) == 0.0 and float(buf1[:, 2:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("w2_form", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("w2_form", ["fp32", "bf16x3", "bf16x3_all"])
 @pytest.mark.parametrize("size", [(1, 16, 32), (2, 23, 37), (1, 128, 160)])
 def test_head_fused_equals_conv_plus_head_regress(size, w2_form):
     """the one-launch depth head (3x3 dilated layer + two 1x1 layers + regression; one tile shared by the four waves of a
@@ -516,7 +516,8 @@ def test_head_fused_equals_conv_plus_head_regress(size, w2_form):
     the softmax sum are accumulated separately and then added, so sums may differ in the last bit -- arg-max bins equal
     wherever the two best probabilities are not within rounding of each other, normalised depth to 1e-6.
     ``bf16x3``: the 64 -> 256 layer on the bf16 matrix instruction (both operands split exactly into three bf16 terms, six cross
-    products, fp32 accumulation: pack_head_w2_split3) -- same gates."""
+    products, fp32 accumulation: pack_head_w2_split3) -- same gates.  ``bf16x3_all``: the dilated 3x3 layer in that arithmetic as well
+    (pack_head_w0_split3; all 32 input channels per matrix instruction, the nine taps split over two waves)."""
     b, h, w = size
     wts = load_weights("seed0")
     p = "iter_mvs.update.depth_head."
@@ -527,7 +528,7 @@ def test_head_fused_equals_conv_plus_head_regress(size, w2_form):
     a1, a2 = ops().pack_head_weights(w1, w2)
     x = ops().conv2d(hidden, pk0, None, pad=2, dilation=2, act="relu")
     nd_ref, best_ref = ops().head_regress(x, a1, a2, b2, want_best=True)
-    if w2_form == "bf16x3":
+    if w2_form != "fp32":
         a2 = ops().pack_head_w2_split3(w2)
         assert a2.dtype == torch.bfloat16 and tuple(a2.shape) == (16, 2, 3, 64, 8)
         # the three terms add up to the weight exactly, element (ob, g, p, 16 q + i, j) = W2[ob*16 + i][(2g + j//4)*16 + 4q + j%4]
@@ -535,6 +536,13 @@ def test_head_fused_equals_conv_plus_head_regress(size, w2_form):
         assert torch.equal(back, w2.reshape(256, 64))
         with pytest.raises(RuntimeError):
             ops().head_fused(hidden, pk0, a1, a2[:8], b2)
+    if w2_form == "bf16x3_all":
+        with pytest.raises(RuntimeError):      # the bf16x3 3x3 layer needs the bf16x3 last layer
+            ops().head_fused(hidden, ops().pack_head_w0_split3(w0), a1, ops().pack_head_weights(w1, w2)[1], b2)
+        pk0 = ops().pack_head_w0_split3(w0)
+        assert pk0.dtype == torch.bfloat16 and tuple(pk0.shape) == (2, 9, 3, 64, 8)
+        back0 = pk0.float().sum(2).reshape(2, 9, 4, 16, 2, 4).permute(0, 3, 4, 2, 5, 1).reshape(32, 32, 3, 3)
+        assert torch.equal(back0, w0)
     nd, best = ops().head_fused(hidden, pk0, a1, a2, b2, want_best=True)
     flips = float((best != best_ref).float().mean())
     assert flips <= 2e-4, flips

@@ -13,7 +13,8 @@ reps = int([a for a in sys.argv[1:] if a.isdigit()][0]) if any(a.isdigit() for a
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(1)
 hidden = torch.randn((1, 32, 128, 160), generator=g).to(dev)
-w0 = ops.MfmaWeight((torch.randn((32, 32, 3, 3), generator=g) * 0.1).to(dev))
+w0_f32 = (torch.randn((32, 32, 3, 3), generator=g) * 0.1).to(dev)
+w0 = ops.MfmaWeight(w0_f32)
 w1 = (torch.randn((64, 32, 1, 1), generator=g) * 0.1).to(dev)
 w2 = (torch.randn((256, 64, 1, 1), generator=g) * 0.1).to(dev)
 b2 = torch.randn((256,), generator=g).to(dev)
@@ -22,6 +23,10 @@ hx = torch.zeros((1, 43, 128, 160), device=dev)
 if "--w2-bf16x3" in sys.argv:      # the 64 -> 256 layer on the bf16 matrix instruction (w2_format 3)
     sys.argv.remove("--w2-bf16x3")
     hw2 = ops.pack_head_w2_split3(w2)
+if "--all-bf16x3" in sys.argv:     # ... and the dilated 3x3 layer (w0_format 3)
+    sys.argv.remove("--all-bf16x3")
+    hw2 = ops.pack_head_w2_split3(w2)
+    w0 = ops.pack_head_w0_split3(w0_f32)
 run = lambda: ops.head_fused(hidden, w0, hw1, hw2, b2, nd_out=[(hx, 32)])
 st = torch.cuda.Stream()
 with torch.cuda.stream(st):            # 20 launches per graph replay: no host launch cost between them
