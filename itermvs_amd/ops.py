@@ -1016,6 +1016,7 @@ def split_bf16x3(t: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
 #   True  -> bf16x3 split on v_mfma_f32_16x16x32_bf16 (conv_tile3.hip, weight_format 3): fp32-comparable error, 2.7x less matrix time
 #   False -> exact fp32 MFMA (conv_tile.hip, weight_format 2): bit-for-bit an fmaf chain
 MFMA_SPLIT3_DEFAULT = True
+SPLIT3_STRIDE2 = False      # True: stride-2 3x3 layers (Cin > 8) of a split3 MfmaWeight on the bf16 instruction as well (measured slower)
 
 
 class MfmaWeight:
@@ -1102,9 +1103,11 @@ def conv2d(x: Tensor, weight, bias=None, *, ksize: int = 3, stride: int = 1, pad
             raise RuntimeError("conv2d: MfmaWeight does not match the input channels / kernel size")
         cout = weights[0].cout
         tiled = transposed or all(_use_tile(wt, stride, dilation) for wt in weights)
-        # (stride-2 layers keep the fp32 form: their halo tiles leave no LDS for two resident workgroups in the split form, and
-        #  the sweep measured no gain -- profiles/r05)
-        split3 = (tiled and not transposed and stride == 1 and all(wt.tile3 is not None for wt in weights)
+        # (stride-2 layers keep the fp32 form: in the step the split form measured 30.2 us per launch against 28.0 -- their halo tiles
+        #  leave no LDS for two resident workgroups and four channel blocks re-stage and re-split each tile; SPLIT3_STRIDE2 = True
+        #  selects the split form for them, profiles/r06/r06l_*)
+        split3 = (tiled and not transposed and (stride == 1 or (stride == 2 and cin > 8 and dilation == 1 and SPLIT3_STRIDE2))
+                  and all(wt.tile3 is not None for wt in weights)
                   and (cin > 8 or dilation == 1))                    # (the tap-pair form of 5..8 channels: no dilation)
         weights = [(wt.tile3 if split3 else wt.tile) if tiled else wt.data for wt in weights]
     else:
