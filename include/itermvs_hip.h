@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define ITERMVS_ABI_VERSION 15
+#define ITERMVS_ABI_VERSION 16
 #define ITERMVS_MAX_SRC 16     /* source views per reference view (pair.txt holds 10) */
 #define ITERMVS_MAX_HYP 8      /* hypotheses per level in the iteration branch (4,4,2) */
 #define ITERMVS_GROUPS 8       /* models/itermvs.py:28  */
@@ -385,6 +385,24 @@ int itermvs_res_chain16(const float* y1, int64_t y1_sn, const float* shortcut, i
 int itermvs_lateral_conv3x3(const float* fine, int64_t fine_sn, int32_t Cf, const float* coarse, int64_t coarse_sn, int32_t N,
                             int32_t H, int32_t W, const float* w_lat, const float* b_lat, const void* w_out, const float* b_out,
                             int32_t Cout, void* out, int64_t out_sn, int32_t out_layout, float* out2, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * itermvs_gru_conv -- the dilated 3x3 convolutions of the ConvGRU with their gate math, as cooperative bf16x3 kernels
+ * (models/module.py:53-66; the GRU of models/itermvs.py:131-137: 32 hidden + 1 + 10 input channels, dilation 2, padding 2).
+ *   mode 0: x = [h | inputs] [B,43,H,W];  z = sigmoid(convz(x)) -> out [B,32,H,W];  r = sigmoid(convr(x)), r * h -> out2
+ *           (module.py:61-63).  w_packed / bias: the two layers stacked along the output channels (64).
+ *   mode 1: x = [r*h | inputs];  q = tanh(convq(x));  h' = (1 - z) h + z q -> out (and out2 when not NULL)  (module.py:64-65).
+ *           h may alias out (every element is read before it is written, by the same thread).
+ * x, h, z, out, out2: fp32 channel planes of H*W elements (row stride W), batch strides *_sb in elements.
+ * w_packed (16-byte aligned): bf16 [output block of 16][tap 9][operand 6][lane 64][8]; with lane = 16 q + i and (h, m, l) the exact
+ * three-term bf16 split of W[16 ob + i][c][tap]:  operands 0..2 = h, m, l of channel c = (j / 4) * 16 + 4 q + j % 4;  operands
+ * 3..5 of channel c = 32 + 8 (q % 2) + j (zero from 43 on) = h, m and (q < 2 ? l : h).
+ * Arithmetic: fp32 accumulation of the six largest cross products (a few 1e-7 of the fp32 form's range; tests/test_kernels_gpu.py).
+ * Replaces, in the inference step, two itermvs_conv2d launches per GRU iteration.
+ * ------------------------------------------------------------------------------------------ */
+int itermvs_gru_conv(const float* x, int64_t x_sb, int32_t B, int32_t H, int32_t W, int32_t mode, const void* w_packed,
+                     const float* bias, const float* h, int64_t h_sb, const float* z, int64_t z_sb, float* out, int64_t out_sb,
+                     float* out2, int64_t out2_sb, void* stream);
 
 
 

@@ -14,7 +14,7 @@ MAX_SRC = 16
 MAX_HYP = 8
 GROUPS = 8
 F32, F16, BF16 = 0, 1, 2      # itermvs_dtype: storage type of feature maps
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitermvs_hip.so")
@@ -143,6 +143,8 @@ PROTOTYPES = {
     "itermvs_lateral_conv3x3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
                                           C.c_void_p, C.c_void_p]),
+    "itermvs_gru_conv": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "itermvs_stem": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_int64, C.c_int32, C.c_void_p]),
     "itermvs_stem_compose": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

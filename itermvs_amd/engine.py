@@ -155,6 +155,12 @@ class InferenceEngine:
         # (z / r gates, 43 -> 64 dilated at 1/4 resolution: the bf16x3 form measured 18.7 us against 18.2 us -- four channel
         #  blocks stage and split each tile four times; the q convolution, two blocks, gains: 11.1 vs 13.1 us)
         self.pk_zr = ops.MfmaWeight(self.w_zr, split3=False)
+        self.gru_coop = self.split3      # both GRU convolutions as cooperative bf16x3 kernels (gru.hip)
+        if self.gru_coop:
+            g = "iter_mvs.update.gru."
+            self.gru_zr = ops.pack_gru_conv_split3(self.w_zr)
+            self.gru_q = ops.pack_gru_conv_split3(w[g + "convq.weight"])
+            self.gru_bq = w[g + "convq.bias"].contiguous()
         # the two conv3x3 32 -> 64 + ReLU + conv1x1 heads, one launch each (csrc/stack2.hip)
         hi, up = "iter_mvs.update.hidden_init_head.", "iter_mvs.upsample."
         self.pk_hi0, self.pk_up0 = ops.MfmaWeight(w[hi + "0.weight"], split3=False), ops.MfmaWeight(w[up + "0.weight"], split3=False)
@@ -407,6 +413,10 @@ class InferenceEngine:
         """ConvGRU (module.py:59-66) with the gate math in the conv epilogues: the update and reset gates read the same
         input -> one launch, two results (z -> ``zbuf``, r*h -> ``hx2``); then q and the state update (-> ``hx``, ``hidden``)"""
         hx, hx2, zbuf = ws["hx"], ws["hx2"], ws["zbuf"]
+        if self.gru_coop:
+            ops.gru_conv(hx, self.gru_zr, self.b_zr, hx[:, :HIDDEN], zbuf, out2=hx2[:, :HIDDEN])
+            ops.gru_conv(hx2, self.gru_q, self.gru_bq, hx[:, :HIDDEN], hx[:, :HIDDEN], out2=ws["hidden"], z=zbuf)
+            return
         ops.conv2d(hx, self.pk_zr, self.b_zr, pad=2, dilation=2, act="sigmoid", out=zbuf, aux1=hx[:, :HIDDEN],
                    split=(HIDDEN, "gru_rh", hx2[:, :HIDDEN]))
         self._conv(hx2, "iter_mvs.update.gru.convq.", bias=True, pad=2, dilation=2, act="gru_out", aux1=hx[:, :HIDDEN],

@@ -774,6 +774,52 @@ def conv3x3_conv1x1(x: Tensor, w0, w1p: Tensor, bias_p: Optional[Tensor], no: in
     return out
 
 
+def pack_gru_conv_split3(w: Tensor) -> Tensor:
+    """ConvGRU 3x3 weight [NO,43,3,3] (NO = 64: convz and convr stacked; 32: convq) -> the bf16x3 operands of itermvs_gru_conv:
+    bfloat16 [NO/16][9][6][64][8].  Operands 0..2: terms h, m, l of input channel (j // 4) * 16 + 4 q + j % 4 (lane = 16 q + i,
+    output channel 16 ob + i); operands 3..5: channel 32 + 8 (q % 2) + j (zero from 43 on), terms h, m and (l if q < 2 else h)."""
+    no = w.shape[0]
+    if tuple(w.shape[1:]) != (43, 3, 3) or no % 16:
+        raise RuntimeError("pack_gru_conv_split3: expects a [16 k, 43, 3, 3] weight")
+    nob = no // 16
+    wf = w.float().reshape(nob, 16, 43, 9)
+    ta = wf[:, :, :32].reshape(nob, 16, 2, 4, 4, 9).permute(0, 5, 3, 1, 2, 4).reshape(nob, 9, 64, 8)      # [ob, tap, (q, i), (jj, r)]
+    ah, am, al = split_bf16x3(ta)
+    full = torch.zeros((nob, 16, 16, 9), device=w.device, dtype=torch.float32)
+    full[:, :, :11] = wf[:, :, 32:]
+    tb = full.reshape(nob, 16, 2, 8, 9).permute(0, 4, 2, 1, 3)                                             # [ob, tap, half, i, j]
+    tb = torch.stack([tb, tb], 2).reshape(nob, 9, 64, 8)                                                   # q = 2 second + half
+    bh, bm, bl = split_bf16x3(tb)
+    b3 = torch.cat([bl.reshape(nob, 9, 4, 16, 8)[:, :, :2], bh.reshape(nob, 9, 4, 16, 8)[:, :, 2:]], 2).reshape(nob, 9, 64, 8)
+    return torch.stack([ah, am, al, bh, bm, b3], 2).contiguous()
+
+
+def gru_conv(x: Tensor, wp: Tensor, bias: Optional[Tensor], h: Tensor, out: Tensor, out2: Optional[Tensor] = None,
+             z: Optional[Tensor] = None) -> None:
+    """itermvs_gru_conv.  ``z`` None: the update / reset gates (``wp`` [4,9,6,64,8]): x = [h | inputs] [B,43,H,W] ->
+    out = z, out2 = r * h.  ``z`` given: the candidate state and the update (``wp`` [2,9,6,64,8]): x = [r*h | inputs] ->
+    out (= out2 if given) = (1 - z) h + z tanh(convq(x))  (models/module.py:59-66)."""
+    px, sx = _planes(x, "gru_conv input")
+    b, c, hh, ww = x.shape
+    mode = 0 if z is None else 1
+    nob = 4 if mode == 0 else 2
+    if c != 43 or not (wp.is_cuda and wp.dtype == torch.bfloat16 and tuple(wp.shape) == (nob, 9, 6, 64, 8) and wp.is_contiguous()):
+        raise RuntimeError("gru_conv: expects a 43-channel input and the weights of pack_gru_conv_split3")
+    if bias is not None and bias.numel() != 16 * nob:
+        raise RuntimeError("gru_conv: bias size")
+    if mode == 0 and out2 is None:
+        raise RuntimeError("gru_conv: the gate form needs both outputs")
+    for t in (h, out, out2, z):
+        if t is not None and tuple(t.shape) != (b, 32, hh, ww):
+            raise RuntimeError(f"gru_conv: expected [B,32,H,W] tensors, got {tuple(t.shape)}")
+    ph, sh = _planes(h, "gru_conv h")
+    po, so = _planes(out, "gru_conv out")
+    po2, so2 = _planes(out2, "gru_conv out2") if out2 is not None else (None, 0)
+    pz, sz = _planes(z, "gru_conv z") if z is not None else (None, 0)
+    check(_lib.load().itermvs_gru_conv(px, sx, b, hh, ww, mode, wp.data_ptr(), _ptr(bias), ph, sh, pz, sz, po, so, po2, so2, _stream()),
+          "itermvs_gru_conv")
+
+
 def head_regress(x: Tensor, w1p: Tensor, w2p: Tensor, bias2: Tensor,
                  nd_out: Optional[Sequence[Tuple[Tensor, int]]] = None, want_best: bool = False):
     """itermvs_head_regress: x [B,32,H,W] (after depth_head[0:2]) -> normalised depth (and arg-max bin),

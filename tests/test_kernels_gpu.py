@@ -961,3 +961,60 @@ def test_conv3x3_conv1x1_one_launch_matches_torch(head, size):
     assert torch.equal(wide3[:, 2:2 + no], got3) and float((wide3[:, :2] - 7.0).abs().max()) == 0.0 and float((wide3[:, 2 + no:] - 7.0).abs().max()) == 0.0
     with pytest.raises(RuntimeError):
         ops().conv3x3_conv1x1(x, a0, a1[:1] if a1.shape[0] > 1 else a1[:, :1], bp3, no)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(1, 128, 160), (2, 37, 53), (1, 3, 9), (3, 64, 80)])
+def test_gru_conv_matches_the_torch_gru(size):
+    """itermvs_gru_conv (csrc/gru.hip) against the reference's ConvGRU (models/module.py:53-66: dilated 3x3 gates over
+    [h | normalised depth | scores], 43 channels) in float64: z, r*h and the updated state, bf16x3 arithmetic -- 2e-6 of the
+    pre-activation range on every output; and against the two itermvs_conv2d launches it replaces.  Ragged widths, maps smaller than
+    a tile, more tiles than workgroups, outputs written into channel slices of wider buffers, the state updated in place"""
+    import torch.nn.functional as F
+    b, h, w = size
+    wts = load_weights("dtu")
+    p = "iter_mvs.update.gru."
+    wz, wr, wq = (cu(wts[p + f"conv{k}.weight"]) for k in "zrq")
+    bz, br, bq = (cu(wts[p + f"conv{k}.bias"]) for k in "zrq")
+    gen = torch.Generator().manual_seed(h * w + 43)
+    hx = torch.randn((b, 43, h, w), generator=gen).to(DEV)
+    hx[:, :32] = torch.tanh(hx[:, :32])
+    hd, xd = hx[:, :32].double(), hx[:, 32:].double()
+    cz = F.conv2d(hx.double(), wz.double(), bz.double(), padding=2, dilation=2)
+    cr = F.conv2d(hx.double(), wr.double(), br.double(), padding=2, dilation=2)
+    z_want, rh_want = torch.sigmoid(cz), torch.sigmoid(cr) * hd
+    wp_zr = ops().pack_gru_conv_split3(torch.cat([wz, wr], 0))
+    wp_q = ops().pack_gru_conv_split3(wq)
+    assert wp_zr.dtype == torch.bfloat16 and tuple(wp_zr.shape) == (4, 9, 6, 64, 8) and tuple(wp_q.shape) == (2, 9, 6, 64, 8)
+    # operands 0..2 add up to the weights of channels 0..31, operands 3, 4 and the l half of 5 to those of 32..42
+    back = wp_q[:, :, :3].float().sum(2).reshape(2, 9, 4, 16, 2, 4).permute(0, 3, 4, 2, 5, 1).reshape(32, 32, 3, 3)
+    assert torch.equal(back, wq[:, :32])
+    tail = (wp_q[:, :, 3].float() + wp_q[:, :, 4].float() + wp_q[:, :, 5].float()).reshape(2, 9, 4, 16, 8)[:, :, :2]   # [ob, tap, half, i, j]
+    assert torch.equal(tail.permute(0, 3, 2, 4, 1).reshape(32, 16, 3, 3)[:, :11], wq[:, 32:])
+    hx2 = torch.full((b, 45, h, w), 7.0, device=DEV)
+    hx2[:, 33:44] = hx[:, 32:]
+    zbuf = torch.empty((b, 32, h, w), device=DEV)
+    ops().gru_conv(hx, wp_zr, torch.cat([bz, br]), hx[:, :32], zbuf, out2=hx2[:, 1:33])
+    scale = float(max(cz.abs().max(), cr.abs().max()))
+    assert float((zbuf.double() - z_want).abs().max()) <= 2e-6 * scale
+    assert float((hx2[:, 1:33].double() - rh_want).abs().max()) <= 2e-6 * scale
+    assert float((hx2[:, :1] - 7.0).abs().max()) == 0.0 and float((hx2[:, 44:] - 7.0).abs().max()) == 0.0
+    assert torch.equal(hx2[:, 33:44], hx[:, 32:])
+    # the second convolution on what the first produced
+    x2 = hx2[:, 1:44].contiguous()
+    cq = F.conv2d(x2.double(), wq.double(), bq.double(), padding=2, dilation=2)
+    h_want = (1.0 - zbuf.double()) * hd + zbuf.double() * torch.tanh(cq)
+    state = hx.clone()
+    hidden = torch.empty((b, 32, h, w), device=DEV)
+    ops().gru_conv(x2, wp_q, bq, state[:, :32], state[:, :32], out2=hidden, z=zbuf)
+    assert float((hidden.double() - h_want).abs().max()) <= 2e-6 * float(cq.abs().max())
+    assert torch.equal(state[:, :32], hidden) and torch.equal(state[:, 32:], hx[:, 32:])
+    # the two launches of the LDS-tiled kernels it replaces (exact fp32 gates, bf16x3 candidate)
+    pk_zr = ops().MfmaWeight(torch.cat([wz, wr], 0), split3=False)
+    z_old, rh_old = torch.empty_like(zbuf), torch.empty_like(zbuf)
+    ops().conv2d(hx, pk_zr, torch.cat([bz, br]), pad=2, dilation=2, act="sigmoid", out=z_old, aux1=hx[:, :32], split=(32, "gru_rh", rh_old))
+    assert float((z_old - zbuf).abs().max()) <= 2e-6 * scale and float((rh_old - hx2[:, 1:33]).abs().max()) <= 2e-6 * scale
+    with pytest.raises(RuntimeError):
+        ops().gru_conv(hx, wp_q, torch.cat([bz, br]), hx[:, :32], zbuf, out2=hx2[:, 1:33])
+    with pytest.raises(RuntimeError):
+        ops().gru_conv(hx[:, :40], wp_zr, None, hx[:, :32], zbuf, out2=hx2[:, 1:33])
