@@ -58,11 +58,10 @@ constexpr int kW3 = kW2 + 9 * 4 * 4 * 32;      // conv3 (transposed): 9 x 8 x 4 
 constexpr int kW4 = kW3 + 9 * 8 * 4 * 16;      // conv4 (transposed): 9 x 4 x 4 x 16
 constexpr int kW5 = kW4 + 9 * 4 * 4 * 16;      // conv5: [ci 8][tap 9], then the bias
 constexpr int kWBias = kW5 + 72;
-constexpr int kCnWeightFloats = kWBias + 8;
+static_assert(kWBias + 8 <= kSzW, "the fp32 weight set (ops.CORRNET_WEIGHT_FLOATS) must fit the weight buffer");
 // bf16x3 form (corrnet_kernel<true>): conv0's weights as bf16 A operands of v_mfma_f32_16x16x32_bf16 -- [18 MFMAs][64 lanes][8 bf16]
 // = 4608 floats -- in front of the same layers 1..5 (ops.pack_corrnet_weights(split3=True))
 constexpr int kW0Split = 18 * 64 * 4;
-constexpr int kSplitShift = kW0Split - (kW1 - kW0);        // every later offset moves by this much
 static_assert(kW0Split <= kSzW, "conv0's split weights must fit the weight buffer");
 constexpr int kXPlaneB = XS * XP * 16;                     // bytes of one bf16 plane of the x tile: [row 45][col 46][8 channels]
 static_assert(2 * kXPlaneB <= kSzX * 4 && kXPlaneB <= kSzC0 * 4, "planes h, m of x must fit the x region, plane l the c0 region");

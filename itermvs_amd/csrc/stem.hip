@@ -27,8 +27,8 @@ typedef __attribute__((address_space(4))) float ConstF;      // constant address
 
 constexpr int kStTW = 32;                                // output tile: TH x 32 (half resolution), TH = 8 or 4
 constexpr int kStThreads = 256;
-constexpr int kStIC = 2 * kStTW + 3, kStIP = 68;         // image patch columns / pitch
-constexpr int kStFC = 2 * kStTW + 1, kStFP = 66;         // f0 patch columns / pitch
+constexpr int kStIP = 68;                                // pitch of the image patch (2 * 32 + 3 columns)
+constexpr int kStFP = 66;                                // pitch of the f0 patch (2 * 32 + 1 columns)
 
 struct StemArgs {
     const float* x;

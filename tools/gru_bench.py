@@ -1,13 +1,16 @@
 """Same-box timing of the ConvGRU's two convolutions: the LDS-tiled launches (conv_tile fp32 gates, conv_tile3 candidate) against
-itermvs_gru_conv (csrc/gru.hip), 20 iterations per hipGraph replay, best of several:   python tools/gru_bench.py [reps]"""
+itermvs_gru_conv (csrc/gru.hip), 20 iterations per hipGraph replay, best of several:   python tools/gru_bench.py [reps] [--lib variant.so]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from itermvs_amd import _lib
+if "--lib" in sys.argv:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from itermvs_amd import ops, synthetic
 from itermvs_amd.engine import InferenceEngine
 from itermvs_amd.net import Pipeline
 
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10
 dev = torch.device("cuda:0")
 
 
