@@ -58,7 +58,6 @@ constexpr int kW3 = kW2 + 9 * 4 * 4 * 32;      // conv3 (transposed): 9 x 8 x 4 
 constexpr int kW4 = kW3 + 9 * 8 * 4 * 16;      // conv4 (transposed): 9 x 4 x 4 x 16
 constexpr int kW5 = kW4 + 9 * 4 * 4 * 16;      // conv5: [ci 8][tap 9], then the bias
 constexpr int kWBias = kW5 + 72;
-static_assert(kWBias + 8 <= kSzW, "the fp32 weight set (ops.CORRNET_WEIGHT_FLOATS) must fit the weight buffer");
 // bf16x3 form (corrnet_kernel<true>): conv0's weights as bf16 A operands of v_mfma_f32_16x16x32_bf16 -- [18 MFMAs][64 lanes][8 bf16]
 // = 4608 floats -- in front of the same layers 1..5 (ops.pack_corrnet_weights(split3=True))
 constexpr int kW0Split = 18 * 64 * 4;
