@@ -413,7 +413,7 @@ class InferenceEngine:
         """ConvGRU (module.py:59-66) with the gate math in the conv epilogues: the update and reset gates read the same
         input -> one launch, two results (z -> ``zbuf``, r*h -> ``hx2``); then q and the state update (-> ``hx``, ``hidden``)"""
         hx, hx2, zbuf = ws["hx"], ws["hx2"], ws["zbuf"]
-        if self.gru_coop:
+        if self.gru_coop and hx.shape[1] * hx.shape[2] * hx.shape[3] * 4 <= 1 << 29:      # (its 32-bit buffer offsets: maps up to 3.1 M pixels)
             ops.gru_conv(hx, self.gru_zr, self.b_zr, hx[:, :HIDDEN], zbuf, out2=hx2[:, :HIDDEN])
             ops.gru_conv(hx2, self.gru_q, self.gru_bq, hx[:, :HIDDEN], hx[:, :HIDDEN], out2=ws["hidden"], z=zbuf)
             return
