@@ -53,6 +53,38 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& H, uint
     L = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
 }
 
+
+// Reductions over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15 of a wave) on the VALU's data-parallel-primitive path:
+// quad_perm (lane ^ 1, lane ^ 2), row_half_mirror (quad 0 <-> 1, 2 <-> 3 once the quads are uniform), row_mirror (the two halves).
+// Every step combines a lane with a partner that holds the other half of the step's group, so a commutative operation gives all 16
+// lanes the bits an xor butterfly (__shfl_xor 1, 2, 4, 8 = four LDS-crossbar round trips) gives them.
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int row_dpp(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true); }
+constexpr int kDppXor1 = 0xb1, kDppXor2 = 0x4e, kDppHalfMirror = 0x141, kDppMirror = 0x140;   // quad_perm [1,0,3,2], [2,3,0,1]
+constexpr int kDppRowShl = 0x100;                                                             // + n: lane l reads lane l + n of its row
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, row_dpp<kDppXor1>(v));
+    v = fmaxf(v, row_dpp<kDppXor2>(v));
+    v = fmaxf(v, row_dpp<kDppHalfMirror>(v));
+    return fmaxf(v, row_dpp<kDppMirror>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += row_dpp<kDppXor1>(v);
+    v += row_dpp<kDppXor2>(v);
+    v += row_dpp<kDppHalfMirror>(v);
+    return v + row_dpp<kDppMirror>(v);
+}
+__device__ __forceinline__ int row16_sum(int v) {
+    v += row_dpp<kDppXor1>(v);
+    v += row_dpp<kDppXor2>(v);
+    v += row_dpp<kDppHalfMirror>(v);
+    return v + row_dpp<kDppMirror>(v);
+}
+
 }  // namespace itermvs
 
 // compute units of the current device (grid size of persistent kernels)

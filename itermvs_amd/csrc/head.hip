@@ -582,8 +582,7 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
         float m = e[0];
 #pragma unroll
         for (int i = 1; i < 16; ++i) m = fmaxf(m, e[i]);
-#pragma unroll
-        for (int sh = 1; sh <= 8; sh <<= 1) m = fmaxf(m, __shfl_xor(m, sh));
+        m = row16_max(m);             // (the 16 lanes of a pixel are one DPP row)
         float s = 0.0f, bv = -1.0f;
         int bi = 0;
 #pragma unroll
@@ -595,18 +594,14 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
                 bi = t * 16 + i;
             }
         }
-#pragma unroll
-        for (int sh = 1; sh <= 8; sh <<= 1) s += __shfl_xor(s, sh);
-        float gm = bv;
-#pragma unroll
-        for (int sh = 1; sh <= 8; sh <<= 1) gm = fmaxf(gm, __shfl_xor(gm, sh));
+        s = row16_sum(s);
+        const float gm = row16_max(bv);
         // first arg-max of p = e / s: see head_tail (quotients compared only when another bin lies within 2^-22 of the maximum)
         const float thresh = gm * 0.99999976f;
         int close = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) close += e[i] >= thresh ? 1 : 0;
-#pragma unroll
-        for (int sh = 1; sh <= 8; sh <<= 1) close += __shfl_xor(close, sh);
+        close = row16_sum(close);
         float bp = bv;
         if (__any(close > 1)) {         // wave-uniform, rare
             bp = -1.0f;
@@ -619,15 +614,16 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
                 }
             }
         }
-#pragma unroll
-        for (int sh = 1; sh <= 8; sh <<= 1) {
-            const float op = __shfl_xor(bp, sh);
-            const int oi = __shfl_xor(bi, sh);
+        auto take_better = [&](float op, int oi) {
             if (op > bp || (op == bp && oi < bi)) {
                 bp = op;
                 bi = oi;
             }
-        }
+        };
+        take_better(row_dpp<kDppXor1>(bp), row_dpp<kDppXor1>(bi));
+        take_better(row_dpp<kDppXor2>(bp), row_dpp<kDppXor2>(bi));
+        take_better(row_dpp<kDppHalfMirror>(bp), row_dpp<kDppHalfMirror>(bi));
+        take_better(row_dpp<kDppMirror>(bp), row_dpp<kDppMirror>(bi));
         // window k*-4 .. k*+4 (clamped; border duplicates double-counted): lane i < 9 of the pixel's 16 lanes fetches its bin
         // back from LDS as e, the nine terms are then summed in window order by lane 0 (the arithmetic of prob_regress_kernel)
         const int lo = bi - ITERMVS_WINDOW_RADIUS;
@@ -635,9 +631,16 @@ __global__ void __launch_bounds__(256, 2) head_coop_kernel(const FusedArgs a, co
         kbin = kbin < 0 ? 0 : (kbin > kHeadBins - 1 ? kHeadBins - 1 : kbin);
         const float pk_mine = __expf(LG[pl * kCoLgStride + kbin] - m) / s;
         float num = 0.0f, den = 1e-6f;   // itermvs.py:212
+        float pkw[kHeadWin];            // lane 0 of the pixel's row: the probabilities of lanes 0 .. 8 (row_shl: lane l reads lane l + i)
+        pkw[0] = pk_mine;
+        pkw[1] = row_dpp<kDppRowShl + 1>(pk_mine); pkw[2] = row_dpp<kDppRowShl + 2>(pk_mine);
+        pkw[3] = row_dpp<kDppRowShl + 3>(pk_mine); pkw[4] = row_dpp<kDppRowShl + 4>(pk_mine);
+        pkw[5] = row_dpp<kDppRowShl + 5>(pk_mine); pkw[6] = row_dpp<kDppRowShl + 6>(pk_mine);
+        pkw[7] = row_dpp<kDppRowShl + 7>(pk_mine); pkw[8] = row_dpp<kDppRowShl + 8>(pk_mine);
+        static_assert(kHeadWin == 9, "window of nine bins");
 #pragma unroll
         for (int i = 0; i < kHeadWin; ++i) {
-            const float pk = __shfl(pk_mine, (lane & 48) + i);
+            const float pk = pkw[i];
             int k = lo + i;
             k = k < 0 ? 0 : (k > kHeadBins - 1 ? kHeadBins - 1 : k);
             num = num + (float)k * pk;
