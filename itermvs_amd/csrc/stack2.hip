@@ -63,26 +63,6 @@ __global__ void __launch_bounds__(256, 2) stack2_coop_kernel(const Stack2Args a,
     const int q = lane >> 4, l16 = lane & 15;
     const uint32_t plane = (uint32_t)(a.H * a.W);
 
-    // this wave's split weight slices -> registers, once
-    bf8 wc[9][2], w1r[kS2MaxOB][2][3];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) wc[tap][pl] = reinterpret_cast<const bf8*>(a.w0t)[((wave * 9 + tap) * 3 + pl) * 64 + lane];
-        reinterpret_cast<bf8*>(WL3)[(wave * 9 + tap) * 64 + lane] = reinterpret_cast<const bf8*>(a.w0t)[((wave * 9 + tap) * 3 + 2) * 64 + lane];
-    }
-    if (tid < kS2MaxOB * 4 * 16) BS3[tid] = (a.bias && tid < a.NOB * 16) ? a.bias[tid] : 0.0f;
-#pragma unroll
-    for (int k = 0; k < kS2MaxOB; ++k) {
-        const int ob = wave + 4 * k;
-        const bool on = ob < a.NOB;          // wave-uniform
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                w1r[k][g][pl] = reinterpret_cast<const bf8*>(a.w1p)[(((on ? ob : 0) * 2 + g) * 3 + pl) * 64 + lane];
-    }
-
     // staging: item = (q, row, column) of the 3 x 18 halo tile = the lane-q channels {4q .. 4q+3, 16+4q .. 16+4q+3} of one pixel
     const int it_q = tid / 54, it_r = tid - it_q * 54;
     const int it_row = it_r / 18, it_col = it_r - it_row * 18;
@@ -115,10 +95,29 @@ __global__ void __launch_bounds__(256, 2) stack2_coop_kernel(const Stack2Args a,
     };
 
     int tile = blockIdx.x, buf = 0;
-    if (tile < tiles_total) {
-        fetch(tile);
-        stash(smem3);
+    if (tile < tiles_total) fetch(tile);            // the first tile's loads go out in front of the weights' (loads return in order)
+
+    // this wave's split weight slices -> registers, once
+    bf8 wc[9][2], w1r[kS2MaxOB][2][3];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wc[tap][pl] = reinterpret_cast<const bf8*>(a.w0t)[((wave * 9 + tap) * 3 + pl) * 64 + lane];
+        reinterpret_cast<bf8*>(WL3)[(wave * 9 + tap) * 64 + lane] = reinterpret_cast<const bf8*>(a.w0t)[((wave * 9 + tap) * 3 + 2) * 64 + lane];
     }
+    if (tid < kS2MaxOB * 4 * 16) BS3[tid] = (a.bias && tid < a.NOB * 16) ? a.bias[tid] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < kS2MaxOB; ++k) {
+        const int ob = wave + 4 * k;
+        const bool on = ob < a.NOB;          // wave-uniform
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                w1r[k][g][pl] = reinterpret_cast<const bf8*>(a.w1p)[(((on ? ob : 0) * 2 + g) * 3 + pl) * 64 + lane];
+    }
+
+    if (tile < tiles_total) stash(smem3);
     if (tile + (int)gridDim.x < tiles_total) fetch(tile + gridDim.x);
     for (; tile < tiles_total; tile += gridDim.x, buf ^= 1) {
         __syncthreads();            // this tile's staging is visible; the previous tile's readers of Y are done
