@@ -16,7 +16,7 @@ import sys
 
 root, out = sys.argv[1:3]
 KEEP = ("lat_conv_kernel", "res_chain16_kernel", "corr_iter", "corr_init", "corrnet_kernel", "lateral_up2_kernel", "conv_tile_kernel", "conv_tile3_kernel", "deconv_tile_kernel", "conv_mfma", "conv_direct_kernel",
-        "head_fused", "head_coop", "stem_kernel", "softmax_max", "view_aggregate", "ref_quarter", "convex_upsample")
+        "head_fused", "head_coop", "gru_conv_kernel", "stack2_coop", "stem_kernel", "softmax_max", "view_aggregate", "ref_quarter", "convex_upsample")
 
 
 def short(name: str) -> str:
