@@ -47,6 +47,7 @@ struct GruConvArgs {
     float* out2;             // mode 0: r * h; mode 1: second copy of h' or nullptr
     int64_t out2_sb;
     int H, W, tiles_x;
+    int run, run_extra;      // a workgroup's run of tiles: tiles / grid, the first tiles % grid workgroups one more
 };
 
 // A pair of tiles -- rows y and y + 2 of one column tile -- and where its image rows sit
@@ -85,8 +86,8 @@ __global__ void __launch_bounds__(kGcThreads) gru_conv_kernel(const GruConvArgs 
 
     // this workgroup's run of tiles
     const int g = banded ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int t0 = (int)((int64_t)tiles_total * g / gridDim.x);
-    int left = (int)((int64_t)tiles_total * (g + 1) / gridDim.x) - t0;           // tiles not yet given to a pair
+    const int t0 = g * a.run + min(g, a.run_extra);           // (no 64-bit division in the prologue: the host splits the tile list)
+    int left = a.run + (g < a.run_extra ? 1 : 0);             // tiles not yet given to a pair
     auto row_of = [&](int k) { return k < He ? 2 * k : 2 * (k - He) + 1; };
     auto second_ok = [&](int k) { return left > 1 && k + 1 != He && k + 1 != a.H; };
     auto advance = [&](GruPair t) {             // the pair after t; takes its tiles from ``left``
@@ -334,6 +335,7 @@ extern "C" int itermvs_gru_conv(const float* x, int64_t x_sb, int32_t B, int32_t
     const int cus = itermvs_num_cus();                       // one 8-wave workgroup per CU (256 registers per lane)
     int grid = (int)(tiles < cus ? tiles : cus);
     if (grid >= 16) grid &= ~7;
+    a.run = (int)(tiles / grid); a.run_extra = (int)(tiles % grid);
     const int banded = grid % 8 == 0;     // workgroup b runs on XCD b % 8: neighbouring runs of tiles on one XCD
     if (mode == 0) hipLaunchKernelGGL(gru_conv_kernel<4>, dim3(grid), dim3(kGcThreads), kGcLds, (hipStream_t)stream, a, (int)tiles, banded);
     else hipLaunchKernelGGL(gru_conv_kernel<2>, dim3(grid), dim3(kGcThreads), kGcLds, (hipStream_t)stream, a, (int)tiles, banded);

@@ -27,9 +27,8 @@ for mode in (0, 1):
             ops.gru_conv(hx, wq, bias[:32], hid, rh, z=zb)
     torch.cuda.synchronize()
     t = st.view(8, 64).cpu()
-    names = ["weights issued (+ first fetch)", "first stash + second fetch"] + ["barrier", "matrix work + P", "epilogue (previous tile)", "operands + stash + fetch"] * 5 + ["barrier", "last epilogue"]
-    print("mode", mode)
+    print("mode", mode, "(stamps: start | per pair: before barrier, after barrier, matrix done, P stored, epilogue + operands done, loads waited, stashed, advanced, fetch issued)")
     for wv in (0, 3, 4, 7):
         row = t[wv]
-        d = [int(row[j + 1] - row[j]) for j in range(24)]
-        print(f"wave {wv}: " + " | ".join(f"{names[j]} {d[j]}" for j in range(24)) + f" | total {int(row[24] - row[0])}")
+        n = int((row != 0).sum())
+        print(f"wave {wv}: " + " ".join(str(int(row[j + 1] - row[j])) for j in range(n - 1)) + f" | total {int(row[n - 1] - row[0])}")
