@@ -197,6 +197,33 @@ def test_weight_packings_of_the_fused_kernels():
     assert pk[idx0 + co] == c0[co, 4 * ks + q, 0, kx] and pk[idx0 + 8 + co] == 0
 
 
+def test_gru_conv_weight_packing():
+    """pack_gru_conv_split3 lays the ConvGRU weights out as include/itermvs_hip.h documents for itermvs_gru_conv (CPU, no launch):
+    three exact bf16 terms per weight; channels 0..31 as one term per operand, channels 32..42 as the two-term operands
+    A1 = [h | h], A2 = [m | m], A3 = [l | h]"""
+    from itermvs_amd import ops
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn((64, 43, 3, 3), generator=g)
+    wp = ops.pack_gru_conv_split3(w)
+    assert wp.dtype == torch.bfloat16 and tuple(wp.shape) == (4, 9, 6, 64, 8)
+    f = wp.float()
+    back = f[:, :, :3].sum(2).reshape(4, 9, 4, 16, 2, 4).permute(0, 3, 4, 2, 5, 1).reshape(64, 32, 3, 3)       # (ob, i), (jj, q, r), tap
+    assert torch.equal(back, w[:, :32])
+    ob, tap, q, i, j = 2, 5, 3, 7, 6                     # lane 16 q + i, slot j: channel (j // 4) * 16 + 4 q + j % 4
+    c = (j // 4) * 16 + 4 * q + j % 4
+    assert float(f[ob, tap, :3, 16 * q + i, j].sum()) == float(w[16 * ob + i, c, tap // 3, tap % 3])
+    b = f[:, :, 3:].reshape(4, 9, 3, 2, 2, 16, 8)        # [ob, tap, operand, second, half, i, j]
+    assert torch.equal(b[:, :, 0, 0], b[:, :, 0, 1]) and torch.equal(b[:, :, 1, 0], b[:, :, 1, 1])             # A1 = [h | h], A2 = [m | m]
+    assert torch.equal(b[:, :, 2, 1], b[:, :, 0, 0])                                                            # A3 = [l | h]
+    tail = (b[:, :, 0, 0] + b[:, :, 1, 0] + b[:, :, 2, 0]).permute(0, 3, 2, 4, 1).reshape(64, 16, 3, 3)         # (ob, i), (half, j), tap
+    assert torch.equal(tail[:, :11], w[:, 32:]) and float(tail[:, 11:].abs().max()) == 0.0
+    assert tuple(ops.pack_gru_conv_split3(w[:32]).shape) == (2, 9, 6, 64, 8)
+    with pytest.raises(RuntimeError):
+        ops.pack_gru_conv_split3(w[:, :40])
+    with pytest.raises(RuntimeError):
+        ops.pack_gru_conv_split3(w[:24])
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "itermvs_amd")
     for fn in os.listdir(pkg):
