@@ -520,15 +520,20 @@ __global__ void __launch_bounds__(kCnThreads) corrnet_kernel(const CorrNetArgs a
         // zeros), up to 3 per thread.  (A form with aligned 16-byte loads -- 540 threads x 8 planes x float4, four positions
         // split per thread -- measured 25.2 us per launch against 23.9 us: the split arithmetic of a position is the
         // long pole of this phase and spreads better over all 1024 threads.)
+        // (buffer loads: one vector offset per position -- out of range where the zero padding is --, the channel plane in the scalar
+        //  offset: the phase is bound by its vector instructions, 16 waves per CU computing 64-bit addresses and predicates)
         float v[3][8];
+        const uint32_t plane_b = (uint32_t)(H * W) * 4u;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xm, 0, (int)(8u * plane_b), 0x00020000);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int p = tid + k * kCnThreads;
             const int ry = p / XP, rx = p - ry * XP;
             const int gy = Y0 - 8 + ry, gx = X0 - 8 + rx;
             const bool ok = p < XS * XP && rx < XS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const uint32_t vo = ok ? (uint32_t)(gy * W + gx) * 4u : 0x7fffffffu;
 #pragma unroll
-            for (int ci = 0; ci < 8; ++ci) v[k][ci] = ok ? xm[(int64_t)ci * H * W + gy * W + gx] : 0.0f;
+            for (int ci = 0; ci < 8; ++ci) v[k][ci] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vo, (uint32_t)ci * plane_b, 0));
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -722,6 +727,7 @@ static int launch_corrnet(const float* x, int64_t x_sn, const float* const* weig
                           void* stream) {
     ITERMVS_RETURN_IF(!x || !weights || !out, ITERMVS_ERR_NULL);
     ITERMVS_RETURN_IF(M < 1 || H < 4 || W < 4 || (H & 3) || (W & 3) || n_seg < 1 || n_seg > 3, ITERMVS_ERR_DIMS);
+    ITERMVS_RETURN_IF((int64_t)8 * H * W * 4 >= ((int64_t)1 << 31), ITERMVS_ERR_DIMS);      // 32-bit buffer offsets within a map
     CorrNetArgs a;
     a.x = x; a.x_sn = x_sn;
     for (int i = 0; i < 3; ++i) {
