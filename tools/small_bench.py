@@ -1,8 +1,13 @@
 """Same-box timings of the small launches around the GRU loop and of their fused replacements (round 6), each as 20 launches per
-hipGraph replay, best of several replays:   python tools/small_bench.py [reps]"""
+hipGraph replay, best of several replays:   python tools/small_bench.py [reps] [--lib other.so]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from itermvs_amd import _lib
+if "--lib" in sys.argv:
+    _i = sys.argv.index("--lib")
+    _lib.LIB_PATH = os.path.abspath(sys.argv[_i + 1])
+    del sys.argv[_i:_i + 2]
 from itermvs_amd import ops, synthetic
 from itermvs_amd.engine import InferenceEngine
 from itermvs_amd.net import Pipeline
