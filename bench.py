@@ -498,7 +498,7 @@ def main() -> None:
         ops.profile_enable(0)
         if conv_ms and len(conv_ms) == ops.CONV_FLOP_COUNTER["launches"]:
             tf = ops.CONV_FLOP_COUNTER["flops"] / (sum(conv_ms) * 1e-3) / 1e12
-            conv_roofline = {"bound": "mfma", "kernel": "itermvs_conv2d (conv_tile3_kernel / conv_tile_kernel / conv_mfma_kernel / lateral_up2_kernel) + itermvs_res_chain16 + itermvs_lateral_conv3x3",
+            conv_roofline = {"bound": "mfma", "kernel": "itermvs_conv2d (conv_tile3_kernel / conv_tile_kernel / conv_mfma_kernel / lateral_up2_kernel) + itermvs_res_chain16 + itermvs_lateral_conv3x3 + itermvs_gru_conv",
                              "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
                              "launches_per_step": len(conv_ms) // n_extra, "ms_per_step": sum(conv_ms) / n_extra,
                              "gflop_per_step": ops.CONV_FLOP_COUNTER["flops"] / n_extra / 1e9,

@@ -337,7 +337,9 @@ extern "C" int itermvs_gru_conv(const float* x, int64_t x_sb, int32_t B, int32_t
     if (grid >= 16) grid &= ~7;
     a.run = (int)(tiles / grid); a.run_extra = (int)(tiles % grid);
     const int banded = grid % 8 == 0;     // workgroup b runs on XCD b % 8: neighbouring runs of tiles on one XCD
+    itermvs_profile_begin(3, (hipStream_t)stream);          // bench.py's convolution roofline brackets this launch like an itermvs_conv2d one
     if (mode == 0) hipLaunchKernelGGL(gru_conv_kernel<4>, dim3(grid), dim3(kGcThreads), kGcLds, (hipStream_t)stream, a, (int)tiles, banded);
     else hipLaunchKernelGGL(gru_conv_kernel<2>, dim3(grid), dim3(kGcThreads), kGcLds, (hipStream_t)stream, a, (int)tiles, banded);
+    itermvs_profile_end(3, (hipStream_t)stream);
     return itermvs_launch_status();
 }

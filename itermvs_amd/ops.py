@@ -818,6 +818,9 @@ def gru_conv(x: Tensor, wp: Tensor, bias: Optional[Tensor], h: Tensor, out: Tens
     pz, sz = _planes(z, "gru_conv z") if z is not None else (None, 0)
     check(_lib.load().itermvs_gru_conv(px, sx, b, hh, ww, mode, wp.data_ptr(), _ptr(bias), ph, sh, pz, sz, po, so, po2, so2, _stream()),
           "itermvs_gru_conv")
+    if CONV_FLOP_COUNTER["enabled"]:         # the dilated 3x3 layer(s) over the 43 input channels, one bracketed launch
+        CONV_FLOP_COUNTER["flops"] += 2.0 * b * hh * ww * 16 * nob * 43 * 9
+        CONV_FLOP_COUNTER["launches"] += 1
 
 
 def head_regress(x: Tensor, w1p: Tensor, w2p: Tensor, bias2: Tensor,
